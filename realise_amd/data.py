@@ -1,0 +1,61 @@
+"""SIGHAN-shaped synthetic batches.
+
+Produces exactly the dict ``make_features`` + ``build_batch`` hand to
+``model(batch)`` in the reference trainer (src/run.py:68-101,
+src/models.py:797-804): ``src_idx / tgt_idx / masks / loss_masks`` int64
+[B,S], ``pho_idx`` int64 [B*S, Tp], ``pho_lens`` python list (host) of B*S ints,
+plus the python-list keys the model ignores.
+"""
+import numpy as np
+import torch
+
+CLS, SEP, PAD = 101, 102, 0
+PHO_UNK = 32  # 'U' in Pinyin2's vocab (src/utils.py:61-67)
+
+
+def synthetic_batch(batch_size, seq_len, vocab_size=21128, seed=0, with_pho=True, full_length=False,
+                    id_lo=670, id_hi=7992):
+    g = np.random.Generator(np.random.Philox(key=[0x5EA115E, seed]))
+    id_hi = min(id_hi, vocab_size)
+    id_lo = min(id_lo, max(1, id_hi - 1))
+    max_chars = seq_len - 2
+    lo = max(1, min(32, max_chars // 4))
+    src = np.zeros((batch_size, seq_len), np.int64)
+    tgt = np.zeros((batch_size, seq_len), np.int64)
+    masks = np.zeros((batch_size, seq_len), np.int64)
+    loss_masks = np.zeros((batch_size, seq_len), np.int64)
+    lengths = []
+    for b in range(batch_size):
+        L = max_chars if full_length else int(g.integers(lo, max_chars + 1))
+        ids = g.integers(id_lo, id_hi, size=L)
+        row = np.concatenate([[CLS], ids, [SEP]])
+        src[b, :L + 2] = row
+        t = row.copy()
+        flip = g.random(L) < 0.02
+        t[1:L + 1] = np.where(flip, g.integers(id_lo, id_hi, size=L), ids)
+        tgt[b, :L + 2] = t
+        masks[b, :L + 2] = 1
+        loss_masks[b, 1:L + 1] = 1          # run.py:86-92
+        lengths.append(L)
+    batch = {
+        "src_idx": torch.from_numpy(src), "tgt_idx": torch.from_numpy(tgt),
+        "masks": torch.from_numpy(masks), "loss_masks": torch.from_numpy(loss_masks),
+        "lengths": lengths, "tokens_size": [[1] * l for l in lengths],
+        "id": list(range(batch_size)), "src": [""] * batch_size, "tgt": [""] * batch_size,
+    }
+    if with_pho:
+        flat = src.reshape(-1)
+        is_char = (flat != CLS) & (flat != SEP) & (flat != PAD)
+        n = flat.shape[0]
+        lens = np.where(is_char, g.integers(2, 8, size=n), 1)
+        tp = int(lens.max())
+        pho = np.zeros((n, tp), np.int64)
+        tone = g.integers(1, 6, size=n)
+        letters = g.integers(6, 32, size=(n, tp))
+        for t in range(tp):
+            v = tone if t == 0 else letters[:, t]
+            pho[:, t] = np.where(lens > t, v, 0)
+        pho[~is_char, 0] = PHO_UNK
+        batch["pho_idx"] = torch.from_numpy(pho)
+        batch["pho_lens"] = [int(x) for x in lens]
+    return batch
