@@ -1,0 +1,167 @@
+/*
+ * realise_hip.h - C ABI of the MI355X-native ReaLiSe hot path (librealise_hip.so).
+ *
+ * The reference (DaDaMrX/ReaLiSe) is 100 % Python on PyTorch; there is no FFI layer in it.  The
+ * boundary this library sits behind is the nn.Module protocol of `SpellBertPho2ResArch3` /
+ * `SpellBert` (src/models.py:652-870, :32-73) as consumed by src/run.py:191,200,258.  Each entry
+ * point below names the reference call site(s) it replaces.  All pointers are DEVICE pointers
+ * unless stated otherwise; `stream` is a hipStream_t; no torch types cross this boundary.
+ * Every function returns 0 on success, non-zero on error (1 = bad argument, 2 = launch failure).
+ * dtype: 0 = float32 (exact-fp32 parity mode, v_mfma_f32_16x16x4_f32), 1 = bfloat16 (speed mode,
+ * v_mfma_f32_16x16x32_bf16; fp32 accumulation / statistics).
+ */
+#ifndef REALISE_HIP_H
+#define REALISE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REALISE_F32 0
+#define REALISE_BF16 1
+
+/* ------------------------------------------------------------------------------------------
+ * Fine-grained operators (each one kernel family).  Used by the engine and by the parity tests.
+ * ---------------------------------------------------------------------------------------- */
+
+/* Epilogue of realise_gemm_nt / realise_conv_nt.  mode: 0 store(+bias,+accumulate), 1 bias+erf-GELU
+ * (out2 = pre-activation), 2 dropout(acc+bias)+aux (residual), 4 acc * gelu'(aux). */
+typedef struct {
+  int32_t mode;
+  int32_t accumulate;
+  void* out;
+  int64_t ldo;
+  void* out2;
+  const float* bias;
+  const void* aux;
+  int64_t ldaux;
+  float alpha;
+  uint32_t drop_seed;
+  uint32_t drop_thresh;   /* p * 2^32 ; 0 = no dropout */
+  float drop_scale;       /* 1 / (1 - p) */
+} realise_epilogue;
+
+/* Implicit-im2col geometry over an NHWC tensor: rows are the pixels of an Hr x Wr map, K = KH*KW*C.
+ * mode 0 = forward gather, 1 = data-gradient gather.  img_index (nullable) maps image n to a row
+ * of `src` (glyph lookup char_images_multifonts.index_select, src/models.py:829-834). */
+typedef struct {
+  const void* src;
+  const int64_t* img_index;
+  int32_t rows, Hr, Wr, Hs, Ws, C, KH, KW, stride, pad, mode;
+} realise_conv_geom;
+
+/* C[M,N] = A[M,K] . B[N,K]^T  - nn.Linear forward (modeling_bert.py:221,231-232,273,326,339;
+ * models.py:859), and its data gradient when B is the transposed weight. */
+int realise_gemm_nt(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
+                    int M, int N, int K, const realise_epilogue* ep);
+/* Same with A gathered on the fly: nn.Conv2d forward / input gradient (src/char_cnn.py:15-28). */
+int realise_conv_nt(void* stream, int dtype, const realise_conv_geom* a, const void* B, int64_t ldb,
+                    int M, int N, int K, const realise_epilogue* ep);
+/* out[I,J] += sum_p A[p,i] * B[p,j] (fp32, atomic) - nn.Linear weight gradient. */
+int realise_gemm_tn(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
+                    int P, int I, int J, float* out, int64_t ldo);
+/* Conv2d weight gradient into the reference's [Co][Ci][KH][KW] layout. */
+int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const realise_conv_geom* b,
+                    int P, int Co, int Ci, float* out);
+/* 1: ds_read_b64_tr_b16 transposed operand reads in the TN kernel (bf16), 0: 16-bit LDS gathers. */
+void realise_set_tn_transpose_read(int enable);
+
+/* BertSelfAttention core (modeling_bert.py:239-260): softmax(QK^T/8 + mask_add) -> dropout -> .V
+ * q/k/v: [B*S][ldq] token-major, head h at columns 64h..64h+63; ctx [B*S][ldc]; lse [B][nh][S]. */
+int realise_attention_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ldq,
+                          const float* mask_add, void* ctx, int64_t ldc, float* lse, int B, int nh, int S,
+                          uint32_t drop_seed, uint32_t drop_thresh, float drop_scale);
+int realise_attention_bwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ldq,
+                          const float* mask_add, const void* ctx, const void* dctx, int64_t ldc, const float* lse,
+                          float* rowdot, void* dq, void* dk, void* dv, int64_t ldd, int B, int nh, int S,
+                          uint32_t drop_seed, uint32_t drop_thresh, float drop_scale);
+int realise_mask_to_additive(void* stream, const int64_t* masks, float* out, int n);
+
+/* torch.nn.LayerNorm over the last dim (eps inside the sqrt), y/xhat of `dtype`, rstd fp32. */
+int realise_layernorm_fwd(void* stream, int dtype, const void* x, const float* gamma, const float* beta, float eps,
+                          void* y, void* xhat, float* rstd, int rows, int H);
+int realise_layernorm_bwd(void* stream, int dtype, const void* dy, const void* xhat, const float* rstd,
+                          const float* gamma, void* dx, float* dgamma, float* dbeta, int rows, int H);
+/* CrossEntropyLoss over rows with loss_mask == 1 (src/models.py:862-869); dlogits nullable. */
+int realise_masked_ce(void* stream, int dtype, const void* logits, int64_t ld, const int64_t* labels,
+                      const int64_t* loss_mask, int rows, int V, float* loss_out, float* count_scratch, void* dlogits);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-model engine: SpellBert.forward (models.py:50-73) / SpellBertPho2ResArch3.forward
+ * (models.py:806-870) and their autograd (`loss.backward()`, run.py:200), one C call each.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t model_type;        /* 0 = SpellBert (BERT only), 1 = SpellBertPho2ResArch3 */
+  int32_t dtype;
+  int32_t hidden, heads, intermediate, vocab, max_pos, type_vocab;
+  int32_t bert_layers, pho_layers, out_layers;
+  int32_t num_fonts, glyph_size, pho_vocab;
+  float hidden_dropout, attn_dropout, ln_eps;
+  int32_t tie_classifier;    /* classifier.weight aliases bert word embeddings (models.py:700-701) */
+} realise_config;
+
+/* Parameter layout: the library is the source of truth for where each state_dict tensor of the
+ * reference lives inside five flat arenas:
+ *   0 trainable fp32 (ordered by backward completion, so DDP buckets are contiguous slices)
+ *   1 trainable-but-never-used fp32 (poolers, unused word embeddings: no gradient, as in the reference)
+ *   2 frozen fp32 (char_images_multifonts)   3 fp32 buffers (BN running stats)   4 int64 buffers */
+int realise_layout_count(const realise_config* cfg);
+int realise_layout_entry(const realise_config* cfg, int index, char* name, int name_cap, int32_t* arena,
+                         int64_t* offset, int32_t* ndim, int64_t* shape4);
+int64_t realise_arena_elems(const realise_config* cfg, int arena);
+/* gradient-bucket boundaries (element offsets into arena 0, in backward completion order) */
+int realise_bucket_count(const realise_config* cfg);
+int realise_bucket_bounds(const realise_config* cfg, int bucket, int64_t* begin, int64_t* end);
+
+typedef struct realise_engine realise_engine;
+realise_engine* realise_engine_create(const realise_config* cfg, float* params, float* grads, float* unused_params,
+                                      float* frozen, float* buffers_f32, int64_t* buffers_i64);
+void realise_engine_destroy(realise_engine* e);
+int64_t realise_engine_shadow_bytes(const realise_engine* e);
+int64_t realise_engine_workspace_bytes(const realise_engine* e, int B, int S, int Tp);
+/* hand the engine its operand-shadow arena and its activation workspace (caller-allocated) */
+int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_t workspace_bytes);
+/* re-derive the compute-dtype operand copies from the fp32 masters (after any parameter update) */
+int realise_engine_refresh_shadows(realise_engine* e, void* stream);
+
+typedef struct {
+  int32_t B, S, Tp;
+  int32_t training;           /* dropout + BatchNorm batch statistics + keep activations for backward */
+  int32_t want_dlogits;       /* compute d loss / d logits during the loss pass (needed before backward) */
+  uint64_t seed;              /* dropout stream for this step */
+  const int64_t* src_idx;     /* [B,S] */
+  const int64_t* masks;       /* [B,S] */
+  const int64_t* loss_masks;  /* [B,S] nullable when tgt_idx is null */
+  const int64_t* tgt_idx;     /* [B,S] nullable */
+  const int64_t* pho_idx;     /* [B*S,Tp] (arch3) */
+  const int32_t* pho_perm;    /* [B*S] tokens sorted by decreasing pinyin length (device) */
+  const int32_t* pho_lens_sorted; /* [B*S] (device) */
+  const int32_t* n_alive;     /* HOST array [Tp]: #sequences with length > t */
+  float* loss_out;            /* 1 float (device), nullable when tgt_idx is null */
+  void* logits_out;           /* [B*S, vocab] in `dtype` (device) */
+} realise_batch;
+
+int realise_engine_forward(realise_engine* e, void* stream, const realise_batch* batch);
+/* gradients of the loss computed by the last training forward are ACCUMULATED into the grads arena.
+ * Runs buckets [first_bucket, last_bucket] of the backward pass (see realise_bucket_bounds) so a
+ * caller can overlap the all-reduce of finished buckets; pass 0, -1 for the whole pass. */
+int realise_engine_backward(realise_engine* e, void* stream, int first_bucket, int last_bucket);
+/* named view of an internal activation (parity tests): returns 0 and fills ptr/numel if it exists */
+int realise_engine_tap(realise_engine* e, const char* name, void** ptr, int64_t* numel);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer step adjacent to the path (transformers/optimization.py:110-169, run.py:207-211)
+ * ---------------------------------------------------------------------------------------- */
+int realise_sumsq(void* stream, const float* g, int64_t n, float* out_accum);
+int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, int correct_bias,
+                  const float* grad_norm_sq, float max_grad_norm);
+int realise_fill_f32(void* stream, float* p, float value, int64_t n);
+
+const char* realise_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REALISE_HIP_H */

@@ -1,0 +1,142 @@
+"""ctypes binding of librealise_hip.so (the C ABI declared in include/realise_hip.h).
+
+This is the reference-side binding a maintainer would add: plain pointers
+and sizes, no torch types.  The product path FAILS LOUDLY when the library is missing - there
+is no CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librealise_hip.so")
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_GELU, EPI_DROP_RESID, EPI_GELU_BWD = 0, 1, 2, 4
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("accumulate", C.c_int32), ("out", C.c_void_p), ("ldo", C.c_int64),
+                ("out2", C.c_void_p), ("bias", C.c_void_p), ("aux", C.c_void_p), ("ldaux", C.c_int64),
+                ("alpha", C.c_float), ("drop_seed", C.c_uint32), ("drop_thresh", C.c_uint32), ("drop_scale", C.c_float)]
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("img_index", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("rows", "Hr", "Wr", "Hs", "Ws", "C", "KH", "KW", "stride", "pad", "mode")]
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("model_type", "dtype", "hidden", "heads", "intermediate", "vocab", "max_pos",
+                                         "type_vocab", "bert_layers", "pho_layers", "out_layers", "num_fonts",
+                                         "glyph_size", "pho_vocab")] + \
+               [("hidden_dropout", C.c_float), ("attn_dropout", C.c_float), ("ln_eps", C.c_float),
+                ("tie_classifier", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("Tp", C.c_int32), ("training", C.c_int32),
+                ("want_dlogits", C.c_int32), ("seed", C.c_uint64),
+                ("src_idx", C.c_void_p), ("masks", C.c_void_p), ("loss_masks", C.c_void_p), ("tgt_idx", C.c_void_p),
+                ("pho_idx", C.c_void_p), ("pho_perm", C.c_void_p), ("pho_lens_sorted", C.c_void_p),
+                ("n_alive", C.POINTER(C.c_int32)), ("loss_out", C.c_void_p), ("logits_out", C.c_void_p)]
+
+
+# every symbol include/realise_hip.h declares: name -> (restype, argtypes)
+_P, _I, _L, _F, _U = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
+SYMBOLS = {
+    "realise_version": (C.c_char_p, []),
+    "realise_gemm_nt": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
+    "realise_conv_nt": (_I, [_P, _I, C.POINTER(ConvGeom), _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
+    "realise_gemm_tn": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, _P, _L]),
+    "realise_conv_tn": (_I, [_P, _I, _P, _L, C.POINTER(ConvGeom), _I, _I, _I, _P]),
+    "realise_set_tn_transpose_read": (None, [_I]),
+    "realise_attention_fwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _U, _U, _F]),
+    "realise_attention_bwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _U, _U, _F]),
+    "realise_mask_to_additive": (_I, [_P, _P, _P, _I]),
+    "realise_layernorm_fwd": (_I, [_P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I]),
+    "realise_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I]),
+    "realise_masked_ce": (_I, [_P, _I, _P, _L, _P, _P, _I, _I, _P, _P, _P]),
+    "realise_layout_count": (_I, [C.POINTER(Config)]),
+    "realise_layout_entry": (_I, [C.POINTER(Config), _I, C.c_char_p, _I, C.POINTER(C.c_int32), C.POINTER(_L),
+                                  C.POINTER(C.c_int32), C.POINTER(_L)]),
+    "realise_arena_elems": (_L, [C.POINTER(Config), _I]),
+    "realise_bucket_count": (_I, [C.POINTER(Config)]),
+    "realise_bucket_bounds": (_I, [C.POINTER(Config), _I, C.POINTER(_L), C.POINTER(_L)]),
+    "realise_engine_create": (_P, [C.POINTER(Config), _P, _P, _P, _P, _P, _P]),
+    "realise_engine_destroy": (None, [_P]),
+    "realise_engine_shadow_bytes": (_L, [_P]),
+    "realise_engine_workspace_bytes": (_L, [_P, _I, _I, _I]),
+    "realise_engine_bind": (_I, [_P, _P, _P, _L]),
+    "realise_engine_refresh_shadows": (_I, [_P, _P]),
+    "realise_engine_forward": (_I, [_P, _P, C.POINTER(Batch)]),
+    "realise_engine_backward": (_I, [_P, _P, _I, _I]),
+    "realise_engine_tap": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_L)]),
+    "realise_sumsq": (_I, [_P, _P, _L, _P]),
+    "realise_adamw": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _I, _P, _F]),
+    "realise_fill_f32": (_I, [_P, _P, _F, _L]),
+}
+
+_lib = None
+
+
+class RealiseHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RealiseHipError(
+            "librealise_hip.so is missing (%s). Build it with `python -m realise_amd.build` "
+            "(or __graft_entry__.build()); the HIP path has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError here == header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RealiseHipError("%s failed with status %d" % (what, rc))
+
+
+def make_config(cfg, model_type, dtype, tie=True):
+    c = Config()
+    c.model_type = 1 if model_type == "arch3" else 0
+    c.dtype = dtype
+    c.hidden, c.heads, c.intermediate = cfg["hidden_size"], cfg["num_attention_heads"], cfg["intermediate_size"]
+    c.vocab, c.max_pos, c.type_vocab = cfg["vocab_size"], cfg["max_position_embeddings"], cfg["type_vocab_size"]
+    c.bert_layers, c.pho_layers, c.out_layers = cfg["num_hidden_layers"], cfg["pho_layers"], cfg["out_layers"]
+    c.num_fonts, c.glyph_size, c.pho_vocab = cfg["num_fonts"], cfg["glyph_size"], cfg["pho_vocab_size"]
+    c.hidden_dropout, c.attn_dropout = cfg["hidden_dropout_prob"], cfg["attention_probs_dropout_prob"]
+    c.ln_eps = cfg["layer_norm_eps"]
+    c.tie_classifier = 1 if tie else 0
+    return c
+
+
+def layout(c):
+    """[(name, arena, offset, shape)], arena sizes, bucket bounds from the library."""
+    lib = load()
+    n = lib.realise_layout_count(C.byref(c))
+    out = []
+    name = C.create_string_buffer(256)
+    arena, ndim = C.c_int32(), C.c_int32()
+    off = C.c_int64()
+    shape = (C.c_int64 * 4)()
+    for i in range(n):
+        check(lib.realise_layout_entry(C.byref(c), i, name, 256, C.byref(arena), C.byref(off), C.byref(ndim), shape),
+              "realise_layout_entry")
+        out.append((name.value.decode(), arena.value, off.value, tuple(shape[k] for k in range(ndim.value))))
+    sizes = [lib.realise_arena_elems(C.byref(c), a) for a in range(5)]
+    buckets = []
+    b0, b1 = C.c_int64(), C.c_int64()
+    for i in range(lib.realise_bucket_count(C.byref(c))):
+        check(lib.realise_bucket_bounds(C.byref(c), i, C.byref(b0), C.byref(b1)), "realise_bucket_bounds")
+        buckets.append((b0.value, b1.value))
+    return out, sizes, buckets

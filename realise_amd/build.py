@@ -1,0 +1,70 @@
+"""Build librealise_hip.so (gfx950) from realise_amd/csrc/*.hip with hipcc.
+
+Cross-compiles without a GPU (seconds per file).  The shared object is written IN-TREE next
+to this file so it travels with the repository snapshot to the GPU box; objects are cached
+under realise_amd/_obj/ keyed by source mtime.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "librealise_hip.so")
+SOURCES = ["gemm.hip", "attention.hip", "ops.hip", "ops2.hip", "engine.hip", "capi.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newest_header():
+    t = 0.0
+    for d in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                t = max(t, os.path.getmtime(os.path.join(d, f)))
+    return t
+
+
+def _compile(src, hdr_time, verbose):
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    sp = os.path.join(CSRC, src)
+    if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), hdr_time):
+        return obj, False
+    cmd = [_hipcc()] + FLAGS + ["-c", sp, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    return obj, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    hdr_time = _newest_header()
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        res = list(ex.map(lambda s: _compile(s, hdr_time, verbose), SOURCES))
+    objs = [o for o, _ in res]
+    if any(ch for _, ch in res) or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,16 @@
+// Fused attention launchers (attention.hip).
+#pragma once
+#include "common.h"
+
+namespace rl {
+// q/k/v: token-major [B*S][ldq] matrices (head h at columns h*64..h*64+63); mask_add: [B][S] fp32
+// additive mask ((1-m) * -10000); ctx: [B*S][ldc]; lse: [B][nh][S] fp32 row log-sum-exp.
+template <typename T>
+int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, const float* mask_add, T* ctx, int64_t ldc,
+             float* lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale);
+// rowdot: [B][nh][S] fp32 scratch; dq/dk/dv: token-major [B*S][ldd], fully overwritten for every head.
+template <typename T>
+int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, const float* mask_add, const T* ctx,
+             const T* dctx, int64_t ldc, const float* lse, float* rowdot, T* dq, T* dk, T* dv, int64_t ldd,
+             int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale);
+}  // namespace rl

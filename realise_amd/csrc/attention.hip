@@ -1,0 +1,477 @@
+// Fused single-tile self-attention for S <= 128, head_dim 64 (K3 + its backward, K14).
+// Reference math: transformers/modeling_bert.py:239-260 -
+//   scores = Q K^T / 8 + (1 - mask) * -10000 ; softmax ; dropout(p) ; ctx = P V.
+// One workgroup (4 waves) per (batch, head).  The whole [S,S] score tile stays in registers;
+// only the row log-sum-exp is saved for backward, which recomputes the probabilities.
+//
+// Register-resident operand trick used throughout: an MFMA result (lane l holds rows 4*(l>>4)+r
+// of column l&15) is directly a valid OPERAND of the next MFMA whose contraction index is the
+// result's row index, provided the partner operand enumerates the contraction slots in the same
+// order.  The product orientation (which matrix goes first) is therefore chosen per GEMM so the
+// probabilities never take a round trip through LDS:
+//   forward :  S^T = K Q^T  (lane <-> query, regs <-> keys)  feeds  O^T = V^T P^T
+//   bwd dK/dV: S   = Q K^T  (lane <-> key,   regs <-> queries) feeds dV^T = dO^T P, dK^T = Q^T dS
+//   bwd dQ   : S^T = K Q^T                                       feeds dQ^T = K^T dS^T
+// Operands contracted over the sequence dimension (V^T, dO^T, Q^T, K^T) are kept in LDS in a
+// [64][S] sequence-contiguous image with a 16-byte row pad (conflict-free ds_read_b64).
+#include "attention.h"
+
+namespace rl {
+
+static constexpr int HD = 64;      // head dim
+static constexpr int SMAX = 128;
+
+template <typename T> struct AttnGeo {
+  static constexpr int VEC = 16 / (int)sizeof(T);
+  static constexpr int CH = HD / VEC;                        // 16-byte chunks per [.,64] row
+  static constexpr int KSTEPS = HD / MmaOf<T>::type::K;      // MMA steps over head_dim
+  static constexpr int TPITCH = SMAX * (int)sizeof(T) + 16;  // pitch of the [64][S] images
+  static constexpr int KT_BYTES = SMAX * HD * (int)sizeof(T);
+  static constexpr int TT_BYTES = HD * TPITCH;
+};
+
+// stage rows [0,S) of a [S][64] matrix (row stride `stride`) into a K-contiguous swizzled tile
+// and/or its [64][S] transposed image; rows >= S are zero-filled up to 128.
+template <typename T, bool WITH_K, bool WITH_T>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ src, int64_t stride, int S, char* kt, char* tt, int tid) {
+  typedef AttnGeo<T> G;
+  for (int c = tid; c < SMAX * G::CH; c += 256) {
+    const int row = c / G::CH, ch = c - row * G::CH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < S) v = *(const uint4*)(src + (int64_t)row * stride + ch * G::VEC);
+    if (WITH_K) *(uint4*)(kt + KTile<T, HD>::off(row, ch)) = v;
+    if (WITH_T) {
+      const T* e = (const T*)&v;
+#pragma unroll
+      for (int j = 0; j < G::VEC; ++j) *(T*)(tt + (ch * G::VEC + j) * G::TPITCH + row * (int)sizeof(T)) = e[j];
+    }
+  }
+}
+
+// operand fragment loaded straight from global memory: row `row` of a [.,64] matrix, MMA step ks
+template <typename T>
+__device__ __forceinline__ typename MmaOf<T>::type::Frag gfrag(const T* __restrict__ base, int64_t stride, int row, int S, int ks, int g);
+template <> __device__ __forceinline__ bf16x8_t gfrag<bf16_t>(const bf16_t* __restrict__ base, int64_t stride, int row, int S, int ks, int g) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (row < S) v = *(const uint4*)(base + (int64_t)row * stride + ks * 32 + 8 * g);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+template <> __device__ __forceinline__ float gfrag<float>(const float* __restrict__ base, int64_t stride, int row, int S, int ks, int g) {
+  return row < S ? base[(int64_t)row * stride + ks * 4 + g] : 0.0f;
+}
+
+__device__ __forceinline__ bf16x8_t pack8(floatx4 a, floatx4 b) {
+  uint4 u;
+  u.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
+  u.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
+  u.z = (uint32_t)f2bf(b[0]) | ((uint32_t)f2bf(b[1]) << 16);
+  u.w = (uint32_t)f2bf(b[2]) | ((uint32_t)f2bf(b[3]) << 16);
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+// bf16 fragment from a [64][S] image: row d, contraction slots (g,e) <-> seq = base + 16*(e>>2) + 4*g + (e&3)
+__device__ __forceinline__ bf16x8_t tfrag_bf16(const char* tt, int d, int base, int g) {
+  const char* p = tt + d * AttnGeo<bf16_t>::TPITCH + (base + 4 * g) * 2;
+  const uint2 lo = *(const uint2*)p;
+  const uint2 hi = *(const uint2*)(p + 32);
+  uint4 u; u.x = lo.x; u.y = lo.y; u.z = hi.x; u.w = hi.y;
+  return __builtin_bit_cast(bf16x8_t, u);
+}
+
+// acc[dn] += X^T-image(d = 16*dn + l15, seq slots of the 32-block starting at base) x regs(c0,c1)
+// where c0/c1 are the two 16-row result tiles covering seq base..base+15 / base+16..base+31.
+template <typename T>
+__device__ __forceinline__ void contract_seq32(floatx4 (&acc)[4], const char* tt, int base, floatx4 c0, floatx4 c1, int l15, int g) {
+  typedef typename MmaOf<T>::type Mma;
+  if constexpr (sizeof(T) == 2) {
+    const bf16x8_t y = pack8(c0, c1);
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) acc[dn] = Mma::mma(tfrag_bf16(tt, dn * 16 + l15, base, g), y, acc[dn]);
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int seq = base + 16 * h + 4 * g + r;
+        const float y = h ? c1[r] : c0[r];
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) {
+          const float x = *(const float*)(tt + (dn * 16 + l15) * AttnGeo<float>::TPITCH + seq * 4);
+          acc[dn] = Mma::mma(x, y, acc[dn]);
+        }
+      }
+  }
+}
+
+// ================================= forward ======================================================
+template <typename T>
+__global__ void __launch_bounds__(256)
+attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
+                const float* __restrict__ mask_add, T* __restrict__ ctx, int64_t ldc,
+                float* __restrict__ lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+  typedef typename MmaOf<T>::type Mma;
+  typedef AttnGeo<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vt = smem + G::KT_BYTES;
+  float* madd = (float*)(smem + G::KT_BYTES + G::TT_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
+  const T* Q = q_ + (int64_t)b * S * ldq + h * HD;
+  const T* K = k_ + (int64_t)b * S * ldq + h * HD;
+  const T* V = v_ + (int64_t)b * S * ldq + h * HD;
+
+  stage_rows<T, true, false>(K, ldq, S, Ks, nullptr, tid);
+  stage_rows<T, false, true>(V, ldq, S, nullptr, Vt, tid);
+  if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
+  __syncthreads();
+  const int q0 = wave * 32;
+  if (q0 >= S) return;
+
+  typename Mma::Frag qf[2][G::KSTEPS];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) qf[m][ks] = gfrag<T>(Q, ldq, q0 + 16 * m + l15, S, ks, g);
+
+  floatx4 sc[8][2];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) sc[n][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    if (16 * n < S) {
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks) {
+        const typename Mma::Frag kf = ktile_frag<T, HD>(Ks, 16 * n + l15, ks, g);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) sc[n][m] = Mma::mma(kf, qf[m][ks], sc[n][m]);
+      }
+    }
+  }
+  // softmax over keys; lane owns query (q0 + 16m + l15), keys 16n + 4g + r
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int q = q0 + 16 * m + l15;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const floatx4 ma = *(const floatx4*)(madd + 16 * n + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * n + 4 * g + r;
+        const float s = key < S ? sc[n][m][r] * 0.125f + ma[r] : -3.0e38f;
+        sc[n][m][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * n + 4 * g + r;
+        const float p = key < S ? expf(sc[n][m][r] - mx) : 0.0f;
+        sc[n][m][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (g == 0 && q < S && lse != nullptr) lse[(int64_t)bh * S + q] = mx + logf(sum);
+    const uint32_t rowbase = ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S;
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sc[n][m][r] *= inv * drop_mult(drop_seed, drop_thresh, drop_scale, rowbase + 16 * n + 4 * g + r);
+  }
+  // O^T = V^T P^T : lane ends with O[query l15][d = 16dn + 4g + r]
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    floatx4 o[4];
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) o[dn] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      if (32 * kk < S) contract_seq32<T>(o, Vt, 32 * kk, sc[2 * kk][m], sc[2 * kk + 1][m], l15, g);
+    const int q = q0 + 16 * m + l15;
+    if (q < S) {
+      T* dst = ctx + ((int64_t)b * S + q) * ldc + h * HD + 4 * g;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) store4<T>(dst + 16 * dn, o[dn]);
+    }
+  }
+}
+
+// ================================= backward: dK, dV (+ row dots) ================================
+template <typename T>
+__global__ void __launch_bounds__(256)
+attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
+                    const float* __restrict__ mask_add, const T* __restrict__ ctx, const T* __restrict__ dctx, int64_t ldc,
+                    const float* __restrict__ lse, float* __restrict__ rowdot, T* __restrict__ dk_, T* __restrict__ dv_,
+                    int64_t ldd, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+  typedef typename MmaOf<T>::type Mma;
+  typedef AttnGeo<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = Qs + G::KT_BYTES;
+  char* Qt = dOs + G::KT_BYTES;
+  char* dOt = Qt + G::TT_BYTES;
+  float* lse_s = (float*)(dOt + G::TT_BYTES);
+  float* dot_s = lse_s + SMAX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
+  const int64_t H = ldc;
+  const T* Q = q_ + (int64_t)b * S * ldq + h * HD;
+  const T* K = k_ + (int64_t)b * S * ldq + h * HD;
+  const T* V = v_ + (int64_t)b * S * ldq + h * HD;
+  const T* O = ctx + (int64_t)b * S * H + h * HD;
+  const T* dO = dctx + (int64_t)b * S * H + h * HD;
+
+  stage_rows<T, true, true>(Q, ldq, S, Qs, Qt, tid);
+  stage_rows<T, true, true>(dO, H, S, dOs, dOt, tid);
+  {  // rowdot[q] = sum_d dO[q,d] * O[q,d]  (two threads per row)
+    const int row = tid >> 1, half = tid & 1;
+    float acc = 0.f;
+    if (row < S) {
+      const T* po = O + (int64_t)row * H + half * 32;
+      const T* pd = dO + (int64_t)row * H + half * 32;
+#pragma unroll
+      for (int j = 0; j < 32; j += 4) {
+        const floatx4 x = load4<T>(po + j), y = load4<T>(pd + j);
+        acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    if (half == 0) {
+      dot_s[row] = acc;
+      lse_s[row] = row < S ? lse[(int64_t)bh * S + row] : 0.0f;
+      if (row < S) rowdot[(int64_t)bh * S + row] = acc;
+    }
+  }
+  __syncthreads();
+  const int k0 = wave * 32;
+  if (k0 >= S) return;
+
+  typename Mma::Frag kf[2][G::KSTEPS], vf[2][G::KSTEPS];
+  float ma[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int key = k0 + 16 * n + l15;
+    ma[n] = key < S ? mask_add[b * S + key] : 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+      kf[n][ks] = gfrag<T>(K, ldq, key, S, ks, g);
+      vf[n][ks] = gfrag<T>(V, ldq, key, S, ks, g);
+    }
+  }
+  floatx4 dv[2][4], dk[2][4];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) { dv[n][dn] = floatx4{0.f, 0.f, 0.f, 0.f}; dk[n][dn] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int mm = 0; mm < 4; ++mm) {
+    if (32 * mm >= S) break;
+    floatx4 s[2][2], dp[2][2];   // [mi][n] : queries 32mm + 16mi + 4g + r, key k0 + 16n + l15
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) { s[mi][n] = floatx4{0.f, 0.f, 0.f, 0.f}; dp[mi][n] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int qrow = 32 * mm + 16 * mi + l15;
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks) {
+        const typename Mma::Frag qx = ktile_frag<T, HD>(Qs, qrow, ks, g);
+        const typename Mma::Frag dx = ktile_frag<T, HD>(dOs, qrow, ks, g);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          s[mi][n] = Mma::mma(qx, kf[n][ks], s[mi][n]);
+          dp[mi][n] = Mma::mma(dx, vf[n][ks], dp[mi][n]);
+        }
+      }
+    }
+    floatx4 pd[2][2], ds[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const floatx4 l4 = *(const floatx4*)(lse_s + 32 * mm + 16 * mi + 4 * g);
+      const floatx4 d4 = *(const floatx4*)(dot_s + 32 * mm + 16 * mi + 4 * g);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int key = k0 + 16 * n + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 32 * mm + 16 * mi + 4 * g + r;
+          const bool ok = (q < S) && (key < S);
+          const float p = ok ? expf(s[mi][n][r] * 0.125f + ma[n] - l4[r]) : 0.0f;
+          const float dm = drop_mult(drop_seed, drop_thresh, drop_scale,
+                                     ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)key);
+          pd[mi][n][r] = p * dm;
+          ds[mi][n][r] = p * (dp[mi][n][r] * dm - d4[r]) * 0.125f;
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      contract_seq32<T>(dv[n], dOt, 32 * mm, pd[0][n], pd[1][n], l15, g);
+      contract_seq32<T>(dk[n], Qt, 32 * mm, ds[0][n], ds[1][n], l15, g);
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int key = k0 + 16 * n + l15;
+    if (key < S) {
+      T* pk = dk_ + ((int64_t)b * S + key) * ldd + h * HD + 4 * g;
+      T* pv = dv_ + ((int64_t)b * S + key) * ldd + h * HD + 4 * g;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) { store4<T>(pk + 16 * dn, dk[n][dn]); store4<T>(pv + 16 * dn, dv[n][dn]); }
+    }
+  }
+}
+
+// ================================= backward: dQ =================================================
+template <typename T>
+__global__ void __launch_bounds__(256)
+attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
+                   const float* __restrict__ mask_add, const T* __restrict__ dctx, int64_t ldc,
+                   const float* __restrict__ lse, const float* __restrict__ rowdot, T* __restrict__ dq_out, int64_t ldd,
+                   int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+  typedef typename MmaOf<T>::type Mma;
+  typedef AttnGeo<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = Ks + G::KT_BYTES;
+  char* Kt = Vs + G::KT_BYTES;
+  float* madd = (float*)(Kt + G::TT_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
+  const int64_t H = ldc;
+  const T* Q = q_ + (int64_t)b * S * ldq + h * HD;
+  const T* K = k_ + (int64_t)b * S * ldq + h * HD;
+  const T* V = v_ + (int64_t)b * S * ldq + h * HD;
+  const T* dO = dctx + (int64_t)b * S * H + h * HD;
+
+  stage_rows<T, true, true>(K, ldq, S, Ks, Kt, tid);
+  stage_rows<T, true, false>(V, ldq, S, Vs, nullptr, tid);
+  if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
+  __syncthreads();
+  const int q0 = wave * 32;
+  if (q0 >= S) return;
+
+  typename Mma::Frag qf[2][G::KSTEPS], dof[2][G::KSTEPS];
+  float lq[2], dq_[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int q = q0 + 16 * m + l15;
+    lq[m] = q < S ? lse[(int64_t)bh * S + q] : 0.0f;
+    dq_[m] = q < S ? rowdot[(int64_t)bh * S + q] : 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+      qf[m][ks] = gfrag<T>(Q, ldq, q, S, ks, g);
+      dof[m][ks] = gfrag<T>(dO, H, q, S, ks, g);
+    }
+  }
+  floatx4 dq[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) dq[m][dn] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  for (int nn = 0; nn < 4; ++nn) {
+    if (32 * nn >= S) break;
+    floatx4 s[2][2], dp[2][2];   // [ni][m] : keys 32nn + 16ni + 4g + r, query q0 + 16m + l15
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) { s[ni][m] = floatx4{0.f, 0.f, 0.f, 0.f}; dp[ni][m] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int krow = 32 * nn + 16 * ni + l15;
+#pragma unroll
+      for (int ks = 0; ks < G::KSTEPS; ++ks) {
+        const typename Mma::Frag kx = ktile_frag<T, HD>(Ks, krow, ks, g);
+        const typename Mma::Frag vx = ktile_frag<T, HD>(Vs, krow, ks, g);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          s[ni][m] = Mma::mma(kx, qf[m][ks], s[ni][m]);
+          dp[ni][m] = Mma::mma(vx, dof[m][ks], dp[ni][m]);
+        }
+      }
+    }
+    floatx4 ds[2][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const floatx4 ma = *(const floatx4*)(madd + 32 * nn + 16 * ni + 4 * g);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int q = q0 + 16 * m + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 32 * nn + 16 * ni + 4 * g + r;
+          const bool ok = (q < S) && (key < S);
+          const float p = ok ? expf(s[ni][m][r] * 0.125f + ma[r] - lq[m]) : 0.0f;
+          const float dm = drop_mult(drop_seed, drop_thresh, drop_scale,
+                                     ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)key);
+          ds[ni][m][r] = p * (dp[ni][m][r] * dm - dq_[m]) * 0.125f;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) contract_seq32<T>(dq[m], Kt, 32 * nn, ds[0][m], ds[1][m], l15, g);
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int q = q0 + 16 * m + l15;
+    if (q < S) {
+      T* pq = dq_out + ((int64_t)b * S + q) * ldd + h * HD + 4 * g;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) store4<T>(pq + 16 * dn, dq[m][dn]);
+    }
+  }
+}
+
+// ================================= launchers ====================================================
+template <typename K> static void set_lds(K kernel, size_t bytes) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T>
+int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, const float* mask_add, T* ctx, int64_t ldc,
+             float* lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+  if (S < 1 || S > SMAX || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC)) return RL_ERR_ARG;
+  typedef AttnGeo<T> G;
+  const size_t lds = G::KT_BYTES + G::TT_BYTES + SMAX * sizeof(float);
+  static bool once = false;
+  if (!once) { set_lds(attn_fwd_kernel<T>, lds); once = true; }
+  hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(B * nh), dim3(256), lds, st, q, k, v, ldq, mask_add, ctx, ldc, lse, B, nh, S,
+                     drop_seed, drop_thresh, drop_scale);
+  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+}
+
+template <typename T>
+int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, const float* mask_add, const T* ctx,
+             const T* dctx, int64_t ldc, const float* lse, float* rowdot, T* dq, T* dk, T* dv, int64_t ldd,
+             int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+  if (S < 1 || S > SMAX || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC) || (ldd & 3)) return RL_ERR_ARG;
+  typedef AttnGeo<T> G;
+  const size_t lds1 = 2 * G::KT_BYTES + 2 * G::TT_BYTES + 2 * SMAX * sizeof(float);
+  const size_t lds2 = 2 * G::KT_BYTES + G::TT_BYTES + SMAX * sizeof(float);
+  static bool once = false;
+  if (!once) { set_lds(attn_bwd_dkv_kernel<T>, lds1); set_lds(attn_bwd_dq_kernel<T>, lds2); once = true; }
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(B * nh), dim3(256), lds1, st, q, k, v, ldq, mask_add, ctx, dctx, ldc,
+                     lse, rowdot, dk, dv, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(B * nh), dim3(256), lds2, st, q, k, v, ldq, mask_add, dctx, ldc, lse,
+                     rowdot, dq, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale);
+  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+}
+
+template int attn_fwd<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, int64_t, const float*, bf16_t*, int64_t, float*, int, int, int, uint32_t, uint32_t, float);
+template int attn_fwd<float>(hipStream_t, const float*, const float*, const float*, int64_t, const float*, float*, int64_t, float*, int, int, int, uint32_t, uint32_t, float);
+template int attn_bwd<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, int64_t, const float*, const bf16_t*, const bf16_t*, int64_t, const float*, float*, bf16_t*, bf16_t*, bf16_t*, int64_t, int, int, int, uint32_t, uint32_t, float);
+template int attn_bwd<float>(hipStream_t, const float*, const float*, const float*, int64_t, const float*, const float*, const float*, int64_t, const float*, float*, float*, float*, float*, int64_t, int, int, int, uint32_t, uint32_t, float);
+
+}  // namespace rl

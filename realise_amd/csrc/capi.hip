@@ -1,0 +1,209 @@
+// extern "C" surface of librealise_hip.so (declared in include/realise_hip.h).
+#include <math.h>
+#include <string.h>
+
+#include "attention.h"
+#include "engine.h"
+#include "gemm.h"
+#include "layout.h"
+#include "ops.h"
+
+using namespace rl;
+
+struct realise_engine { EngineBase* impl; };
+
+namespace {
+template <typename T> EpiParams<T> to_epi(const realise_epilogue* e) {
+  EpiParams<T> p;
+  if (!e) return p;
+  p.mode = e->mode; p.accumulate = e->accumulate; p.out = (T*)e->out; p.ldo = e->ldo; p.out2 = (T*)e->out2;
+  p.bias = e->bias; p.aux = (const T*)e->aux; p.ldaux = e->ldaux; p.alpha = e->alpha;
+  p.drop_seed = e->drop_seed; p.drop_thresh = e->drop_thresh; p.drop_scale = e->drop_scale;
+  return p;
+}
+template <typename T> ConvLoader<T> to_geom(const realise_conv_geom* g) {
+  ConvLoader<T> c;
+  c.src = (const T*)g->src; c.img_index = g->img_index; c.rows = g->rows; c.Hr = g->Hr; c.Wr = g->Wr; c.Hs = g->Hs; c.Ws = g->Ws;
+  c.C = g->C; c.KH = g->KH; c.KW = g->KW; c.stride = g->stride; c.pad = g->pad; c.mode = g->mode; c.K = g->KH * g->KW * g->C;
+  return c;
+}
+}  // namespace
+
+extern "C" {
+
+const char* realise_version(void) { return "realise_hip 0.1 (gfx950)"; }
+
+int realise_gemm_nt(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                    const realise_epilogue* ep) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!ep || !ep->out) return RL_ERR_ARG;
+  if (dtype == REALISE_BF16) return gemm_nt<bf16_t>(st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, to_epi<bf16_t>(ep));
+  if (dtype == REALISE_F32) return gemm_nt<float>(st, (const float*)A, lda, (const float*)B, ldb, M, N, K, to_epi<float>(ep));
+  return RL_ERR_ARG;
+}
+int realise_conv_nt(void* stream, int dtype, const realise_conv_geom* a, const void* B, int64_t ldb, int M, int N, int K,
+                    const realise_epilogue* ep) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!ep || !ep->out || !a) return RL_ERR_ARG;
+  if (dtype == REALISE_BF16) return gemm_nt_conv<bf16_t>(st, to_geom<bf16_t>(a), (const bf16_t*)B, ldb, M, N, K, to_epi<bf16_t>(ep));
+  if (dtype == REALISE_F32) return gemm_nt_conv<float>(st, to_geom<float>(a), (const float*)B, ldb, M, N, K, to_epi<float>(ep));
+  return RL_ERR_ARG;
+}
+int realise_gemm_tn(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int P, int I, int J,
+                    float* out, int64_t ldo) {
+  hipStream_t st = (hipStream_t)stream;
+  TnEpi te; te.out = out; te.ldo = ldo;
+  if (dtype == REALISE_BF16) return gemm_tn<bf16_t>(st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, P, I, J, te);
+  if (dtype == REALISE_F32) return gemm_tn<float>(st, (const float*)A, lda, (const float*)B, ldb, P, I, J, te);
+  return RL_ERR_ARG;
+}
+int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const realise_conv_geom* b, int P, int Co, int Ci,
+                    float* out) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!b) return RL_ERR_ARG;
+  TnEpi te; te.mode = TN_CONVW; te.out = out; te.Cin = Ci; te.Cpad = b->C; te.KHW = b->KH * b->KW;
+  const int J = b->KH * b->KW * b->C;
+  if (dtype == REALISE_BF16) return gemm_tn_conv<bf16_t>(st, (const bf16_t*)A, lda, to_geom<bf16_t>(b), P, Co, J, te);
+  if (dtype == REALISE_F32) return gemm_tn_conv<float>(st, (const float*)A, lda, to_geom<float>(b), P, Co, J, te);
+  return RL_ERR_ARG;
+}
+void realise_set_tn_transpose_read(int enable) { set_tn_transpose_read(enable); }
+
+int realise_attention_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ldq, const float* mask_add,
+                          void* ctx, int64_t ldc, float* lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh,
+                          float drop_scale) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == REALISE_BF16)
+    return attn_fwd<bf16_t>(st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, mask_add, (bf16_t*)ctx, ldc, lse, B, nh, S,
+                            drop_seed, drop_thresh, drop_scale);
+  if (dtype == REALISE_F32)
+    return attn_fwd<float>(st, (const float*)q, (const float*)k, (const float*)v, ldq, mask_add, (float*)ctx, ldc, lse, B, nh, S,
+                           drop_seed, drop_thresh, drop_scale);
+  return RL_ERR_ARG;
+}
+int realise_attention_bwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ldq, const float* mask_add,
+                          const void* ctx, const void* dctx, int64_t ldc, const float* lse, float* rowdot, void* dq, void* dk,
+                          void* dv, int64_t ldd, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == REALISE_BF16)
+    return attn_bwd<bf16_t>(st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, mask_add, (const bf16_t*)ctx,
+                            (const bf16_t*)dctx, ldc, lse, rowdot, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, ldd, B, nh, S, drop_seed,
+                            drop_thresh, drop_scale);
+  if (dtype == REALISE_F32)
+    return attn_bwd<float>(st, (const float*)q, (const float*)k, (const float*)v, ldq, mask_add, (const float*)ctx,
+                           (const float*)dctx, ldc, lse, rowdot, (float*)dq, (float*)dk, (float*)dv, ldd, B, nh, S, drop_seed,
+                           drop_thresh, drop_scale);
+  return RL_ERR_ARG;
+}
+int realise_mask_to_additive(void* stream, const int64_t* masks, float* out, int n) {
+  return mask_to_additive((hipStream_t)stream, masks, out, n);
+}
+
+int realise_layernorm_fwd(void* stream, int dtype, const void* x, const float* gamma, const float* beta, float eps, void* y,
+                          void* xhat, float* rstd, int rows, int H) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == REALISE_BF16) {
+    LnFwdArgs<bf16_t> a; a.rows = rows; a.H = H; a.x = (const bf16_t*)x; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.y = (bf16_t*)y; a.xhat = (bf16_t*)xhat; a.rstd = rstd;
+    return ln_fwd<bf16_t>(st, a);
+  }
+  if (dtype == REALISE_F32) {
+    LnFwdArgs<float> a; a.rows = rows; a.H = H; a.x = (const float*)x; a.gamma = gamma; a.beta = beta; a.eps = eps;
+    a.y = (float*)y; a.xhat = (float*)xhat; a.rstd = rstd;
+    return ln_fwd<float>(st, a);
+  }
+  return RL_ERR_ARG;
+}
+int realise_layernorm_bwd(void* stream, int dtype, const void* dy, const void* xhat, const float* rstd, const float* gamma,
+                          void* dx, float* dgamma, float* dbeta, int rows, int H) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == REALISE_BF16) {
+    LnBwdArgs<bf16_t> a; a.rows = rows; a.H = H; a.dy = (const bf16_t*)dy; a.xhat = (const bf16_t*)xhat; a.rstd = rstd;
+    a.gamma = gamma; a.dx = (bf16_t*)dx; a.dgamma = dgamma; a.dbeta = dbeta;
+    return ln_bwd<bf16_t>(st, a);
+  }
+  if (dtype == REALISE_F32) {
+    LnBwdArgs<float> a; a.rows = rows; a.H = H; a.dy = (const float*)dy; a.xhat = (const float*)xhat; a.rstd = rstd;
+    a.gamma = gamma; a.dx = (float*)dx; a.dgamma = dgamma; a.dbeta = dbeta;
+    return ln_bwd<float>(st, a);
+  }
+  return RL_ERR_ARG;
+}
+int realise_masked_ce(void* stream, int dtype, const void* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask,
+                      int rows, int V, float* loss_out, float* count_scratch, void* dlogits) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == REALISE_BF16)
+    return ce_loss<bf16_t>(st, (const bf16_t*)logits, ld, labels, loss_mask, rows, V, loss_out, count_scratch, (bf16_t*)dlogits);
+  if (dtype == REALISE_F32)
+    return ce_loss<float>(st, (const float*)logits, ld, labels, loss_mask, rows, V, loss_out, count_scratch, (float*)dlogits);
+  return RL_ERR_ARG;
+}
+
+// ---- layout --------------------------------------------------------------------------------------
+int realise_layout_count(const realise_config* cfg) { return cfg ? (int)build_layout(*cfg).tensors.size() : -1; }
+int realise_layout_entry(const realise_config* cfg, int index, char* name, int name_cap, int32_t* arena, int64_t* offset,
+                         int32_t* ndim, int64_t* shape4) {
+  if (!cfg) return RL_ERR_ARG;
+  const Layout L = build_layout(*cfg);
+  if (index < 0 || index >= (int)L.tensors.size()) return RL_ERR_ARG;
+  const TensorInfo& t = L.tensors[index];
+  if ((int)t.name.size() + 1 > name_cap) return RL_ERR_ARG;
+  strcpy(name, t.name.c_str());
+  *arena = t.arena; *offset = t.offset; *ndim = t.ndim;
+  for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+  return RL_OK;
+}
+int64_t realise_arena_elems(const realise_config* cfg, int arena) {
+  if (!cfg || arena < 0 || arena >= AR_COUNT) return -1;
+  return build_layout(*cfg).arena_elems[arena];
+}
+int realise_bucket_count(const realise_config* cfg) { return cfg ? (int)build_layout(*cfg).buckets.size() : -1; }
+int realise_bucket_bounds(const realise_config* cfg, int bucket, int64_t* begin, int64_t* end) {
+  if (!cfg) return RL_ERR_ARG;
+  const Layout L = build_layout(*cfg);
+  if (bucket < 0 || bucket >= (int)L.buckets.size()) return RL_ERR_ARG;
+  *begin = L.buckets[bucket].first; *end = L.buckets[bucket].second;
+  return RL_OK;
+}
+
+// ---- engine ----------------------------------------------------------------------------------------
+realise_engine* realise_engine_create(const realise_config* cfg, float* params, float* grads, float* unused_params, float* frozen,
+                                      float* buffers_f32, int64_t* buffers_i64) {
+  if (!cfg) return nullptr;
+  EngineBase* impl = make_engine(*cfg, params, grads, unused_params, frozen, buffers_f32, buffers_i64);
+  if (!impl) return nullptr;
+  realise_engine* e = new realise_engine;
+  e->impl = impl;
+  return e;
+}
+void realise_engine_destroy(realise_engine* e) { if (e) { delete e->impl; delete e; } }
+int64_t realise_engine_shadow_bytes(const realise_engine* e) { return e ? e->impl->shadow_bytes() : -1; }
+int64_t realise_engine_workspace_bytes(const realise_engine* e, int B, int S, int Tp) { return e ? e->impl->workspace_bytes(B, S, Tp) : -1; }
+int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_t workspace_bytes) {
+  return e ? e->impl->bind(shadow, workspace, workspace_bytes) : RL_ERR_ARG;
+}
+int realise_engine_refresh_shadows(realise_engine* e, void* stream) { return e ? e->impl->refresh_shadows((hipStream_t)stream) : RL_ERR_ARG; }
+int realise_engine_forward(realise_engine* e, void* stream, const realise_batch* batch) {
+  return (e && batch) ? e->impl->forward((hipStream_t)stream, *batch) : RL_ERR_ARG;
+}
+int realise_engine_backward(realise_engine* e, void* stream, int first_bucket, int last_bucket) {
+  return e ? e->impl->backward((hipStream_t)stream, first_bucket, last_bucket) : RL_ERR_ARG;
+}
+int realise_engine_tap(realise_engine* e, const char* name, void** ptr, int64_t* numel) {
+  return (e && name && ptr && numel) ? e->impl->get_tap(name, ptr, numel) : RL_ERR_ARG;
+}
+
+// ---- optimizer ---------------------------------------------------------------------------------------
+int realise_sumsq(void* stream, const float* g, int64_t n, float* out_accum) { return sumsq_accum((hipStream_t)stream, g, n, out_accum); }
+int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, int correct_bias, const float* grad_norm_sq, float max_grad_norm) {
+  float bc1 = 1.0f, bc2 = 1.0f;
+  if (correct_bias) {
+    bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+  }
+  return adamw_flat((hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_norm_sq, max_grad_norm);
+}
+int realise_fill_f32(void* stream, float* p, float value, int64_t n) { return fill_f32((hipStream_t)stream, p, value, n); }
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+// Shared device helpers for the ReaLiSe MI355X (gfx950 / CDNA4) kernels.
+// Wave = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rl {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;   // one MFMA 16x16x32 operand
+typedef __attribute__((ext_vector_type(4))) float floatx4;      // one MFMA 16x16 accumulator
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+
+struct bf16_t { uint16_t v; };                                    // storage-only bf16
+
+__device__ __forceinline__ float bf2f(uint16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {                // round-to-nearest-even
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;              // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T x);
+template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return bf2f(x.v); }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { bf16_t r; r.v = f2bf(x); return r; }
+
+// ---- 4-wide load / store of T (8 B for bf16, 16 B for f32) ---------------------------------
+template <typename T> __device__ __forceinline__ floatx4 load4(const T* p);
+template <> __device__ __forceinline__ floatx4 load4<float>(const float* p) { return *(const floatx4*)p; }
+template <> __device__ __forceinline__ floatx4 load4<bf16_t>(const bf16_t* p) {
+  uint2 u = *(const uint2*)p;
+  floatx4 r;
+  r[0] = __uint_as_float(u.x << 16); r[1] = __uint_as_float(u.x & 0xffff0000u);
+  r[2] = __uint_as_float(u.y << 16); r[3] = __uint_as_float(u.y & 0xffff0000u);
+  return r;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, floatx4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, floatx4 v) { *(floatx4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, floatx4 v) {
+  uint2 u;
+  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  *(uint2*)p = u;
+}
+
+// ---- MMA atoms -----------------------------------------------------------------------------
+// Both atoms compute a 16x16 fp32 tile.  Operand register layout is symmetric for the
+// two inputs: lane l supplies, for row/col index (l & 15), the K-slots owned by group
+// g = l >> 4.  Result layout (dtype independent on gfx950):
+//   mma(x, y, c): lane l holds c[r] = D[i = 4*g + r][j = l & 15], i indexes x rows, j indexes y.
+struct MmaBF16 {
+  typedef bf16_t T;
+  static constexpr int K = 32;                 // K per instruction
+  typedef bf16x8_t Frag;
+  static __device__ __forceinline__ floatx4 mma(Frag x, Frag y, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+  }
+};
+struct MmaF32 {                                // exact fp32: bitwise a k-ordered fmaf chain
+  typedef float T;
+  static constexpr int K = 4;
+  typedef float Frag;
+  static __device__ __forceinline__ floatx4 mma(Frag x, Frag y, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0);
+  }
+};
+template <typename T> struct MmaOf;
+template <> struct MmaOf<bf16_t> { typedef MmaBF16 type; };
+template <> struct MmaOf<float> { typedef MmaF32 type; };
+
+// ---- LDS tile with K contiguous rows of KELEMS elements, 16-byte chunks XOR-swizzled by row --
+// chunk c of row r lives at chunk (c ^ (r & 7)): conflict-free ds_read_b128 for MFMA operand
+// reads (rows vary across lanes, same logical chunk) and for the 8-lanes-per-row staging writes.
+template <typename T, int KELEMS> struct KTile {
+  static constexpr int ROWB = KELEMS * (int)sizeof(T);
+  static constexpr int CH = ROWB / 16;
+  static_assert(CH >= 8 && (CH & (CH - 1)) == 0, "row must hold a power-of-two >= 8 chunks");
+  static __device__ __forceinline__ int off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+  static constexpr int bytes(int rows) { return rows * ROWB; }
+};
+
+// operand fragment for MMA k-step `ks` (ks counts Mma::K-sized steps inside the tile row)
+template <typename T, int KELEMS>
+__device__ __forceinline__ typename MmaOf<T>::type::Frag ktile_frag(const char* tile, int row, int ks, int g);
+template <> __device__ __forceinline__ bf16x8_t ktile_frag<bf16_t, 64>(const char* tile, int row, int ks, int g) {
+  return *(const bf16x8_t*)(tile + KTile<bf16_t, 64>::off(row, ks * 4 + g));
+}
+template <> __device__ __forceinline__ float ktile_frag<float, 32>(const char* tile, int row, int ks, int g) {
+  return *(const float*)(tile + KTile<float, 32>::off(row, ks) + 4 * g);
+}
+template <> __device__ __forceinline__ float ktile_frag<float, 64>(const char* tile, int row, int ks, int g) {
+  return *(const float*)(tile + KTile<float, 64>::off(row, ks) + 4 * g);
+}
+
+// ---- counter-based dropout RNG (K17): mask is recomputed in backward, never stored ----------
+__device__ __forceinline__ uint32_t rng_hash(uint32_t seed, uint32_t idx) {
+  uint32_t x = idx ^ seed;
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  x += seed * 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x2c1b3c6du;
+  x ^= x >> 12;
+  return x;
+}
+// keep element idx?  thresh = p * 2^32 (0 disables dropout)
+__device__ __forceinline__ float drop_mult(uint32_t seed, uint32_t thresh, float scale, uint32_t idx) {
+  if (thresh == 0u) return 1.0f;
+  return rng_hash(seed, idx) >= thresh ? scale : 0.0f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// XCD-aware bijective block remap (8 XCDs; block b is observed on XCD b % 8): each XCD gets a
+// contiguous run of logical tiles so neighbouring tiles share operand panels in one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (bid >> 3);
+}
+
+}  // namespace rl
+
+#define RL_OK 0
+#define RL_ERR_ARG 1
+#define RL_ERR_LAUNCH 2

@@ -1,0 +1,19 @@
+// Engine interface shared by engine.hip (implementation) and capi.hip (C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/realise_hip.h"
+
+namespace rl {
+struct EngineBase {
+  virtual ~EngineBase() {}
+  virtual int64_t shadow_bytes() const = 0;
+  virtual int64_t workspace_bytes(int B, int S, int Tp) = 0;
+  virtual int bind(void* shadow, void* workspace, int64_t bytes) = 0;
+  virtual int refresh_shadows(hipStream_t st) = 0;
+  virtual int forward(hipStream_t st, const realise_batch& b) = 0;
+  virtual int backward(hipStream_t st, int first, int last) = 0;
+  virtual int get_tap(const char* name, void** ptr, int64_t* numel) = 0;
+};
+EngineBase* make_engine(const realise_config& c, float* p, float* g, float* pu, float* fz, float* bf, int64_t* bi);
+}  // namespace rl

@@ -1,0 +1,693 @@
+// The step engine: SpellBert.forward / SpellBertPho2ResArch3.forward (src/models.py:50-73, 806-870)
+// and their backward as ONE host call each.  The engine owns the launch order, the activation
+// workspace plan and the compute-dtype operand shadows; it enqueues every kernel on the caller's HIP
+// stream and never synchronises or allocates, so a step is two C calls from Python (forward,
+// backward) plus the optimizer call, independent of the ~900 kernels in between.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "attention.h"
+#include "engine.h"
+#include "gemm.h"
+#include "layout.h"
+#include "ops.h"
+
+namespace rl {
+
+#define RL_TRY(expr) do { const int _rc = (expr); if (_rc != RL_OK) { fprintf(stderr, "[realise_hip] %s failed (%d) at %s:%d\n", #expr, _rc, __FILE__, __LINE__); return _rc; } } while (0)
+
+static inline int64_t al256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+struct Bump {
+  int64_t off = 0;
+  int64_t take(int64_t bytes) { const int64_t o = off; off = al256(off + bytes); return o; }
+};
+
+static inline uint64_t splitmix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+template <typename T> struct Engine : EngineBase {
+  realise_config cfg;
+  Layout L;
+  float *P = nullptr, *G = nullptr, *PU = nullptr, *FZ = nullptr, *BF = nullptr;
+  int64_t* BI = nullptr;
+  char* sh = nullptr;      // shadow arena
+  char* ws = nullptr;      // workspace
+  int64_t ws_bytes = 0;
+  int H, nh, I, V;
+
+  // ---------------------------------------------------------------- shadows (offsets in bytes)
+  struct LayerSh { int64_t qkv_w, qkv_wT, ao_w, ao_wT, in_w, in_wT, out_w, out_wT; };
+  struct BlockSh { int64_t w1f, w1d, w2f, w2d, wsf, wsd; int cin_pad; };
+  std::vector<LayerSh> sh_bert, sh_pho, sh_out;
+  BlockSh sh_blk[5];
+  int64_t sh_cls_w = 0, sh_cls_wT = 0, sh_gru_hh = 0, sh_gru_hhT = 0, sh_glyph = 0;
+  int64_t shadow_total = 0;
+  bool glyph_built = false;
+
+  // ---------------------------------------------------------------- workspace plan (byte offsets)
+  struct LayerAct { int64_t qkv, lse, ctx, s1, rstd1, y1, pre, post, s2, rstd2, y2; };
+  struct StackAct { int64_t emb_y, emb_xhat, emb_rstd; std::vector<LayerAct> layers; };
+  struct BnAct { int64_t mean, rstd, scale, shift; };
+  struct BlockAct { int64_t c1, h1, c2, cs, out; BnAct bn1, bn2, bns; int Hin, Hout, Pout; };
+  struct Plan {
+    int B = 0, S = 0, Tp = 0;
+    int64_t total = 0;
+    StackAct bert, pho, outb;
+    BlockAct blk[5];
+    int64_t mask_add, out_d, dlogits, count, loss_internal;
+    int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
+    int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
+    int64_t bn_sums;
+    // backward scratch
+    int64_t gA, gB, gC, gE, gD, gF, rowdot, X1, X2, X3, dz;
+    int64_t gru_dh, gru_dgi, gru_dgh, gru_onehot, gru_dtable;
+    int64_t r_dout, r_dc2, r_dcs, r_dh1, r_dc1, r_dx;
+  } pl;
+  std::map<std::string, std::pair<int64_t, int64_t>> taps;   // name -> (byte offset, numel)
+
+  // last forward
+  realise_batch last;
+  std::vector<int> last_alive;
+  bool have_fwd = false;
+
+  template <typename U> U* wp(int64_t off) const { return (U*)(ws + off); }
+  template <typename U> U* sp(int64_t off) const { return (U*)(sh + off); }
+  const float* pp(int64_t off) const { return P + off; }
+  float* gp(int64_t off) const { return G + off; }
+
+  Engine(const realise_config& c, float* p, float* g, float* pu, float* fz, float* bf, int64_t* bi)
+      : cfg(c), L(build_layout(c)), P(p), G(g), PU(pu), FZ(fz), BF(bf), BI(bi) {
+    H = c.hidden; nh = c.heads; I = c.intermediate; V = c.vocab;
+    plan_shadows();
+  }
+
+  static int pad8(int c) { return (c + 7) & ~7; }
+
+  void plan_shadows() {
+    Bump b;
+    const int64_t e = sizeof(T);
+    auto plan_stack = [&](std::vector<LayerSh>& v, int n) {
+      v.resize(n);
+      for (int l = 0; l < n; ++l) {
+        v[l].qkv_w = b.take(3LL * H * H * e); v[l].qkv_wT = b.take(3LL * H * H * e);
+        v[l].ao_w = b.take((int64_t)H * H * e); v[l].ao_wT = b.take((int64_t)H * H * e);
+        v[l].in_w = b.take((int64_t)I * H * e); v[l].in_wT = b.take((int64_t)I * H * e);
+        v[l].out_w = b.take((int64_t)I * H * e); v[l].out_wT = b.take((int64_t)I * H * e);
+      }
+    };
+    plan_stack(sh_bert, cfg.bert_layers);
+    sh_cls_w = b.take((int64_t)V * H * e);
+    sh_cls_wT = b.take((int64_t)V * H * e);
+    if (cfg.model_type == 1) {
+      plan_stack(sh_pho, cfg.pho_layers);
+      plan_stack(sh_out, cfg.out_layers);
+      sh_gru_hh = b.take(3LL * H * H * e);
+      sh_gru_hhT = b.take(3LL * H * H * e);
+      for (int k = 0; k < 5; ++k) {
+        const BlockOff& o = L.blocks[k];
+        BlockSh& s = sh_blk[k];
+        s.cin_pad = pad8(o.cin);
+        s.w1f = b.take((int64_t)o.cout * 9 * s.cin_pad * e);
+        s.w1d = b.take((int64_t)s.cin_pad * 9 * o.cout * e);
+        s.w2f = b.take((int64_t)o.cout * 9 * o.cout * e);
+        s.w2d = b.take((int64_t)o.cout * 9 * o.cout * e);
+        s.wsf = b.take((int64_t)o.cout * s.cin_pad * e);
+        s.wsd = b.take((int64_t)s.cin_pad * o.cout * e);
+      }
+      const int gs = cfg.glyph_size;
+      sh_glyph = b.take((int64_t)V * gs * gs * 8 * e);
+    }
+    shadow_total = b.off;
+  }
+
+  int64_t shadow_bytes() const override { return shadow_total; }
+
+  int refresh_shadows(hipStream_t st) override {
+    if (!sh) return RL_ERR_ARG;
+    auto do_stack = [&](const StackOff& so, const std::vector<LayerSh>& v) -> int {
+      for (size_t l = 0; l < v.size(); ++l) {
+        const LayerOff& o = so.layers[l];
+        RL_TRY(cast_transpose<T>(st, pp(o.qkv_w), 3 * H, H, sp<T>(v[l].qkv_w), sp<T>(v[l].qkv_wT)));
+        RL_TRY(cast_transpose<T>(st, pp(o.ao_w), H, H, sp<T>(v[l].ao_w), sp<T>(v[l].ao_wT)));
+        RL_TRY(cast_transpose<T>(st, pp(o.in_w), I, H, sp<T>(v[l].in_w), sp<T>(v[l].in_wT)));
+        RL_TRY(cast_transpose<T>(st, pp(o.out_w), H, I, sp<T>(v[l].out_w), sp<T>(v[l].out_wT)));
+      }
+      return RL_OK;
+    };
+    RL_TRY(do_stack(L.bert, sh_bert));
+    RL_TRY(cast_transpose<T>(st, pp(L.cls_w), V, H, sp<T>(sh_cls_w), sp<T>(sh_cls_wT)));
+    if (cfg.model_type == 1) {
+      RL_TRY(do_stack(L.pho, sh_pho));
+      RL_TRY(do_stack(L.outb, sh_out));
+      RL_TRY(cast_transpose<T>(st, pp(L.gru_w_hh), 3 * H, H, sp<T>(sh_gru_hh), sp<T>(sh_gru_hhT)));
+      for (int k = 0; k < 5; ++k) {
+        const BlockOff& o = L.blocks[k];
+        const BlockSh& s = sh_blk[k];
+        RL_TRY(conv_weight_shadow<T>(st, pp(o.w1), o.cout, o.cin, 9, s.cin_pad, s.cin_pad, sp<T>(s.w1f), sp<T>(s.w1d)));
+        RL_TRY(conv_weight_shadow<T>(st, pp(o.w2), o.cout, o.cout, 9, o.cout, o.cout, sp<T>(s.w2f), sp<T>(s.w2d)));
+        RL_TRY(conv_weight_shadow<T>(st, pp(o.ws), o.cout, o.cin, 1, s.cin_pad, s.cin_pad, sp<T>(s.wsf), sp<T>(s.wsd)));
+      }
+      // the glyph table is frozen (requires_grad=False, models.py:679): rebuilt on every refresh anyway,
+      // it only changes through load_state_dict / build_glyce_embed*
+      RL_TRY(glyph_shadow<T>(st, FZ + L.glyph, V, cfg.num_fonts, cfg.glyph_size * cfg.glyph_size, 8, sp<T>(sh_glyph)));
+    }
+    return RL_OK;
+  }
+
+  // ---------------------------------------------------------------- workspace planning
+  void tap(const std::string& name, int64_t off, int64_t numel) { taps[name] = {off, numel}; }
+
+  Plan make_plan(int B, int S, int Tp) {
+    Plan p;
+    p.B = B; p.S = S; p.Tp = Tp;
+    Bump b;
+    const int64_t e = sizeof(T), Tk = (int64_t)B * S;
+    taps.clear();
+    auto plan_stack = [&](StackAct& a, int n, const std::string& name) {
+      a.emb_y = b.take(Tk * H * e); a.emb_xhat = b.take(Tk * H * e); a.emb_rstd = b.take(Tk * 4);
+      tap(name + ".emb", a.emb_y, Tk * H);
+      a.layers.resize(n);
+      for (int l = 0; l < n; ++l) {
+        LayerAct& x = a.layers[l];
+        x.qkv = b.take(Tk * 3 * H * e); x.lse = b.take((int64_t)B * nh * S * 4); x.ctx = b.take(Tk * H * e);
+        x.s1 = b.take(Tk * H * e); x.rstd1 = b.take(Tk * 4); x.y1 = b.take(Tk * H * e);
+        x.pre = b.take(Tk * I * e); x.post = b.take(Tk * I * e);
+        x.s2 = b.take(Tk * H * e); x.rstd2 = b.take(Tk * 4); x.y2 = b.take(Tk * H * e);
+        const std::string ln = name + ".layer." + std::to_string(l);
+        tap(ln + ".qkv", x.qkv, Tk * 3 * H); tap(ln + ".ctx", x.ctx, Tk * H); tap(ln + ".attn_out", x.y1, Tk * H);
+        tap(ln + ".inter", x.post, Tk * I); tap(ln + ".out", x.y2, Tk * H);
+      }
+    };
+    p.mask_add = b.take(Tk * 4);
+    plan_stack(p.bert, cfg.bert_layers, "bert");
+    p.out_d = b.take(Tk * H * e);
+    p.dlogits = b.take(Tk * V * e);
+    tap("dlogits", p.dlogits, Tk * V);
+    p.count = b.take(256);
+    p.loss_internal = b.take(256);
+    // shared backward scratch
+    p.gA = b.take(Tk * H * e); p.gB = b.take(Tk * H * e); p.gC = b.take(Tk * H * e); p.gE = b.take(Tk * H * e);
+    p.gD = b.take(Tk * I * e); p.gF = b.take(Tk * 3 * H * e); p.rowdot = b.take((int64_t)B * nh * S * 4);
+    tap("d_x0", p.gB, Tk * H);
+    if (cfg.model_type == 1) {
+      plan_stack(p.pho, cfg.pho_layers, "pho_model");
+      plan_stack(p.outb, cfg.out_layers, "output_block");
+      p.gru_table = b.take(64LL * 3 * H * 4);
+      p.gru_hs = b.take((int64_t)Tp * Tk * H * e);
+      p.gru_rzn = b.take((int64_t)Tp * Tk * 3 * H * e);
+      p.gru_gh = b.take((int64_t)Tp * Tk * 3 * H * e);
+      p.gru_out = b.take(Tk * H * e);
+      tap("pho_gru", p.gru_out, Tk * H);
+      int hin = cfg.glyph_size;
+      for (int k = 0; k < 5; ++k) {
+        BlockAct& a = p.blk[k];
+        const int C = L.blocks[k].cout;
+        a.Hin = hin; a.Hout = hin / 2; a.Pout = (int)(Tk * a.Hout * a.Hout);
+        const int64_t n = (int64_t)a.Pout * C * e;
+        a.c1 = b.take(n); a.h1 = b.take(n); a.c2 = b.take(n); a.cs = b.take(n); a.out = b.take(n);
+        for (BnAct* q : {&a.bn1, &a.bn2, &a.bns}) {
+          q->mean = b.take(C * 4); q->rstd = b.take(C * 4); q->scale = b.take(C * 4); q->shift = b.take(C * 4);
+        }
+        tap("resnet.block" + std::to_string(k + 1), a.out, (int64_t)a.Pout * C);
+        hin = a.Hout;
+      }
+      p.bn_sums = b.take(2 * 1024 * 4);
+      p.res_xhat = b.take(Tk * H * e); p.res_rstd = b.take(Tk * 4); p.res_h = b.take(Tk * H * e);
+      p.gate_mean = b.take((int64_t)B * H * 4); p.gate_msum = b.take(B * 4 + 256); p.gate_g = b.take(Tk * 16);
+      p.fused = b.take(Tk * H * e);
+      tap("res_h", p.res_h, Tk * H); tap("fused", p.fused, Tk * H);
+      p.X1 = b.take(Tk * H * e); p.X2 = b.take(Tk * H * e); p.X3 = b.take(Tk * H * e); p.dz = b.take(Tk * 16);
+      p.gru_dh = b.take(Tk * H * e); p.gru_dgi = b.take(Tk * 3 * H * e); p.gru_dgh = b.take(Tk * 3 * H * e);
+      p.gru_onehot = b.take(Tk * 64 * e); p.gru_dtable = b.take(64LL * 3 * H * 4);
+      const int64_t big = (int64_t)p.blk[0].Pout * 64 * e;     // block 1 is the largest activation
+      p.r_dout = b.take(big); p.r_dc2 = b.take(big); p.r_dcs = b.take(big); p.r_dh1 = b.take(big); p.r_dc1 = b.take(big);
+      p.r_dx = b.take(big);
+    }
+    p.total = b.off;
+    return p;
+  }
+
+  int64_t workspace_bytes(int B, int S, int Tp) override {
+    std::map<std::string, std::pair<int64_t, int64_t>> keep = taps;
+    const Plan p = make_plan(B, S, Tp > 0 ? Tp : 1);
+    taps = keep;
+    return p.total;
+  }
+  int bind(void* shadow, void* workspace, int64_t bytes) override {
+    sh = (char*)shadow; ws = (char*)workspace; ws_bytes = bytes; pl = Plan(); have_fwd = false;
+    return RL_OK;
+  }
+  int get_tap(const char* name, void** ptr, int64_t* numel) override {
+    auto it = taps.find(name);
+    if (it == taps.end() || !ws) return RL_ERR_ARG;
+    *ptr = ws + it->second.first; *numel = it->second.second;
+    return RL_OK;
+  }
+
+  // ---------------------------------------------------------------- dropout sites
+  DropParams site(int id, float p) const {
+    DropParams d;
+    if (!last.training || p <= 0.f) return d;
+    d.seed = (uint32_t)splitmix(last.seed * 0x100000001B3ull + (uint64_t)id);
+    d.thresh = (uint32_t)((double)p * 4294967296.0);
+    d.scale = 1.0f / (1.0f - p);
+    return d;
+  }
+  static void set_drop(EpiParams<T>& ep, const DropParams& d) { ep.drop_seed = d.seed; ep.drop_thresh = d.thresh; ep.drop_scale = d.scale; }
+
+  // ---------------------------------------------------------------- BERT stack
+  int stack_forward(hipStream_t st, int sid, const StackOff& so, const std::vector<LayerSh>& shs, StackAct& a,
+                    const int64_t* ids, const T* embeds, int pos_zero, const T** out) {
+    const int B = pl.B, S = pl.S, Tk = B * S;
+    {
+      LnFwdArgs<T> ln;
+      ln.rows = Tk; ln.H = H; ln.S = S;
+      ln.in_mode = ids ? 1 : 2; ln.x = embeds; ln.ids = ids;
+      ln.word = so.word >= 0 ? pp(so.word) : nullptr;
+      ln.pos = pp(so.pos); ln.type0 = pp(so.type); ln.pos_zero = pos_zero;
+      ln.gamma = pp(so.ln_g); ln.beta = pp(so.ln_b); ln.eps = cfg.ln_eps;
+      ln.y = wp<T>(a.emb_y); ln.xhat = wp<T>(a.emb_xhat); ln.rstd = wp<float>(a.emb_rstd);
+      ln.drop = site(sid * 1000 + 900, cfg.hidden_dropout);
+      RL_TRY(ln_fwd<T>(st, ln));
+    }
+    const T* x = wp<T>(a.emb_y);
+    for (size_t l = 0; l < a.layers.size(); ++l) {
+      const LayerOff& o = so.layers[l];
+      const LayerSh& w = shs[l];
+      LayerAct& t = a.layers[l];
+      {  // fused QKV projection (modeling_bert.py:221,231-232)
+        EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = wp<T>(t.qkv); ep.ldo = 3 * H; ep.bias = pp(o.qkv_b);
+        RL_TRY(gemm_nt<T>(st, x, H, sp<T>(w.qkv_w), H, Tk, 3 * H, H, ep));
+      }
+      {
+        const DropParams d = site(sid * 1000 + (int)l * 10 + 1, cfg.attn_dropout);
+        const T* q = wp<T>(t.qkv);
+        RL_TRY(attn_fwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), H, wp<float>(t.lse), B, nh, S,
+                           d.seed, d.thresh, d.scale));
+      }
+      {  // BertSelfOutput: dense -> dropout -> + input -> LayerNorm (modeling_bert.py:273-277)
+        EpiParams<T> ep; ep.mode = EPI_DROP_RESID; ep.out = wp<T>(t.s1); ep.ldo = H; ep.bias = pp(o.ao_b);
+        ep.aux = x; ep.ldaux = H; set_drop(ep, site(sid * 1000 + (int)l * 10 + 2, cfg.hidden_dropout));
+        RL_TRY(gemm_nt<T>(st, wp<T>(t.ctx), H, sp<T>(w.ao_w), H, Tk, H, H, ep));
+        LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = wp<T>(t.s1); ln.gamma = pp(o.ao_ln_g); ln.beta = pp(o.ao_ln_b);
+        ln.eps = cfg.ln_eps; ln.y = wp<T>(t.y1); ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
+        RL_TRY(ln_fwd<T>(st, ln));
+      }
+      {  // BertIntermediate (modeling_bert.py:326-329)
+        EpiParams<T> ep; ep.mode = EPI_GELU; ep.out = wp<T>(t.post); ep.out2 = wp<T>(t.pre); ep.ldo = I; ep.bias = pp(o.in_b);
+        RL_TRY(gemm_nt<T>(st, wp<T>(t.y1), H, sp<T>(w.in_w), H, Tk, I, H, ep));
+      }
+      {  // BertOutput (modeling_bert.py:339-343)
+        EpiParams<T> ep; ep.mode = EPI_DROP_RESID; ep.out = wp<T>(t.s2); ep.ldo = H; ep.bias = pp(o.out_b);
+        ep.aux = wp<T>(t.y1); ep.ldaux = H; set_drop(ep, site(sid * 1000 + (int)l * 10 + 3, cfg.hidden_dropout));
+        RL_TRY(gemm_nt<T>(st, wp<T>(t.post), I, sp<T>(w.out_w), I, Tk, H, I, ep));
+        LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = wp<T>(t.s2); ln.gamma = pp(o.out_ln_g); ln.beta = pp(o.out_ln_b);
+        ln.eps = cfg.ln_eps; ln.y = wp<T>(t.y2); ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
+        RL_TRY(ln_fwd<T>(st, ln));
+      }
+      x = wp<T>(t.y2);
+    }
+    *out = x;
+    return RL_OK;
+  }
+
+  // backward of layers [hi .. lo] of a stack; gA holds d(output of layer hi) on entry and d(input of layer lo) on exit
+  int layers_backward(hipStream_t st, int sid, const StackOff& so, const std::vector<LayerSh>& shs, StackAct& a, int hi, int lo,
+                      T* gA) {
+    const int B = pl.B, S = pl.S, Tk = B * S;
+    T* gB = wp<T>(pl.gB); T* gC = wp<T>(pl.gC); T* gE = wp<T>(pl.gE); T* gD = wp<T>(pl.gD); T* gF = wp<T>(pl.gF);
+    for (int l = hi; l >= lo; --l) {
+      const LayerOff& o = so.layers[l];
+      const LayerSh& w = shs[l];
+      LayerAct& t = a.layers[l];
+      const T* x_in = l > 0 ? wp<T>(a.layers[l - 1].y2) : wp<T>(a.emb_y);
+      const DropParams d3 = site(sid * 1000 + l * 10 + 3, cfg.hidden_dropout);
+      const DropParams d2 = site(sid * 1000 + l * 10 + 2, cfg.hidden_dropout);
+      const DropParams d1 = site(sid * 1000 + l * 10 + 1, cfg.attn_dropout);
+      {  // output LayerNorm: gA = d y2 -> gB = d s2 (residual part of d y1), gC = d(dense out) = d s2 * dropmask
+        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
+        ln.gamma = pp(o.out_ln_g); ln.dx = gB; ln.dx_drop = d3.thresh ? gC : nullptr; ln.out_drop = d3;
+        ln.dgamma = gp(o.out_ln_g); ln.dbeta = gp(o.out_ln_b);
+        RL_TRY(ln_bwd<T>(st, ln));
+      }
+      const T* dso = d3.thresh ? gC : gB;
+      RL_TRY(bias_grad<T>(st, dso, H, Tk, H, gp(o.out_b)));
+      { TnEpi te; te.out = gp(o.out_w); te.ldo = I; RL_TRY(gemm_tn<T>(st, dso, H, wp<T>(t.post), I, Tk, H, I, te)); }
+      {  // d pre = (d s2' . W_out) * gelu'(pre)
+        EpiParams<T> ep; ep.mode = EPI_GELU_BWD; ep.out = gD; ep.ldo = I; ep.aux = wp<T>(t.pre); ep.ldaux = I;
+        RL_TRY(gemm_nt<T>(st, dso, H, sp<T>(w.out_wT), H, Tk, I, H, ep));
+      }
+      RL_TRY(bias_grad<T>(st, gD, I, Tk, I, gp(o.in_b)));
+      { TnEpi te; te.out = gp(o.in_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gD, I, wp<T>(t.y1), H, Tk, I, H, te)); }
+      {  // d y1 = d s2 + d pre . W_in
+        EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gB; ep.ldo = H; ep.accumulate = 1;
+        RL_TRY(gemm_nt<T>(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
+      }
+      {  // attention-output LayerNorm: gB = d y1 -> gA = d s1, gC = d(dense out)
+        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
+        ln.gamma = pp(o.ao_ln_g); ln.dx = gA; ln.dx_drop = d2.thresh ? gC : nullptr; ln.out_drop = d2;
+        ln.dgamma = gp(o.ao_ln_g); ln.dbeta = gp(o.ao_ln_b);
+        RL_TRY(ln_bwd<T>(st, ln));
+      }
+      const T* dsa = d2.thresh ? gC : gA;
+      RL_TRY(bias_grad<T>(st, dsa, H, Tk, H, gp(o.ao_b)));
+      { TnEpi te; te.out = gp(o.ao_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dsa, H, wp<T>(t.ctx), H, Tk, H, H, te)); }
+      {  // d ctx = d s1' . W_ao
+        EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gE; ep.ldo = H;
+        RL_TRY(gemm_nt<T>(st, dsa, H, sp<T>(w.ao_wT), H, Tk, H, H, ep));
+      }
+      {
+        const T* q = wp<T>(t.qkv);
+        RL_TRY(attn_bwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), gE, H, wp<float>(t.lse),
+                           wp<float>(pl.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale));
+      }
+      RL_TRY(bias_grad<T>(st, gF, 3 * H, Tk, 3 * H, gp(o.qkv_b)));
+      { TnEpi te; te.out = gp(o.qkv_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gF, 3 * H, x_in, H, Tk, 3 * H, H, te)); }
+      {  // d x_in = d s1 + d qkv . W_qkv
+        EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H; ep.accumulate = 1;
+        RL_TRY(gemm_nt<T>(st, gF, 3 * H, sp<T>(w.qkv_wT), 3 * H, Tk, H, 3 * H, ep));
+      }
+    }
+    return RL_OK;
+  }
+
+  // embeddings backward: gA = d(embedding output) -> dx (T*, d of the pre-LayerNorm sum) ; scatters table grads
+  int emb_backward(hipStream_t st, int sid, const StackOff& so, StackAct& a, const int64_t* ids, int pos_zero, const T* gA, T* dx) {
+    const int B = pl.B, S = pl.S, Tk = B * S;
+    LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gA; ln.in_drop = site(sid * 1000 + 900, cfg.hidden_dropout);
+    ln.xhat = wp<T>(a.emb_xhat); ln.rstd = wp<float>(a.emb_rstd); ln.gamma = pp(so.ln_g); ln.dx = dx;
+    ln.dgamma = gp(so.ln_g); ln.dbeta = gp(so.ln_b);
+    RL_TRY(ln_bwd<T>(st, ln));
+    RL_TRY(embed_bwd<T>(st, dx, ids, B, S, H, (ids && so.word >= 0) ? gp(so.word) : nullptr, gp(so.pos), pos_zero, gp(so.type)));
+    return RL_OK;
+  }
+
+  // ---------------------------------------------------------------- glyph ResNet (char_cnn.py)
+  ConvLoader<T> geom(const T* src, const int64_t* index, int rows, int Hr, int Hs, int C, int ksz, int stride, int pad, int mode) const {
+    ConvLoader<T> g;
+    g.src = src; g.img_index = index; g.rows = rows; g.Hr = Hr; g.Wr = Hr; g.Hs = Hs; g.Ws = Hs; g.C = C;
+    g.KH = ksz; g.KW = ksz; g.stride = stride; g.pad = pad; g.mode = mode; g.K = ksz * ksz * C;
+    return g;
+  }
+  int bn_forward(hipStream_t st, const T* x, int Pn, int C, const BnOff& o, const BnAct& a) {
+    if (last.training) {
+      float* sums = wp<float>(pl.bn_sums);
+      RL_TRY(fill_f32(st, sums, 0.f, 2 * C));
+      RL_TRY(col_sum<T>(st, x, Pn, C, sums));
+      RL_TRY(bn_finalize_mean(st, sums, C, Pn, wp<float>(a.mean)));
+      RL_TRY(col_sumsq_centered<T>(st, x, Pn, C, wp<float>(a.mean), sums + C));
+      RL_TRY(bn_finalize_train(st, wp<float>(a.mean), sums + C, C, Pn, pp(o.g), pp(o.b), 1e-5f, 0.1f, BF + o.rmean, BF + o.rvar,
+                               wp<float>(a.rstd), wp<float>(a.scale), wp<float>(a.shift)));
+      RL_TRY(add_i64(st, BI + o.nbt, 1, 1));
+    } else {
+      RL_TRY(bn_finalize_eval(st, C, pp(o.g), pp(o.b), 1e-5f, BF + o.rmean, BF + o.rvar, wp<float>(a.scale), wp<float>(a.shift)));
+    }
+    return RL_OK;
+  }
+  int resnet_forward(hipStream_t st, const int64_t* ids, const T** out) {
+    const int N = pl.B * pl.S;
+    const T* x = sp<T>(sh_glyph);
+    const int64_t* index = ids;
+    for (int k = 0; k < 5; ++k) {
+      const BlockOff& o = L.blocks[k];
+      const BlockSh& s = sh_blk[k];
+      BlockAct& a = pl.blk[k];
+      const int Co = o.cout, Cin = s.cin_pad, Pn = a.Pout;
+      EpiParams<T> ep; ep.mode = EPI_STORE; ep.ldo = Co;
+      // residual_function.0: 3x3 stride 2 pad 1 (char_cnn.py:16)
+      ep.out = wp<T>(a.c1);
+      RL_TRY(gemm_nt_conv<T>(st, geom(x, index, Pn, a.Hout, a.Hin, Cin, 3, 2, 1, 0), sp<T>(s.w1f), 9 * Cin, Pn, Co, 9 * Cin, ep));
+      RL_TRY(bn_forward(st, wp<T>(a.c1), Pn, Co, o.bn1, a.bn1));
+      RL_TRY(bn_apply<T>(st, wp<T>(a.c1), wp<float>(a.bn1.scale), wp<float>(a.bn1.shift), nullptr, nullptr, nullptr, wp<T>(a.h1), Pn, Co, 1));
+      // residual_function.3: 3x3 stride 1 pad 1 (char_cnn.py:19)
+      ep.out = wp<T>(a.c2);
+      RL_TRY(gemm_nt_conv<T>(st, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0), sp<T>(s.w2f), 9 * Co, Pn, Co, 9 * Co, ep));
+      RL_TRY(bn_forward(st, wp<T>(a.c2), Pn, Co, o.bn2, a.bn2));
+      // shortcut: 1x1 stride 2 (char_cnn.py:26-28)
+      ep.out = wp<T>(a.cs);
+      RL_TRY(gemm_nt_conv<T>(st, geom(x, index, Pn, a.Hout, a.Hin, Cin, 1, 2, 0, 0), sp<T>(s.wsf), Cin, Pn, Co, Cin, ep));
+      RL_TRY(bn_forward(st, wp<T>(a.cs), Pn, Co, o.bns, a.bns));
+      RL_TRY(bn_apply<T>(st, wp<T>(a.c2), wp<float>(a.bn2.scale), wp<float>(a.bn2.shift), wp<T>(a.cs), wp<float>(a.bns.scale),
+                         wp<float>(a.bns.shift), wp<T>(a.out), Pn, Co, 1));
+      x = wp<T>(a.out);
+      index = nullptr;
+    }
+    *out = x;
+    return RL_OK;
+  }
+  // d_out: gradient w.r.t. block-5 output [N,768]
+  int resnet_backward(hipStream_t st, const int64_t* ids, const T* d_top) {
+    float* sums = wp<float>(pl.bn_sums);
+    const T* d_out = d_top;
+    for (int k = 4; k >= 0; --k) {
+      const BlockOff& o = L.blocks[k];
+      const BlockSh& s = sh_blk[k];
+      BlockAct& a = pl.blk[k];
+      const int Co = o.cout, Cin = s.cin_pad, Pn = a.Pout;
+      const T* x_in = k > 0 ? wp<T>(pl.blk[k - 1].out) : sp<T>(sh_glyph);
+      const int64_t* index = k > 0 ? nullptr : ids;
+      T* dc2 = wp<T>(pl.r_dc2); T* dcs = wp<T>(pl.r_dcs); T* dh1 = wp<T>(pl.r_dh1); T* dc1 = wp<T>(pl.r_dc1);
+      // out = relu(bn2(c2) + bns(cs))
+      RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));
+      RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), Pn, Co, sums));
+      RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), pp(o.bn2.g), sums,
+                             Pn, Co, dc2, gp(o.bn2.g), gp(o.bn2.b)));
+      RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));
+      RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), Pn, Co, sums));
+      RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), pp(o.bns.g), sums,
+                             Pn, Co, dcs, gp(o.bns.g), gp(o.bns.b)));
+      // conv2 (3x3 s1): weight grad and data grad
+      { TnEpi te; te.mode = TN_CONVW; te.out = gp(o.w2); te.Cin = Co; te.Cpad = Co; te.KHW = 9;
+        RL_TRY(gemm_tn_conv<T>(st, dc2, Co, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0), Pn, Co, 9 * Co, te)); }
+      { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = dh1; ep.ldo = Co;
+        RL_TRY(gemm_nt_conv<T>(st, geom(dc2, nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 1), sp<T>(s.w2d), 9 * Co, Pn, Co, 9 * Co, ep)); }
+      // h1 = relu(bn1(c1))
+      RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));
+      RL_TRY(bn_bwd_reduce<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), Pn, Co, sums));
+      RL_TRY(bn_bwd_apply<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), pp(o.bn1.g), sums,
+                             Pn, Co, dc1, gp(o.bn1.g), gp(o.bn1.b)));
+      // conv1 (3x3 s2) and shortcut (1x1 s2) weight grads
+      { TnEpi te; te.mode = TN_CONVW; te.out = gp(o.w1); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 9;
+        RL_TRY(gemm_tn_conv<T>(st, dc1, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 3, 2, 1, 0), Pn, Co, 9 * Cin, te)); }
+      { TnEpi te; te.mode = TN_CONVW; te.out = gp(o.ws); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 1;
+        RL_TRY(gemm_tn_conv<T>(st, dcs, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 1, 2, 0, 0), Pn, Co, Cin, te)); }
+      if (k > 0) {   // d x_in = dgrad(conv1) + dgrad(shortcut); the glyph table itself is frozen
+        const int Pin = pl.blk[k - 1].Pout;
+        T* dx = (d_out == wp<T>(pl.r_dx)) ? wp<T>(pl.r_dout) : wp<T>(pl.r_dx);
+        EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = dx; ep.ldo = Cin;
+        RL_TRY(gemm_nt_conv<T>(st, geom(dc1, nullptr, Pin, a.Hin, a.Hout, Co, 3, 2, 1, 1), sp<T>(s.w1d), 9 * Co, Pin, Cin, 9 * Co, ep));
+        ep.accumulate = 1;
+        RL_TRY(gemm_nt_conv<T>(st, geom(dcs, nullptr, Pin, a.Hin, a.Hout, Co, 1, 2, 0, 1), sp<T>(s.wsd), Co, Pin, Cin, Co, ep));
+        d_out = dx;
+      }
+    }
+    return RL_OK;
+  }
+
+  // ---------------------------------------------------------------- pinyin GRU (models.py:818-826)
+  int gru_forward(hipStream_t st) {
+    const int N = pl.B * pl.S, Tp = last.Tp;
+    RL_TRY(gru_table(st, pp(L.pho_emb), pp(L.gru_w_ih), pp(L.gru_b_ih), cfg.pho_vocab, H, wp<float>(pl.gru_table)));
+    for (int t = 0; t < Tp; ++t) {
+      const int n = last_alive[t];
+      if (n <= 0) break;
+      T* hs_t = wp<T>(pl.gru_hs) + (int64_t)t * N * H;
+      T* gh_t = wp<T>(pl.gru_gh) + (int64_t)t * N * 3 * H;
+      const T* hs_prev = t > 0 ? wp<T>(pl.gru_hs) + (int64_t)(t - 1) * N * H : nullptr;
+      if (t > 0) {
+        EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gh_t; ep.ldo = 3 * H; ep.bias = pp(L.gru_b_hh);
+        RL_TRY(gemm_nt<T>(st, hs_prev, H, sp<T>(sh_gru_hh), H, n, 3 * H, H, ep));
+      }
+      GruStepArgs<T> a;
+      a.n_alive = n; a.H = H; a.Tp = Tp; a.t = t; a.table = wp<float>(pl.gru_table); a.pho_idx = last.pho_idx;
+      a.perm = last.pho_perm; a.lens = last.pho_lens_sorted; a.gh = t > 0 ? gh_t : nullptr; a.b_hh = pp(L.gru_b_hh);
+      a.h_prev = hs_prev; a.h_new = hs_t; a.rzn = wp<T>(pl.gru_rzn) + (int64_t)t * N * 3 * H; a.out = wp<T>(pl.gru_out);
+      RL_TRY(gru_step_fwd<T>(st, a));
+    }
+    return RL_OK;
+  }
+  int gru_backward(hipStream_t st, const T* dout) {
+    const int N = pl.B * pl.S, Tp = last.Tp;
+    float* dtable = wp<float>(pl.gru_dtable);
+    RL_TRY(fill_f32(st, dtable, 0.f, 64LL * 3 * H));
+    for (int t = Tp - 1; t >= 0; --t) {
+      const int n = last_alive[t];
+      if (n <= 0) continue;
+      const T* hs_prev = t > 0 ? wp<T>(pl.gru_hs) + (int64_t)(t - 1) * N * H : nullptr;
+      T* gh_t = wp<T>(pl.gru_gh) + (int64_t)t * N * 3 * H;
+      GruStepArgs<T> a;
+      a.n_alive = n; a.H = H; a.Tp = Tp; a.t = t; a.pho_idx = last.pho_idx; a.perm = last.pho_perm; a.lens = last.pho_lens_sorted;
+      a.gh = t > 0 ? gh_t : nullptr; a.b_hh = pp(L.gru_b_hh); a.h_prev = hs_prev;
+      a.rzn = wp<T>(pl.gru_rzn) + (int64_t)t * N * 3 * H; a.dout = dout; a.dh = wp<T>(pl.gru_dh); a.dgi = wp<T>(pl.gru_dgi);
+      a.dgh = wp<T>(pl.gru_dgh); a.onehot = wp<T>(pl.gru_onehot);
+      RL_TRY(gru_step_bwd<T>(st, a));
+      { TnEpi te; te.out = dtable; te.ldo = 3 * H; RL_TRY(gemm_tn<T>(st, a.onehot, 64, a.dgi, 3 * H, n, 64, 3 * H, te)); }
+      RL_TRY(bias_grad<T>(st, a.dgh, 3 * H, n, 3 * H, gp(L.gru_b_hh)));
+      if (t > 0) {
+        { TnEpi te; te.out = gp(L.gru_w_hh); te.ldo = H; RL_TRY(gemm_tn<T>(st, a.dgh, 3 * H, hs_prev, H, n, 3 * H, H, te)); }
+        EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = a.dh; ep.ldo = H; ep.accumulate = 1;
+        RL_TRY(gemm_nt<T>(st, a.dgh, 3 * H, sp<T>(sh_gru_hhT), 3 * H, n, H, 3 * H, ep));
+      }
+    }
+    RL_TRY(gru_table_bwd(st, dtable, 3 * H, pp(L.pho_emb), pp(L.gru_w_ih), cfg.pho_vocab, H, gp(L.pho_emb), gp(L.gru_w_ih), gp(L.gru_b_ih)));
+    return RL_OK;
+  }
+
+  GateArgs<T> gate_args() const {
+    GateArgs<T> g;
+    g.B = pl.B; g.S = pl.S; g.H = H;
+    g.bert = wp<T>(pl.bert.layers.back().y2); g.pho = wp<T>(pl.pho.layers.back().y2); g.res = wp<T>(pl.res_h);
+    g.masks = last.masks; g.W = pp(L.gate_w); g.bias = pp(L.gate_b);
+    g.mean = wp<float>(pl.gate_mean); g.msum = wp<float>(pl.gate_msum); g.g = wp<float>(pl.gate_g); g.fused = wp<T>(pl.fused);
+    return g;
+  }
+
+  // ---------------------------------------------------------------- forward
+  int forward(hipStream_t st, const realise_batch& b) override {
+    if (!sh || !ws) return RL_ERR_ARG;
+    if (b.B < 1 || b.S < 1 || b.S > 128 || b.S > cfg.max_pos) return RL_ERR_ARG;
+    const int Tp = cfg.model_type == 1 ? b.Tp : 1;
+    if (cfg.model_type == 1 && (Tp < 1 || !b.pho_idx || !b.pho_perm || !b.pho_lens_sorted || !b.n_alive)) return RL_ERR_ARG;
+    if (pl.B != b.B || pl.S != b.S || pl.Tp != Tp) {
+      pl = make_plan(b.B, b.S, Tp);
+      if (pl.total > ws_bytes) { fprintf(stderr, "[realise_hip] workspace too small: need %lld have %lld\n", (long long)pl.total, (long long)ws_bytes); return RL_ERR_ARG; }
+    }
+    last = b;
+    last.Tp = Tp;
+    last_alive.assign(Tp, 0);
+    if (cfg.model_type == 1) for (int t = 0; t < Tp; ++t) last_alive[t] = b.n_alive[t];
+    last.n_alive = nullptr;
+    have_fwd = false;
+    const int Tk = b.B * b.S;
+    RL_TRY(mask_to_additive(st, b.masks, wp<float>(pl.mask_add), Tk));
+    const T* bert_h = nullptr;
+    RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, b.src_idx, nullptr, 0, &bert_h));
+    const T* top = bert_h;
+    if (cfg.model_type == 1) {
+      RL_TRY(gru_forward(st));
+      const T* pho_h = nullptr;
+      RL_TRY(stack_forward(st, 1, L.pho, sh_pho, pl.pho, nullptr, wp<T>(pl.gru_out), 0, &pho_h));
+      const T* res = nullptr;
+      RL_TRY(resnet_forward(st, b.src_idx, &res));
+      {
+        LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = res; ln.gamma = pp(L.res_ln_g); ln.beta = pp(L.res_ln_b); ln.eps = cfg.ln_eps;
+        ln.y = wp<T>(pl.res_h); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
+        RL_TRY(ln_fwd<T>(st, ln));
+      }
+      RL_TRY(gate_fwd<T>(st, gate_args()));
+      RL_TRY(stack_forward(st, 2, L.outb, sh_out, pl.outb, nullptr, wp<T>(pl.fused), 1, &top));
+    }
+    const DropParams dfin = site(5000, cfg.hidden_dropout);
+    const T* cls_in = top;
+    if (dfin.thresh) { RL_TRY(dropout_apply<T>(st, top, wp<T>(pl.out_d), Tk, H, dfin)); cls_in = wp<T>(pl.out_d); }
+    {  // tied vocabulary classifier (models.py:859)
+      EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = (T*)b.logits_out; ep.ldo = V; ep.bias = pp(L.cls_b);
+      RL_TRY(gemm_nt<T>(st, cls_in, H, sp<T>(sh_cls_w), H, Tk, V, H, ep));
+    }
+    if (b.tgt_idx != nullptr) {
+      if (!b.loss_masks || !b.loss_out) return RL_ERR_ARG;
+      RL_TRY(ce_loss<T>(st, (const T*)b.logits_out, V, b.tgt_idx, b.loss_masks, Tk, V, b.loss_out, wp<float>(pl.count),
+                        b.want_dlogits ? wp<T>(pl.dlogits) : nullptr));
+    }
+    have_fwd = b.training && b.tgt_idx != nullptr && b.want_dlogits;
+    return RL_OK;
+  }
+
+  // ---------------------------------------------------------------- backward, in bucket-sized stages
+  int n_stages() const { return (int)L.buckets.size(); }
+
+  int stage_head(hipStream_t st) {      // classifier + final dropout ; leaves d(top hidden) in gA
+    const int Tk = pl.B * pl.S;
+    const T* dl = wp<T>(pl.dlogits);
+    T* gA = wp<T>(pl.gA);
+    const DropParams dfin = site(5000, cfg.hidden_dropout);
+    const T* top = cfg.model_type == 1 ? wp<T>(pl.outb.layers.back().y2) : wp<T>(pl.bert.layers.back().y2);
+    const T* cls_in = dfin.thresh ? wp<T>(pl.out_d) : top;
+    RL_TRY(bias_grad<T>(st, dl, V, Tk, V, gp(L.cls_b)));
+    { TnEpi te; te.out = gp(L.cls_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dl, V, cls_in, H, Tk, V, H, te)); }
+    { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H;
+      RL_TRY(gemm_nt<T>(st, dl, V, sp<T>(sh_cls_wT), V, Tk, H, V, ep)); }
+    if (dfin.thresh) RL_TRY(dropout_apply<T>(st, gA, gA, Tk, H, dfin));
+    return RL_OK;
+  }
+
+  int run_stage(hipStream_t st, int s) {
+    const int Tk = pl.B * pl.S;
+    T* gA = wp<T>(pl.gA);
+    if (cfg.model_type == 0) {
+      // stage g (0..groups-1): bert layer group g (stage 0 also runs the head); last stage: embeddings
+      const int groups = L.bert_groups;
+      if (s < groups) {
+        if (s == 0) RL_TRY(stage_head(st));
+        int hi = cfg.bert_layers - 1 - 4 * s;
+        int lo = hi - 3 > 0 ? hi - 3 : 0;
+        RL_TRY(layers_backward(st, 0, L.bert, sh_bert, pl.bert, hi, lo, gA));
+      } else {
+        RL_TRY(emb_backward(st, 0, L.bert, pl.bert, last.src_idx, 0, gA, wp<T>(pl.gB)));
+      }
+      return RL_OK;
+    }
+    switch (s) {
+      case 0: {   // head + output_block
+        RL_TRY(stage_head(st));
+        RL_TRY(layers_backward(st, 2, L.outb, sh_out, pl.outb, cfg.out_layers - 1, 0, gA));
+        RL_TRY(emb_backward(st, 2, L.outb, pl.outb, nullptr, 1, gA, wp<T>(pl.gB)));      // gB = d fused
+      } break;
+      case 1: {   // gate, resnet LayerNorm, glyph ResNet
+        GateArgs<T> g = gate_args();
+        g.dfused = wp<T>(pl.gB); g.dbert = wp<T>(pl.X1); g.dpho = wp<T>(pl.X2); g.dres = wp<T>(pl.X3); g.dz = wp<float>(pl.dz);
+        g.dW = gp(L.gate_w); g.dbias = gp(L.gate_b);
+        RL_TRY(gate_bwd<T>(st, g));
+        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = wp<T>(pl.X3); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
+        ln.gamma = pp(L.res_ln_g); ln.dx = wp<T>(pl.r_dout); ln.dgamma = gp(L.res_ln_g); ln.dbeta = gp(L.res_ln_b);
+        RL_TRY(ln_bwd<T>(st, ln));
+        RL_TRY(resnet_backward(st, last.src_idx, wp<T>(pl.r_dout)));
+      } break;
+      case 2: {   // pho_model + GRU
+        T* g2 = wp<T>(pl.X2);
+        RL_TRY(layers_backward(st, 1, L.pho, sh_pho, pl.pho, cfg.pho_layers - 1, 0, g2));
+        RL_TRY(emb_backward(st, 1, L.pho, pl.pho, nullptr, 0, g2, wp<T>(pl.gE)));       // gE = d gru_out (original order)
+        RL_TRY(gru_backward(st, wp<T>(pl.gE)));
+      } break;
+      default: {
+        const int g = s - 3;
+        T* g1 = wp<T>(pl.X1);
+        if (g < L.bert_groups) {
+          int hi = cfg.bert_layers - 1 - 4 * g;
+          int lo = hi - 3 > 0 ? hi - 3 : 0;
+          RL_TRY(layers_backward(st, 0, L.bert, sh_bert, pl.bert, hi, lo, g1));
+        } else {
+          RL_TRY(emb_backward(st, 0, L.bert, pl.bert, last.src_idx, 0, g1, wp<T>(pl.gB)));
+        }
+      } break;
+    }
+    return RL_OK;
+  }
+
+  int backward(hipStream_t st, int first, int last_stage) override {
+    if (!have_fwd) { fprintf(stderr, "[realise_hip] backward without a training forward (tgt_idx + want_dlogits)\n"); return RL_ERR_ARG; }
+    const int n = n_stages();
+    if (last_stage < 0) last_stage = n - 1;
+    if (first < 0 || last_stage >= n || first > last_stage) return RL_ERR_ARG;
+    for (int s = first; s <= last_stage; ++s) RL_TRY(run_stage(st, s));
+    return RL_OK;
+  }
+};
+
+EngineBase* make_engine(const realise_config& c, float* p, float* g, float* pu, float* fz, float* bf, int64_t* bi) {
+  if (c.hidden % 64 || c.hidden / c.heads != 64 || c.hidden > 1024 || (c.intermediate % 8) || (c.vocab % 8)) return nullptr;
+  if (c.model_type == 1 && c.hidden != 768) return nullptr;     // CharResNet output is 768 wide (char_cnn.py:44)
+  if (c.dtype == REALISE_BF16) return new Engine<bf16_t>(c, p, g, pu, fz, bf, bi);
+  if (c.dtype == REALISE_F32) return new Engine<float>(c, p, g, pu, fz, bf, bi);
+  return nullptr;
+}
+
+}  // namespace rl

@@ -1,0 +1,111 @@
+// GEMM launchers shared by the engine and the C-ABI (gemm.hip implements them).
+#pragma once
+#include "common.h"
+
+namespace rl {
+
+// ---- epilogue of the NT GEMM (runtime-selected; branches are block-uniform) ------------------
+enum EpiMode {
+  EPI_STORE = 0,       // out = alpha*acc (+bias) (+= if accumulate)
+  EPI_GELU = 1,        // out2 = pre = acc+bias ; out = gelu(pre)                (K5)
+  EPI_DROP_RESID = 2,  // out = dropout(acc+bias) + aux                            (K4 minus LN)
+  EPI_QKV = 3,         // acc+bias scattered to [3][B][nh][S][64]                  (K2)
+  EPI_GELU_BWD = 4,    // out = acc * gelu'(aux)                                   (K14)
+};
+
+template <typename T> struct EpiParams {
+  int mode = EPI_STORE;
+  T* out = nullptr;
+  int64_t ldo = 0;
+  T* out2 = nullptr;
+  const float* bias = nullptr;
+  const T* aux = nullptr;
+  int64_t ldaux = 0;
+  float alpha = 1.0f;
+  int accumulate = 0;
+  uint32_t drop_seed = 0, drop_thresh = 0;
+  float drop_scale = 1.0f;
+  int S = 1, nh = 1;            // EPI_QKV: tokens per sentence, heads
+  int64_t qkv_plane = 0;        // EPI_QKV: elements per Q/K/V plane
+};
+
+// ---- operand loaders ---------------------------------------------------------------------------
+template <typename T> struct DenseLoader {
+  const T* base;
+  int64_t ld;
+  int rows, K;
+  struct Ctx { const T* p; };
+  __device__ __forceinline__ Ctx prepare(int row) const {
+    Ctx c; c.p = (row < rows) ? base + (int64_t)row * ld : nullptr; return c;
+  }
+  __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
+    if (c.p != nullptr && k < K) return *(const uint4*)(c.p + k);
+    return make_uint4(0, 0, 0, 0);
+  }
+};
+
+// Implicit im2col over an NHWC tensor (K7/K8).  Row space = pixels (n, y, x) of an Hr x Wr map,
+// K = (kh, kw, c).  mode 0: forward conv gather, source pixel (y*stride + kh - pad, ...);
+// mode 1: data-gradient gather, source pixel ((y + pad - kh)/stride, ...) when divisible.
+// img_index (optional) redirects image n to table row img_index[n] (glyph lookup by token id).
+template <typename T> struct ConvLoader {
+  const T* src;
+  const int64_t* img_index;
+  int rows, Hr, Wr, Hs, Ws, C, KH, KW, stride, pad, mode, K;
+  struct Ctx { const T* img; int y, x; };
+  __device__ __forceinline__ Ctx prepare(int row) const {
+    Ctx c; c.img = nullptr; c.y = 0; c.x = 0;
+    if (row < rows) {
+      const int hw = Hr * Wr;
+      const int n = row / hw, rem = row - n * hw;
+      c.y = rem / Wr; c.x = rem - c.y * Wr;
+      const int64_t ns = img_index ? img_index[n] : (int64_t)n;
+      c.img = src + ns * Hs * Ws * C;
+    }
+    return c;
+  }
+  __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if (c.img == nullptr || k >= K) return z;
+    const int tap = k / C, ch = k - tap * C;
+    const int kh = tap / KW, kw = tap - kh * KW;
+    int sy, sx;
+    if (mode == 0) {
+      sy = c.y * stride + kh - pad; sx = c.x * stride + kw - pad;
+    } else {
+      const int ty = c.y + pad - kh, tx = c.x + pad - kw;
+      if (ty < 0 || tx < 0) return z;
+      sy = ty / stride; sx = tx / stride;
+      if (sy * stride != ty || sx * stride != tx) return z;
+    }
+    if (sy < 0 || sy >= Hs || sx < 0 || sx >= Ws) return z;
+    return *(const uint4*)(c.img + ((int64_t)(sy * Ws + sx) * C + ch));
+  }
+};
+
+// ---- TN (weight-gradient) epilogue ---------------------------------------------------------------
+enum TnMode { TN_PLAIN = 0, TN_CONVW = 1 };
+struct TnEpi {
+  int mode = TN_PLAIN;
+  float* out = nullptr;     // fp32, atomically accumulated
+  int64_t ldo = 0;
+  float alpha = 1.0f;
+  int Cin = 0, Cpad = 0, KHW = 0;   // TN_CONVW: j = tap*Cpad + ci -> out[(i*Cin + ci)*KHW + tap]
+};
+
+// C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)
+template <typename T>
+int gemm_nt(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K,
+            const EpiParams<T>& ep);
+template <typename T>
+int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la, const T* B, int64_t ldb, int M, int N, int K,
+                 const EpiParams<T>& ep);
+// C[I,J] += sum_p A[p,i] * B[p,j]   (A: [P, >=I] row-major; B dense or gathered)
+template <typename T>
+int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep);
+template <typename T>
+int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& lb, int P, int I, int J, const TnEpi& ep);
+
+void set_tn_transpose_read(int use_tr);   // 1: ds_read_b64_tr_b16 operand reads (bf16), 0: 16-bit LDS gathers
+
+}  // namespace rl

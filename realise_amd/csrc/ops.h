@@ -1,0 +1,152 @@
+// Memory-bound kernels of the path: embeddings, LayerNorm, BatchNorm, gate fusion, GRU gate
+// math, masked cross-entropy, dropout, bias / column reductions, weight shadows, optimizer.
+#pragma once
+#include "common.h"
+
+namespace rl {
+
+struct DropParams { uint32_t seed = 0, thresh = 0; float scale = 1.0f; };
+
+int mask_to_additive(hipStream_t st, const int64_t* masks, float* out, int n);
+
+// ---- LayerNorm (K1, K4 tail, K10) ------------------------------------------------------------
+template <typename T> struct LnFwdArgs {
+  int rows = 0, H = 0, S = 1;
+  int in_mode = 0;                 // 0: x ; 1: word[ids] + pos + type0 ; 2: x + pos + type0
+  const T* x = nullptr;
+  const int64_t* ids = nullptr;
+  const float* word = nullptr;
+  const float* pos = nullptr;      // position table [P][H]
+  const float* type0 = nullptr;    // token_type row 0
+  int pos_zero = 0;                // 1: position id 0 everywhere (models.py:852-854)
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  float eps = 1e-12f;
+  T* y = nullptr;
+  T* xhat = nullptr;               // may alias x
+  float* rstd = nullptr;
+  DropParams drop;                 // applied to y (embeddings)
+};
+template <typename T> int ln_fwd(hipStream_t st, const LnFwdArgs<T>& a);
+
+template <typename T> struct LnBwdArgs {
+  int rows = 0, H = 0;
+  const T* dy = nullptr;
+  DropParams in_drop;              // mask applied to dy first (embedding dropout sits after the LN)
+  const T* xhat = nullptr;
+  const float* rstd = nullptr;
+  const float* gamma = nullptr;
+  T* dx = nullptr;
+  T* dx_drop = nullptr;            // optional second output: dx * mask(out_drop) (dense dropout before the LN)
+  DropParams out_drop;
+  float* dgamma = nullptr;         // atomically accumulated
+  float* dbeta = nullptr;
+};
+template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a);
+
+// scatter d(embedding sum) to the word / position / type tables
+template <typename T>
+int embed_bwd(hipStream_t st, const T* de, const int64_t* ids, int B, int S, int H, float* word_grad, float* pos_grad,
+              int pos_zero, float* type_grad);
+
+template <typename T> int bias_grad(hipStream_t st, const T* dy, int64_t ld, int rows, int N, float* out);
+template <typename T> int dropout_apply(hipStream_t st, const T* x, T* y, int rows, int H, DropParams d);
+
+// ---- masked cross-entropy (K13) ---------------------------------------------------------------
+// loss_out[0] = mean over rows with loss_mask==1 of CE(logits[row], labels[row]); dlogits (optional)
+// = d loss / d logits.  count_buf: 1 float scratch.
+template <typename T>
+int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask, int rows, int V,
+            float* loss_out, float* count_buf, T* dlogits);
+
+// ---- gate fusion (K11) --------------------------------------------------------------------------
+template <typename T> struct GateArgs {
+  int B = 0, S = 0, H = 0;
+  const T* bert = nullptr; const T* pho = nullptr; const T* res = nullptr;
+  const int64_t* masks = nullptr;
+  const float* W = nullptr;        // [3][4H]
+  const float* bias = nullptr;     // [3]
+  float* mean = nullptr;           // [B][H]  (saved)
+  float* msum = nullptr;           // [B]
+  float* g = nullptr;              // [B*S][4] sigmoid gates (saved)
+  T* fused = nullptr;
+  // backward
+  const T* dfused = nullptr;
+  T* dbert = nullptr; T* dpho = nullptr; T* dres = nullptr;
+  float* dz = nullptr;             // [B*S][4] scratch
+  float* dW = nullptr; float* dbias = nullptr;
+};
+template <typename T> int gate_fwd(hipStream_t st, const GateArgs<T>& a);
+template <typename T> int gate_bwd(hipStream_t st, const GateArgs<T>& a);
+
+// ---- pinyin GRU (K6) ------------------------------------------------------------------------------
+int gru_table(hipStream_t st, const float* emb, const float* w_ih, const float* b_ih, int V, int H, float* table);
+template <typename T> struct GruStepArgs {
+  int n_alive = 0, H = 0, Tp = 0, t = 0;
+  const float* table = nullptr;     // [V][3H]
+  const int64_t* pho_idx = nullptr; // [N][Tp] original order
+  const int* perm = nullptr;        // sorted position -> original token
+  const int* lens = nullptr;        // sorted lengths
+  const T* gh = nullptr;            // [n_alive][3H] = h_prev W_hh^T + b_hh (nullptr at t == 0)
+  const float* b_hh = nullptr;
+  const T* h_prev = nullptr;        // [N][H] sorted (nullptr at t == 0)
+  T* h_new = nullptr;               // [N][H] sorted
+  T* rzn = nullptr;                 // [N][3H] saved gates of this step
+  T* out = nullptr;                 // [N][H] original order, written when a sequence ends
+  // backward
+  const T* dout = nullptr;          // [N][H] original order
+  T* dh = nullptr;                  // [N][H] sorted, running dL/dh
+  T* dgi = nullptr;                 // [n_alive][3H]
+  T* dgh = nullptr;                 // [n_alive][3H]
+  T* onehot = nullptr;              // [n_alive][64]
+};
+template <typename T> int gru_step_fwd(hipStream_t st, const GruStepArgs<T>& a);
+template <typename T> int gru_step_bwd(hipStream_t st, const GruStepArgs<T>& a);
+int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const float* emb, const float* w_ih, int V, int H,
+                  float* d_emb, float* d_w_ih, float* d_b_ih);
+
+// ---- BatchNorm over NHWC activations [P][C] (K9) -------------------------------------------------
+template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out);
+template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out);
+// train-mode finalize: stats -> (mean, rstd, scale, shift), running-stat update (unbiased var, momentum)
+int bn_finalize_mean(hipStream_t st, const float* sum, int C, int P, float* mean);
+int bn_finalize_train(hipStream_t st, const float* mean, const float* sqsum, int C, int P, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var, float* rstd, float* scale, float* shift);
+int bn_finalize_eval(hipStream_t st, int C, const float* gamma, const float* beta, float eps, const float* running_mean,
+                     const float* running_var, float* scale, float* shift);
+// y = [relu]( x1*sc1 + sh1 [+ x2*sc2 + sh2] )
+template <typename T>
+int bn_apply(hipStream_t st, const T* x1, const float* sc1, const float* sh1, const T* x2, const float* sc2, const float* sh2,
+             T* y, int P, int C, int relu);
+// sums[0..C) += sum g ; sums[C..2C) += sum g*xhat  with g = dy * (relu_src > 0)
+template <typename T>
+int bn_bwd_reduce(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd, int P, int C,
+                  float* sums);
+// dx = gamma*rstd*(g - sum_g/P - xhat*sum_gx/P); dgamma += sum_gx ; dbeta += sum_g
+template <typename T>
+int bn_bwd_apply(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd,
+                 const float* gamma, const float* sums, int P, int C, T* dx, float* dgamma, float* dbeta);
+// g = dy * (relu_src > 0)
+template <typename T> int relu_bwd(hipStream_t st, const T* dy, const T* relu_src, T* g, int64_t n);
+
+// ---- weight shadows (operand copies in the compute dtype) ----------------------------------------
+template <typename T> int cast_copy(hipStream_t st, const float* src, T* dst, int64_t n);
+// src fp32 [R][C] -> dst [R][C] (optional) and dstT [C][R] (optional)
+template <typename T> int cast_transpose(hipStream_t st, const float* src, int R, int C, T* dst, T* dstT);
+// conv weight [Co][Ci][KH][KW] fp32 -> fwd [Co][KH*KW][Cpad] and dgrad [Ci_rows][KH*KW][Co] (rows >= Ci zero)
+template <typename T>
+int conv_weight_shadow(hipStream_t st, const float* w, int Co, int Ci, int KHW, int Cpad, int CiRows, T* fwd, T* dgrad);
+// glyph table [V][F][HW] fp32 -> NHWC [V][HW][Cpad]
+template <typename T> int glyph_shadow(hipStream_t st, const float* tbl, int V, int F, int HW, int Cpad, T* out);
+
+// ---- optimizer (K15, K16) -------------------------------------------------------------------------
+int sumsq_accum(hipStream_t st, const float* g, int64_t n, float* out);          // out[0] += sum g^2
+// AdamW of transformers/optimization.py:110-169 over a flat range; grads are scaled by
+// min(1, max_norm / (sqrt(*norm_sq) + 1e-6)) when norm_sq != nullptr (clip_grad_norm_, run.py:207)
+int adamw_flat(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, float bias_c1, float bias_c2, const float* norm_sq, float max_norm);
+
+int fill_f32(hipStream_t st, float* p, float v, int64_t n);
+int add_i64(hipStream_t st, int64_t* p, int64_t v, int n);
+
+}  // namespace rl

@@ -1,0 +1,567 @@
+// HBM-bound kernels, part 1: masks, embeddings + LayerNorm (K1/K4/K10), bias gradients, dropout,
+// masked cross-entropy (K13), gate fusion (K11).  All row-wise kernels use one 64-lane wave per
+// row with 8-16 byte per-lane accesses (a 768-wide row = 3 coalesced 4-element vectors per lane);
+// statistics are always fp32.
+#include "ops.h"
+
+namespace rl {
+
+#define RL_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH)
+static constexpr int LN_MAXV = 4;   // up to 4 x (64 lanes x 4 elems) = 1024 columns per row
+
+__global__ void mask_to_additive_kernel(const int64_t* __restrict__ m, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (1.0f - (float)m[i]) * -10000.0f;       // modeling_bert.py:696-697
+}
+int mask_to_additive(hipStream_t st, const int64_t* masks, float* out, int n) {
+  hipLaunchKernelGGL(mask_to_additive_kernel, dim3((n + 255) / 256), dim3(256), 0, st, masks, out, n);
+  return RL_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm forward (BertEmbeddings modeling_bert.py:183-193, BertSelfOutput/BertOutput :273-277,
+// :339-343, resnet_layernorm models.py:838)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs<T> a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.rows) return;
+  const int H = a.H;
+  floatx4 v[LN_MAXV];
+  float sum = 0.f;
+  const int64_t tok = (a.in_mode == 1) ? a.ids[row] : 0;
+  const int prow = a.pos_zero ? 0 : (row % a.S);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (c < H) {
+      floatx4 x;
+      if (a.in_mode == 1) x = *(const floatx4*)(a.word + tok * H + c);
+      else x = load4<T>(a.x + (int64_t)row * H + c);
+      if (a.in_mode != 0) x += *(const floatx4*)(a.pos + (int64_t)prow * H + c) + *(const floatx4*)(a.type0 + c);
+      v[i] = x;
+      sum += x[0] + x[1] + x[2] + x[3];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+    }
+  }
+  const float var = wave_sum(sq) / (float)H;
+  const float rstd = 1.0f / sqrtf(var + a.eps);
+  if (lane == 0 && a.rstd != nullptr) a.rstd[row] = rstd;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      const floatx4 gm = *(const floatx4*)(a.gamma + c), bt = *(const floatx4*)(a.beta + c);
+      floatx4 xh, y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[j] = (v[i][j] - mean) * rstd;
+        y[j] = xh[j] * gm[j] + bt[j];
+        y[j] *= drop_mult(a.drop.seed, a.drop.thresh, a.drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
+      }
+      if (a.xhat != nullptr) store4<T>(a.xhat + (int64_t)row * H + c, xh);
+      store4<T>(a.y + (int64_t)row * H + c, y);
+    }
+  }
+}
+template <typename T> int ln_fwd(hipStream_t st, const LnFwdArgs<T>& a) {
+  if (a.rows <= 0) return RL_OK;
+  if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
+  hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
+  return RL_LAUNCH_CHECK();
+}
+template int ln_fwd<bf16_t>(hipStream_t, const LnFwdArgs<bf16_t>&);
+template int ln_fwd<float>(hipStream_t, const LnFwdArgs<float>&);
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward: dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)); dgamma/dbeta
+// partials are kept in registers across a grid-stride loop over rows, reduced through LDS, then
+// one atomicAdd per column per workgroup.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
+  __shared__ float red[2][4][LN_MAXV * 256];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int H = a.H;
+  floatx4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    dg[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    db[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int c = (i * 64 + lane) * 4;
+    gm[i] = c < H ? *(const floatx4*)(a.gamma + c) : floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+    floatx4 dy[LN_MAXV], xh[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      dy[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+      xh[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+      if (c < H) {
+        dy[i] = load4<T>(a.dy + (int64_t)row * H + c);
+        xh[i] = load4<T>(a.xhat + (int64_t)row * H + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dy[i][j] *= drop_mult(a.in_drop.seed, a.in_drop.thresh, a.in_drop.scale,
+                                (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
+          const float t = dy[i][j] * gm[i][j];
+          s1 += t;
+          s2 += t * xh[i][j];
+          dg[i][j] += dy[i][j] * xh[i][j];
+          db[i][j] += dy[i][j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    const float rstd = a.rstd[row];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
+        floatx4 dx, dxd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dx[j] = rstd * (dy[i][j] * gm[i][j] - s1 - xh[i][j] * s2);
+          dxd[j] = dx[j] * drop_mult(a.out_drop.seed, a.out_drop.thresh, a.out_drop.scale,
+                                     (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
+        }
+        store4<T>(a.dx + (int64_t)row * H + c, dx);
+        if (a.dx_drop != nullptr) store4<T>(a.dx_drop + (int64_t)row * H + c, dxd);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][wave][c + j] = dg[i][j]; red[1][wave][c + j] = db[i][j]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += 256) {
+    const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    if (a.dgamma != nullptr) atomicAdd(a.dgamma + c, g);
+    if (a.dbeta != nullptr) atomicAdd(a.dbeta + c, b);
+  }
+}
+template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
+  if (a.rows <= 0) return RL_OK;
+  if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
+  int blocks = (a.rows + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, a);
+  return RL_LAUNCH_CHECK();
+}
+template int ln_bwd<bf16_t>(hipStream_t, const LnBwdArgs<bf16_t>&);
+template int ln_bwd<float>(hipStream_t, const LnBwdArgs<float>&);
+
+// ---------------------------------------------------------------------------------------------
+// Embedding backward: thread owns 4 columns of one sequence position s and walks the batch.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_bwd_kernel(const T* __restrict__ de, const int64_t* __restrict__ ids, int B, int S, int H,
+                                 float* word_grad, float* pos_grad, int pos_zero, float* type_grad) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int s = blockIdx.y;
+  if (c >= H) return;
+  floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < B; ++b) {
+    const int64_t row = (int64_t)b * S + s;
+    const floatx4 d = load4<T>(de + row * H + c);
+    acc += d;
+    if (word_grad != nullptr) {
+      float* w = word_grad + ids[row] * H + c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(w + j, d[j]);
+    }
+  }
+  float* p = pos_grad + (int64_t)(pos_zero ? 0 : s) * H + c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    atomicAdd(p + j, acc[j]);
+    atomicAdd(type_grad + c + j, acc[j]);
+  }
+}
+template <typename T>
+int embed_bwd(hipStream_t st, const T* de, const int64_t* ids, int B, int S, int H, float* word_grad, float* pos_grad,
+              int pos_zero, float* type_grad) {
+  if (H & 3) return RL_ERR_ARG;
+  const int tx = 64;
+  hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3((H / 4 + tx - 1) / tx, S), dim3(tx), 0, st, de, ids, B, S, H, word_grad,
+                     pos_grad, pos_zero, type_grad);
+  return RL_LAUNCH_CHECK();
+}
+template int embed_bwd<bf16_t>(hipStream_t, const bf16_t*, const int64_t*, int, int, int, float*, float*, int, float*);
+template int embed_bwd<float>(hipStream_t, const float*, const int64_t*, int, int, int, float*, float*, int, float*);
+
+// ---------------------------------------------------------------------------------------------
+// Column reductions over a row-major [rows][C] matrix: 32 threads x 4 columns wide, 8 row lanes.
+// ---------------------------------------------------------------------------------------------
+template <typename F>
+__global__ void __launch_bounds__(256) col_reduce_kernel(F f, int rows, int C, int rows_per_block, float* out0, float* out1) {
+  __shared__ floatx4 red[2][8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = (blockIdx.x * 32 + cx) * 4;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  floatx4 a0 = floatx4{0.f, 0.f, 0.f, 0.f}, a1 = floatx4{0.f, 0.f, 0.f, 0.f};
+  if (col < C)
+    for (int r = r0 + ry; r < r1; r += 8) f(r, col, a0, a1);
+  red[0][ry][cx] = a0;
+  red[1][ry][cx] = a1;
+  __syncthreads();
+  if (ry == 0 && col < C) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { a0 += red[0][k][cx]; a1 += red[1][k][cx]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      atomicAdd(out0 + col + j, a0[j]);
+      if (out1 != nullptr) atomicAdd(out1 + col + j, a1[j]);
+    }
+  }
+}
+template <typename F>
+static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float* out0, float* out1) {
+  if (rows <= 0 || C <= 0) return RL_OK;
+  if (C & 3) return RL_ERR_ARG;
+  const int gx = (C + 127) / 128;
+  int gy = 1024 / gx;
+  if (gy < 1) gy = 1;
+  int rpb = (rows + gy - 1) / gy;
+  if (rpb < 64) rpb = 64;
+  gy = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, rpb, out0, out1);
+  return RL_LAUNCH_CHECK();
+}
+
+template <typename T> struct SumF {
+  const T* x; int64_t ld;
+  __device__ __forceinline__ void operator()(int r, int c, floatx4& a0, floatx4&) const { a0 += load4<T>(x + (int64_t)r * ld + c); }
+};
+template <typename T> int bias_grad(hipStream_t st, const T* dy, int64_t ld, int rows, int N, float* out) {
+  if (ld & 3) return RL_ERR_ARG;
+  SumF<T> f{dy, ld};
+  return launch_col_reduce(st, f, rows, N, out, nullptr);
+}
+template int bias_grad<bf16_t>(hipStream_t, const bf16_t*, int64_t, int, int, float*);
+template int bias_grad<float>(hipStream_t, const float*, int64_t, int, int, float*);
+
+template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out) {
+  SumF<T> f{x, (int64_t)C};
+  return launch_col_reduce(st, f, P, C, out, nullptr);
+}
+template int col_sum<bf16_t>(hipStream_t, const bf16_t*, int, int, float*);
+template int col_sum<float>(hipStream_t, const float*, int, int, float*);
+
+template <typename T> struct SumSqCF {
+  const T* x; int64_t ld; const float* mean;
+  __device__ __forceinline__ void operator()(int r, int c, floatx4& a0, floatx4&) const {
+    const floatx4 d = load4<T>(x + (int64_t)r * ld + c) - *(const floatx4*)(mean + c);
+    a0 += d * d;
+  }
+};
+template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out) {
+  SumSqCF<T> f{x, (int64_t)C, mean};
+  return launch_col_reduce(st, f, P, C, out, nullptr);
+}
+template int col_sumsq_centered<bf16_t>(hipStream_t, const bf16_t*, int, int, const float*, float*);
+template int col_sumsq_centered<float>(hipStream_t, const float*, int, int, const float*, float*);
+
+template <typename T> struct BnBwdF {
+  const T* dy; const T* relu_src; const T* x; const float* mean; const float* rstd; int64_t ld;
+  __device__ __forceinline__ void operator()(int r, int c, floatx4& a0, floatx4& a1) const {
+    floatx4 g = load4<T>(dy + (int64_t)r * ld + c);
+    if (relu_src != nullptr) {
+      const floatx4 o = load4<T>(relu_src + (int64_t)r * ld + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+    }
+    const floatx4 xh = (load4<T>(x + (int64_t)r * ld + c) - *(const floatx4*)(mean + c)) * *(const floatx4*)(rstd + c);
+    a0 += g;
+    a1 += g * xh;
+  }
+};
+template <typename T>
+int bn_bwd_reduce(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd, int P, int C,
+                  float* sums) {
+  BnBwdF<T> f{dy, relu_src, x, mean, rstd, (int64_t)C};
+  return launch_col_reduce(st, f, P, C, sums, sums + C);
+}
+template int bn_bwd_reduce<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, int, int, float*);
+template int bn_bwd_reduce<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, int, int, float*);
+
+// ---------------------------------------------------------------------------------------------
+// Dropout as a stand-alone map (the one before the classifier, models.py:858)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, DropParams d) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  floatx4 v = load4<T>(x + i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] *= drop_mult(d.seed, d.thresh, d.scale, (uint32_t)(i + j));
+  store4<T>(y + i, v);
+}
+template <typename T> int dropout_apply(hipStream_t st, const T* x, T* y, int rows, int H, DropParams d) {
+  const int64_t n = (int64_t)rows * H;
+  if (n & 3) return RL_ERR_ARG;
+  hipLaunchKernelGGL((dropout_kernel<T>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x, y, n, d);
+  return RL_LAUNCH_CHECK();
+}
+template int dropout_apply<bf16_t>(hipStream_t, const bf16_t*, bf16_t*, int, int, DropParams);
+template int dropout_apply<float>(hipStream_t, const float*, float*, int, int, DropParams);
+
+// ---------------------------------------------------------------------------------------------
+// Masked cross-entropy (models.py:862-869): one 256-thread workgroup per token row.
+// ---------------------------------------------------------------------------------------------
+__global__ void count_active_kernel(const int64_t* __restrict__ m, int n, float* out) {
+  float c = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += (m[i] == 1) ? 1.f : 0.f;
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0 && c != 0.f) atomicAdd(out, c);
+}
+
+__device__ __forceinline__ float block_reduce(float v, float* sm, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[wave] = v;
+  __syncthreads();
+  float r = sm[0];
+  for (int w = 1; w < 4; ++w) r = is_max ? fmaxf(r, sm[w]) : r + sm[w];
+  return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels, const int64_t* __restrict__ loss_mask,
+          int V, float* loss_out, const float* __restrict__ count, T* __restrict__ dlogits) {
+  __shared__ float sm[4];
+  const int row = blockIdx.x;
+  const T* x = logits + (int64_t)row * ld;
+  T* dx = dlogits ? dlogits + (int64_t)row * ld : nullptr;
+  const bool active = loss_mask[row] == 1;
+  if (!active) {
+    if (dx != nullptr)
+      for (int c = threadIdx.x * 4; c < V; c += 1024) store4<T>(dx + c, floatx4{0.f, 0.f, 0.f, 0.f});
+    return;
+  }
+  float mx = -3.0e38f;
+  for (int c = threadIdx.x * 4; c < V; c += 1024) {
+    const floatx4 v = load4<T>(x + c);
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  mx = block_reduce(mx, sm, true);
+  float s = 0.f;
+  for (int c = threadIdx.x * 4; c < V; c += 1024) {
+    const floatx4 v = load4<T>(x + c);
+    s += expf(v[0] - mx) + expf(v[1] - mx) + expf(v[2] - mx) + expf(v[3] - mx);
+  }
+  s = block_reduce(s, sm, false);
+  const float inv_n = 1.0f / count[0];
+  const int lab = (int)labels[row];
+  const float lse = mx + logf(s);
+  if (threadIdx.x == 0) atomicAdd(loss_out, (lse - to_f<T>(x[lab])) * inv_n);
+  if (dx != nullptr) {
+    const float inv_s = 1.0f / s;
+    for (int c = threadIdx.x * 4; c < V; c += 1024) {
+      const floatx4 v = load4<T>(x + c);
+      floatx4 d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) d[j] = (expf(v[j] - mx) * inv_s - ((c + j) == lab ? 1.0f : 0.0f)) * inv_n;
+      store4<T>(dx + c, d);
+    }
+  }
+}
+template <typename T>
+int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask, int rows, int V,
+            float* loss_out, float* count_buf, T* dlogits) {
+  if ((V & 3) || (ld & 3)) return RL_ERR_ARG;
+  (void)hipMemsetAsync(loss_out, 0, sizeof(float), st);
+  (void)hipMemsetAsync(count_buf, 0, sizeof(float), st);
+  hipLaunchKernelGGL(count_active_kernel, dim3(64), dim3(256), 0, st, loss_mask, rows, count_buf);
+  hipLaunchKernelGGL((ce_kernel<T>), dim3(rows), dim3(256), 0, st, logits, ld, labels, loss_mask, V, loss_out, count_buf, dlogits);
+  return RL_LAUNCH_CHECK();
+}
+template int ce_loss<bf16_t>(hipStream_t, const bf16_t*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, bf16_t*);
+template int ce_loss<float>(hipStream_t, const float*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, float*);
+
+// ---------------------------------------------------------------------------------------------
+// Gate fusion (models.py:840-850).  The [T, 4H] concat is never materialised.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gate_mean_kernel(GateArgs<T> a) {     // grid (H/4/64, B)
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int b = blockIdx.y;
+  if (c >= a.H) return;
+  floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+  float ms = 0.f;
+  for (int s = 0; s < a.S; ++s) {
+    const float m = (float)a.masks[b * a.S + s];
+    ms += m;
+    acc += load4<T>(a.bert + ((int64_t)b * a.S + s) * a.H + c) * m;
+  }
+  *(floatx4*)(a.mean + (int64_t)b * a.H + c) = acc / ms;
+  if (c == 0) a.msum[b] = ms;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gate_fwd_kernel(GateArgs<T> a) {   // one wave per token
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.B * a.S) return;
+  const int H = a.H, b = row / a.S;
+  floatx4 xb[LN_MAXV], xp[LN_MAXV], xr[LN_MAXV];
+  float z[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      xb[i] = load4<T>(a.bert + (int64_t)row * H + c);
+      xp[i] = load4<T>(a.pho + (int64_t)row * H + c);
+      xr[i] = load4<T>(a.res + (int64_t)row * H + c);
+      const floatx4 xm = *(const floatx4*)(a.mean + (int64_t)b * H + c);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float* w = a.W + (int64_t)k * 4 * H + c;
+        const floatx4 w0 = *(const floatx4*)w, w1 = *(const floatx4*)(w + H), w2 = *(const floatx4*)(w + 2 * H),
+                      w3 = *(const floatx4*)(w + 3 * H);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[k] += w0[j] * xb[i][j] + w1[j] * xp[i][j] + w2[j] * xr[i][j] + w3[j] * xm[j];
+      }
+    }
+  }
+  float gk[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) gk[k] = sigmoidf_(wave_sum(z[k]) + a.bias[k]);
+  if (lane == 0) { a.g[row * 4 + 0] = gk[0]; a.g[row * 4 + 1] = gk[1]; a.g[row * 4 + 2] = gk[2]; a.g[row * 4 + 3] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) store4<T>(a.fused + (int64_t)row * H + c, xb[i] * gk[0] + xp[i] * gk[1] + xr[i] * gk[2]);
+  }
+}
+template <typename T> int gate_fwd(hipStream_t st, const GateArgs<T>& a) {
+  if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
+  hipLaunchKernelGGL((gate_mean_kernel<T>), dim3((a.H / 4 + 63) / 64, a.B), dim3(64), 0, st, a);
+  hipLaunchKernelGGL((gate_fwd_kernel<T>), dim3((a.B * a.S + 3) / 4), dim3(256), 0, st, a);
+  return RL_LAUNCH_CHECK();
+}
+template int gate_fwd<bf16_t>(hipStream_t, const GateArgs<bf16_t>&);
+template int gate_fwd<float>(hipStream_t, const GateArgs<float>&);
+
+// backward, step 1 (per token): dz_k and the direct parts of dbert/dpho/dres
+template <typename T>
+__global__ void __launch_bounds__(256) gate_bwd_token_kernel(GateArgs<T> a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= a.B * a.S) return;
+  const int H = a.H;
+  floatx4 df[LN_MAXV];
+  float dg[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      df[i] = load4<T>(a.dfused + (int64_t)row * H + c);
+      const floatx4 xb = load4<T>(a.bert + (int64_t)row * H + c), xp = load4<T>(a.pho + (int64_t)row * H + c),
+                    xr = load4<T>(a.res + (int64_t)row * H + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dg[0] += df[i][j] * xb[j]; dg[1] += df[i][j] * xp[j]; dg[2] += df[i][j] * xr[j]; }
+    }
+  }
+  float gk[3], dz[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    gk[k] = a.g[row * 4 + k];
+    dz[k] = wave_sum(dg[k]) * gk[k] * (1.0f - gk[k]);
+  }
+  if (lane == 0) { a.dz[row * 4 + 0] = dz[0]; a.dz[row * 4 + 1] = dz[1]; a.dz[row * 4 + 2] = dz[2]; a.dz[row * 4 + 3] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < H) {
+      floatx4 ob = df[i] * gk[0], op = df[i] * gk[1], orr = df[i] * gk[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float* w = a.W + (int64_t)k * 4 * H + c;
+        ob += *(const floatx4*)w * dz[k];
+        op += *(const floatx4*)(w + H) * dz[k];
+        orr += *(const floatx4*)(w + 2 * H) * dz[k];
+      }
+      store4<T>(a.dbert + (int64_t)row * H + c, ob);
+      store4<T>(a.dpho + (int64_t)row * H + c, op);
+      store4<T>(a.dres + (int64_t)row * H + c, orr);
+    }
+  }
+}
+// step 2 (per sentence, 4 columns per thread): d(mean) -> spread over the masked tokens of dbert,
+// and dW[:, 3H:4H] += sum_s dz * mean
+template <typename T>
+__global__ void gate_bwd_mean_kernel(GateArgs<T> a) {    // grid (H/4/64, B)
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int b = blockIdx.y;
+  if (c >= a.H) return;
+  const int H = a.H;
+  float zs[3] = {0.f, 0.f, 0.f};
+  for (int s = 0; s < a.S; ++s)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) zs[k] += a.dz[((int64_t)b * a.S + s) * 4 + k];
+  floatx4 dm = floatx4{0.f, 0.f, 0.f, 0.f};
+  const floatx4 mean = *(const floatx4*)(a.mean + (int64_t)b * H + c);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    dm += *(const floatx4*)(a.W + (int64_t)k * 4 * H + 3 * H + c) * zs[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(a.dW + (int64_t)k * 4 * H + 3 * H + c + j, zs[k] * mean[j]);
+  }
+  dm = dm / a.msum[b];
+  for (int s = 0; s < a.S; ++s) {
+    if (a.masks[b * a.S + s] != 0) {
+      T* p = a.dbert + ((int64_t)b * a.S + s) * H + c;
+      store4<T>(p, load4<T>(p) + dm * (float)a.masks[b * a.S + s]);
+    }
+  }
+  if (c == 0 && blockIdx.x == 0)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(a.dbias + k, zs[k]);
+}
+// step 3: dW[k, 0:3H] += sum_t dz_k[t] * X(t, :)
+template <typename T> struct GateWF {
+  const T* x; const float* dz; int64_t ld; int k;
+  __device__ __forceinline__ void operator()(int r, int c, floatx4& a0, floatx4&) const {
+    a0 += load4<T>(x + (int64_t)r * ld + c) * dz[(int64_t)r * 4 + k];
+  }
+};
+template <typename T> int gate_bwd(hipStream_t st, const GateArgs<T>& a) {
+  if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
+  const int T_ = a.B * a.S;
+  hipLaunchKernelGGL((gate_bwd_token_kernel<T>), dim3((T_ + 3) / 4), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((gate_bwd_mean_kernel<T>), dim3((a.H / 4 + 63) / 64, a.B), dim3(64), 0, st, a);
+  const T* xs[3] = {a.bert, a.pho, a.res};
+  for (int src = 0; src < 3; ++src)
+    for (int k = 0; k < 3; ++k) {
+      GateWF<T> f{xs[src], a.dz, (int64_t)a.H, k};
+      const int rc = launch_col_reduce(st, f, T_, a.H, a.dW + (int64_t)k * 4 * a.H + (int64_t)src * a.H, nullptr);
+      if (rc != RL_OK) return rc;
+    }
+  return RL_LAUNCH_CHECK();
+}
+template int gate_bwd<bf16_t>(hipStream_t, const GateArgs<bf16_t>&);
+template int gate_bwd<float>(hipStream_t, const GateArgs<float>&);
+
+}  // namespace rl

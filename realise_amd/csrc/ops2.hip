@@ -1,0 +1,450 @@
+// HBM-bound kernels, part 2: pinyin-GRU gate math (K6), BatchNorm finalize/apply (K9),
+// operand shadows (compute-dtype copies of the fp32 master weights), optimizer (K15/K16).
+#include "ops.h"
+
+namespace rl {
+
+#define RL_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH)
+
+// ---------------------------------------------------------------------------------------------
+// GRU (models.py:661-669, 818-826).  The input projection only ever sees 33 distinct embedding
+// rows, so W_ih x + b_ih is a [33][3H] table computed once per forward (fp32, from the masters).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gru_table_kernel(const float* __restrict__ emb, const float* __restrict__ w_ih, const float* __restrict__ b_ih, int V, int H,
+                 float* __restrict__ table) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wave;          // output unit in [0, 3H)
+  if (j >= 3 * H) return;
+  float w[16];
+  const int nper = (H + 63) / 64;               // <= 16 for H <= 1024
+  for (int i = 0; i < nper; ++i) { const int k = i * 64 + lane; w[i] = k < H ? w_ih[(int64_t)j * H + k] : 0.f; }
+  for (int v = 0; v < V; ++v) {
+    float s = 0.f;
+    for (int i = 0; i < nper; ++i) { const int k = i * 64 + lane; if (k < H) s += w[i] * emb[(int64_t)v * H + k]; }
+    s = wave_sum(s);
+    if (lane == 0) table[(int64_t)v * 3 * H + j] = s + b_ih[j];
+  }
+}
+int gru_table(hipStream_t st, const float* emb, const float* w_ih, const float* b_ih, int V, int H, float* table) {
+  if (H > 1024) return RL_ERR_ARG;
+  hipLaunchKernelGGL(gru_table_kernel, dim3((3 * H + 3) / 4), dim3(256), 0, st, emb, w_ih, b_ih, V, H, table);
+  return RL_LAUNCH_CHECK();
+}
+
+template <typename T>
+__global__ void gru_step_fwd_kernel(GruStepArgs<T> a) {    // grid (H/4/64, n_alive)
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int i = blockIdx.y;
+  if (c >= a.H) return;
+  const int H = a.H;
+  const int tok = a.perm[i];
+  const int64_t v = a.pho_idx[(int64_t)tok * a.Tp + a.t];
+  const float* gi = a.table + v * 3 * H + c;
+  const floatx4 ir = *(const floatx4*)gi, iz = *(const floatx4*)(gi + H), in = *(const floatx4*)(gi + 2 * H);
+  floatx4 hr, hz, hn, hp;
+  if (a.gh != nullptr) {
+    const T* gh = a.gh + (int64_t)i * 3 * H + c;
+    hr = load4<T>(gh); hz = load4<T>(gh + H); hn = load4<T>(gh + 2 * H);
+    hp = load4<T>(a.h_prev + (int64_t)i * H + c);
+  } else {
+    hr = *(const floatx4*)(a.b_hh + c); hz = *(const floatx4*)(a.b_hh + H + c); hn = *(const floatx4*)(a.b_hh + 2 * H + c);
+    hp = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  floatx4 r, z, n, h;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[j] = sigmoidf_(ir[j] + hr[j]);
+    z[j] = sigmoidf_(iz[j] + hz[j]);
+    n[j] = tanhf(in[j] + r[j] * hn[j]);
+    h[j] = (1.0f - z[j]) * n[j] + z[j] * hp[j];
+  }
+  if (a.rzn != nullptr) {
+    T* s = a.rzn + (int64_t)i * 3 * H + c;
+    store4<T>(s, r); store4<T>(s + H, z); store4<T>(s + 2 * H, n);
+  }
+  store4<T>(a.h_new + (int64_t)i * H + c, h);
+  if (a.lens[i] == a.t + 1) store4<T>(a.out + (int64_t)tok * H + c, h);
+}
+template <typename T> int gru_step_fwd(hipStream_t st, const GruStepArgs<T>& a) {
+  if (a.n_alive <= 0) return RL_OK;
+  if (a.H & 3) return RL_ERR_ARG;
+  hipLaunchKernelGGL((gru_step_fwd_kernel<T>), dim3((a.H / 4 + 63) / 64, a.n_alive), dim3(64), 0, st, a);
+  return RL_LAUNCH_CHECK();
+}
+template int gru_step_fwd<bf16_t>(hipStream_t, const GruStepArgs<bf16_t>&);
+template int gru_step_fwd<float>(hipStream_t, const GruStepArgs<float>&);
+
+// one BPTT step: consumes dL/dh_t (dh, or dout where the sequence ended at t), emits dGi, dGh,
+// the one-hot of the input letter (for the table gradient GEMM) and dh * z into dh.
+template <typename T>
+__global__ void gru_step_bwd_kernel(GruStepArgs<T> a) {    // grid (H/4/64, n_alive)
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int i = blockIdx.y;
+  if (c >= a.H) return;
+  const int H = a.H;
+  const int tok = a.perm[i];
+  const bool ends_here = a.lens[i] == a.t + 1;
+  const floatx4 dh = ends_here ? load4<T>(a.dout + (int64_t)tok * H + c) : load4<T>(a.dh + (int64_t)i * H + c);
+  const T* s = a.rzn + (int64_t)i * 3 * H + c;
+  const floatx4 r = load4<T>(s), z = load4<T>(s + H), n = load4<T>(s + 2 * H);
+  floatx4 hn, hp;
+  if (a.gh != nullptr) {
+    hn = load4<T>(a.gh + (int64_t)i * 3 * H + 2 * H + c);
+    hp = load4<T>(a.h_prev + (int64_t)i * H + c);
+  } else {
+    hn = *(const floatx4*)(a.b_hh + 2 * H + c);
+    hp = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  floatx4 dar, daz, dan, dhn, dhp;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float dn = dh[j] * (1.0f - z[j]);
+    const float dz = dh[j] * (hp[j] - n[j]);
+    dan[j] = dn * (1.0f - n[j] * n[j]);
+    dar[j] = dan[j] * hn[j] * r[j] * (1.0f - r[j]);
+    daz[j] = dz * z[j] * (1.0f - z[j]);
+    dhn[j] = dan[j] * r[j];
+    dhp[j] = dh[j] * z[j];
+  }
+  T* gi = a.dgi + (int64_t)i * 3 * H + c;
+  store4<T>(gi, dar); store4<T>(gi + H, daz); store4<T>(gi + 2 * H, dan);
+  T* gh = a.dgh + (int64_t)i * 3 * H + c;
+  store4<T>(gh, dar); store4<T>(gh + H, daz); store4<T>(gh + 2 * H, dhn);
+  store4<T>(a.dh + (int64_t)i * H + c, dhp);
+  if (c < 64) {
+    const int v = (int)a.pho_idx[(int64_t)tok * a.Tp + a.t];
+    floatx4 oh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oh[j] = (c + j) == v ? 1.0f : 0.0f;
+    store4<T>(a.onehot + (int64_t)i * 64 + c, oh);
+  }
+}
+template <typename T> int gru_step_bwd(hipStream_t st, const GruStepArgs<T>& a) {
+  if (a.n_alive <= 0) return RL_OK;
+  if ((a.H & 3) || a.H < 64) return RL_ERR_ARG;
+  hipLaunchKernelGGL((gru_step_bwd_kernel<T>), dim3((a.H / 4 + 63) / 64, a.n_alive), dim3(64), 0, st, a);
+  return RL_LAUNCH_CHECK();
+}
+template int gru_step_bwd<bf16_t>(hipStream_t, const GruStepArgs<bf16_t>&);
+template int gru_step_bwd<float>(hipStream_t, const GruStepArgs<float>&);
+
+// dTable [V][3H] -> d b_ih, d W_ih [3H][H], d Emb [V][H]
+__global__ void __launch_bounds__(256)
+gru_table_bwd_w_kernel(const float* __restrict__ dt, int ldt, const float* __restrict__ emb, int V, int H,
+                       float* d_w_ih, float* d_b_ih) {                  // block per output unit j, thread per k
+  const int j = blockIdx.x;
+  float bsum = 0.f;
+  for (int v = 0; v < V; ++v) bsum += dt[(int64_t)v * ldt + j];
+  if (threadIdx.x == 0) atomicAdd(d_b_ih + j, bsum);
+  for (int k = threadIdx.x; k < H; k += 256) {
+    float s = 0.f;
+    for (int v = 0; v < V; ++v) s += dt[(int64_t)v * ldt + j] * emb[(int64_t)v * H + k];
+    atomicAdd(d_w_ih + (int64_t)j * H + k, s);
+  }
+}
+__global__ void __launch_bounds__(256)
+gru_table_bwd_e_kernel(const float* __restrict__ dt, int ldt, const float* __restrict__ w_ih, int V, int H, float* d_emb) {
+  const int v = blockIdx.y;                                              // grid (H/256, V)
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= H || v == 0) return;                                          // padding_idx = 0 row gets no gradient
+  float s = 0.f;
+  for (int j = 0; j < 3 * H; ++j) s += dt[(int64_t)v * ldt + j] * w_ih[(int64_t)j * H + k];
+  atomicAdd(d_emb + (int64_t)v * H + k, s);
+}
+int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const float* emb, const float* w_ih, int V, int H,
+                  float* d_emb, float* d_w_ih, float* d_b_ih) {
+  hipLaunchKernelGGL(gru_table_bwd_w_kernel, dim3(3 * H), dim3(256), 0, st, dtable, ld_dtable, emb, V, H, d_w_ih, d_b_ih);
+  hipLaunchKernelGGL(gru_table_bwd_e_kernel, dim3((H + 255) / 256, V), dim3(256), 0, st, dtable, ld_dtable, w_ih, V, H, d_emb);
+  return RL_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d over NHWC [P][C] (char_cnn.py:17-28): statistics come from col_sum /
+// col_sumsq_centered (ops.hip); these kernels finalise and apply them.
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_mean_kernel(const float* sum, int C, float inv_p, float* mean) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) mean[c] = sum[c] * inv_p;
+}
+int bn_finalize_mean(hipStream_t st, const float* sum, int C, int P, float* mean) {
+  hipLaunchKernelGGL(bn_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sum, C, 1.0f / (float)P, mean);
+  return RL_LAUNCH_CHECK();
+}
+__global__ void bn_train_kernel(const float* mean, const float* sqsum, int C, int P, const float* gamma, const float* beta,
+                                float eps, float momentum, float* rmean, float* rvar, float* rstd, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float var = sqsum[c] / (float)P;                                 // biased: used to normalise
+  const float unbiased = sqsum[c] / (float)(P > 1 ? P - 1 : 1);          // running_var update
+  const float rs = 1.0f / sqrtf(var + eps);
+  rstd[c] = rs;
+  scale[c] = gamma[c] * rs;
+  shift[c] = beta[c] - mean[c] * gamma[c] * rs;
+  rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean[c];
+  rvar[c] = (1.0f - momentum) * rvar[c] + momentum * unbiased;
+}
+int bn_finalize_train(hipStream_t st, const float* mean, const float* sqsum, int C, int P, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var, float* rstd, float* scale, float* shift) {
+  hipLaunchKernelGGL(bn_train_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, sqsum, C, P, gamma, beta, eps, momentum,
+                     running_mean, running_var, rstd, scale, shift);
+  return RL_LAUNCH_CHECK();
+}
+__global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, float eps, const float* rmean, const float* rvar,
+                               float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rs = 1.0f / sqrtf(rvar[c] + eps);
+  scale[c] = gamma[c] * rs;
+  shift[c] = beta[c] - rmean[c] * gamma[c] * rs;
+}
+int bn_finalize_eval(hipStream_t st, int C, const float* gamma, const float* beta, float eps, const float* running_mean,
+                     const float* running_var, float* scale, float* shift) {
+  hipLaunchKernelGGL(bn_eval_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, eps, running_mean, running_var,
+                     scale, shift);
+  return RL_LAUNCH_CHECK();
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x1, const float* __restrict__ sc1, const float* __restrict__ sh1,
+                                const T* __restrict__ x2, const float* __restrict__ sc2, const float* __restrict__ sh2,
+                                T* __restrict__ y, int64_t n, int C, int relu) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    const int c = (int)(i % C);
+    floatx4 v = load4<T>(x1 + i) * *(const floatx4*)(sc1 + c) + *(const floatx4*)(sh1 + c);
+    if (x2 != nullptr) v += load4<T>(x2 + i) * *(const floatx4*)(sc2 + c) + *(const floatx4*)(sh2 + c);
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    store4<T>(y + i, v);
+  }
+}
+static inline int ew_blocks(int64_t n4) { int64_t b = (n4 + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+template <typename T>
+int bn_apply(hipStream_t st, const T* x1, const float* sc1, const float* sh1, const T* x2, const float* sc2, const float* sh2,
+             T* y, int P, int C, int relu) {
+  if (C & 3) return RL_ERR_ARG;
+  const int64_t n = (int64_t)P * C;
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, x1, sc1, sh1, x2, sc2, sh2, y, n, C, relu);
+  return RL_LAUNCH_CHECK();
+}
+template int bn_apply<bf16_t>(hipStream_t, const bf16_t*, const float*, const float*, const bf16_t*, const float*, const float*, bf16_t*, int, int, int);
+template int bn_apply<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int, int);
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ relu_src, const T* __restrict__ x,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ sums, int64_t n, int C, float inv_p, T* __restrict__ dx) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    const int c = (int)(i % C);
+    floatx4 g = load4<T>(dy + i);
+    if (relu_src != nullptr) {
+      const floatx4 o = load4<T>(relu_src + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+    }
+    const floatx4 rs = *(const floatx4*)(rstd + c);
+    const floatx4 xh = (load4<T>(x + i) - *(const floatx4*)(mean + c)) * rs;
+    const floatx4 m1 = *(const floatx4*)(sums + c) * inv_p, m2 = *(const floatx4*)(sums + C + c) * inv_p;
+    store4<T>(dx + i, *(const floatx4*)(gamma + c) * rs * (g - m1 - xh * m2));
+  }
+}
+__global__ void bn_param_grad_kernel(const float* sums, int C, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { dbeta[c] += sums[c]; dgamma[c] += sums[C + c]; }
+}
+template <typename T>
+int bn_bwd_apply(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd,
+                 const float* gamma, const float* sums, int P, int C, T* dx, float* dgamma, float* dbeta) {
+  if (C & 3) return RL_ERR_ARG;
+  const int64_t n = (int64_t)P * C;
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, dy, relu_src, x, mean, rstd, gamma,
+                     sums, n, C, 1.0f / (float)P, dx);
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
+  return RL_LAUNCH_CHECK();
+}
+template int bn_bwd_apply<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, const float*, const float*, int, int, bf16_t*, float*, float*);
+template int bn_bwd_apply<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, float*);
+
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ src, T* __restrict__ g, int64_t n) {
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    floatx4 d = load4<T>(dy + i);
+    const floatx4 o = load4<T>(src + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = o[j] > 0.f ? d[j] : 0.f;
+    store4<T>(g + i, d);
+  }
+}
+template <typename T> int relu_bwd(hipStream_t st, const T* dy, const T* relu_src, T* g, int64_t n) {
+  if (n & 3) return RL_ERR_ARG;
+  hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, dy, relu_src, g, n);
+  return RL_LAUNCH_CHECK();
+}
+template int relu_bwd<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, bf16_t*, int64_t);
+template int relu_bwd<float>(hipStream_t, const float*, const float*, float*, int64_t);
+
+// ---------------------------------------------------------------------------------------------
+// Operand shadows
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_copy_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = from_f<T>(src[i]);
+}
+template <typename T> int cast_copy(hipStream_t st, const float* src, T* dst, int64_t n) {
+  if (n <= 0) return RL_OK;
+  hipLaunchKernelGGL((cast_copy_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, src, dst, n);
+  return RL_LAUNCH_CHECK();
+}
+template int cast_copy<bf16_t>(hipStream_t, const float*, bf16_t*, int64_t);
+template int cast_copy<float>(hipStream_t, const float*, float*, int64_t);
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+cast_transpose_kernel(const float* __restrict__ src, int R, int C, T* __restrict__ dst, T* __restrict__ dstT) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) {
+      v = src[(int64_t)r * C + c];
+      if (dst != nullptr) dst[(int64_t)r * C + c] = from_f<T>(v);
+    }
+    tile[ty + 8 * k][tx] = v;
+  }
+  __syncthreads();
+  if (dstT != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c0 + ty + 8 * k, r = r0 + tx;
+      if (r < R && c < C) dstT[(int64_t)c * R + r] = from_f<T>(tile[tx][ty + 8 * k]);
+    }
+  }
+}
+template <typename T> int cast_transpose(hipStream_t st, const float* src, int R, int C, T* dst, T* dstT) {
+  hipLaunchKernelGGL((cast_transpose_kernel<T>), dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, src, R, C, dst, dstT);
+  return RL_LAUNCH_CHECK();
+}
+template int cast_transpose<bf16_t>(hipStream_t, const float*, int, int, bf16_t*, bf16_t*);
+template int cast_transpose<float>(hipStream_t, const float*, int, int, float*, float*);
+
+template <typename T>
+__global__ void conv_weight_shadow_kernel(const float* __restrict__ w, int Co, int Ci, int KHW, int Cpad, int CiRows,
+                                          T* __restrict__ fwd, T* __restrict__ dgrad) {
+  const int64_t nf = (int64_t)Co * KHW * Cpad, nd = (int64_t)CiRows * KHW * Co;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      if (fwd == nullptr) continue;
+      const int ci = (int)(i % Cpad);
+      const int tap = (int)((i / Cpad) % KHW);
+      const int co = (int)(i / ((int64_t)Cpad * KHW));
+      fwd[i] = from_f<T>(ci < Ci ? w[((int64_t)co * Ci + ci) * KHW + tap] : 0.f);
+    } else {
+      if (dgrad == nullptr) continue;
+      const int64_t k = i - nf;
+      const int co = (int)(k % Co);
+      const int tap = (int)((k / Co) % KHW);
+      const int ci = (int)(k / ((int64_t)Co * KHW));
+      dgrad[k] = from_f<T>(ci < Ci ? w[((int64_t)co * Ci + ci) * KHW + tap] : 0.f);
+    }
+  }
+}
+template <typename T>
+int conv_weight_shadow(hipStream_t st, const float* w, int Co, int Ci, int KHW, int Cpad, int CiRows, T* fwd, T* dgrad) {
+  const int64_t n = (int64_t)Co * KHW * Cpad + (int64_t)CiRows * KHW * Co;
+  hipLaunchKernelGGL((conv_weight_shadow_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, w, Co, Ci, KHW, Cpad, CiRows, fwd, dgrad);
+  return RL_LAUNCH_CHECK();
+}
+template int conv_weight_shadow<bf16_t>(hipStream_t, const float*, int, int, int, int, int, bf16_t*, bf16_t*);
+template int conv_weight_shadow<float>(hipStream_t, const float*, int, int, int, int, int, float*, float*);
+
+template <typename T>
+__global__ void glyph_shadow_kernel(const float* __restrict__ tbl, int64_t V, int F, int HW, int Cpad, T* __restrict__ out) {
+  const int64_t n = V * HW * Cpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int f = (int)(i % Cpad);
+    const int64_t px = (i / Cpad) % HW;
+    const int64_t v = i / ((int64_t)Cpad * HW);
+    out[i] = from_f<T>(f < F ? tbl[(v * F + f) * HW + px] : 0.f);
+  }
+}
+template <typename T> int glyph_shadow(hipStream_t st, const float* tbl, int V, int F, int HW, int Cpad, T* out) {
+  hipLaunchKernelGGL((glyph_shadow_kernel<T>), dim3(4096), dim3(256), 0, st, tbl, (int64_t)V, F, HW, Cpad, out);
+  return RL_LAUNCH_CHECK();
+}
+template int glyph_shadow<bf16_t>(hipStream_t, const float*, int, int, int, int, bf16_t*);
+template int glyph_shadow<float>(hipStream_t, const float*, int, int, int, int, float*);
+
+// ---------------------------------------------------------------------------------------------
+// Optimizer: global grad norm + AdamW over flat arenas
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const floatx4 v = *(const floatx4*)(g + i * 4);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n4 * 4; i < n; ++i) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+int sumsq_accum(hipStream_t st, const float* g, int64_t n, float* out) {
+  if (n <= 0) return RL_OK;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, st, g, n, out);
+  return RL_LAUNCH_CHECK();
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             int64_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2,
+                             const float* __restrict__ norm_sq, float max_norm) {
+  float clip = 1.0f;
+  if (norm_sq != nullptr) {
+    const float c = max_norm / (sqrtf(norm_sq[0]) + 1e-6f);
+    clip = c < 1.0f ? c : 1.0f;
+  }
+  const float step_size = lr * sqrtf(bc2) / bc1;     // optimization.py:156-160
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * clip;
+    const float mi = m[i] * beta1 + (1.0f - beta1) * gi;
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    float pi = p[i] - step_size * (mi / (sqrtf(vi) + eps));
+    if (wd > 0.f) pi -= lr * wd * pi;                 // decoupled decay AFTER the update (:162-167)
+    m[i] = mi; v[i] = vi; p[i] = pi;
+  }
+}
+int adamw_flat(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, float bias_c1, float bias_c2, const float* norm_sq, float max_norm) {
+  if (n <= 0) return RL_OK;
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                     bias_c1, bias_c2, norm_sq, max_norm);
+  return RL_LAUNCH_CHECK();
+}
+
+__global__ void fill_kernel(float* p, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+int fill_f32(hipStream_t st, float* p, float v, int64_t n) {
+  if (n <= 0) return RL_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, p, v, n);
+  return RL_LAUNCH_CHECK();
+}
+__global__ void add_i64_kernel(int64_t* p, int64_t v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] += v;
+}
+int add_i64(hipStream_t st, int64_t* p, int64_t v, int n) {
+  hipLaunchKernelGGL(add_i64_kernel, dim3((n + 63) / 64), dim3(64), 0, st, p, v, n);
+  return RL_LAUNCH_CHECK();
+}
+
+}  // namespace rl

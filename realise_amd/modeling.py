@@ -1,0 +1,400 @@
+"""Drop-in ``nn.Module`` shells for the reference's ``SpellBert`` / ``SpellBertPho2ResArch3``.
+
+Same constructor (``Model(config)``), same ``forward(batch) -> (loss, logits) | (logits,)``
+contract (src/models.py:50-73, 806-870), same ``state_dict`` keys, same
+trainer-facing methods (``tie_cls_weight``, ``from_pretrained``, ``save_pretrained``,
+``build_batch``; src/run.py:429-445).  All arithmetic happens in librealise_hip.so: the module
+owns five flat arenas (parameters, gradients, ...) that the C engine indexes directly, every
+``nn.Parameter`` is a *view* into them, and one ``torch.autograd.Function`` spans the whole
+model so ``loss.backward()`` is a single C call that accumulates into the gradient arena.
+
+There is no PyTorch / CPU fallback: forward on a non-CUDA device or without the built library
+raises.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _capi
+from .config import RealiseConfig
+from .init import tensor_init, tensor_specs, synth_glyph_table
+
+_DTYPES = {"bf16": (_capi.BF16, torch.bfloat16), "fp32": (_capi.F32, torch.float32)}
+_AR_TRAIN, _AR_UNUSED, _AR_FROZEN, _AR_BUF_F32, _AR_BUF_I64 = range(5)
+
+
+class _EngineLoss(torch.autograd.Function):
+    """Whole-model autograd node: forward already ran inside the engine; backward runs the
+    engine's backward stages, which ACCUMULATE into the module's gradient arena."""
+
+    @staticmethod
+    def forward(ctx, anchor, loss_value, module):
+        ctx.module = module
+        return loss_value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.module._run_backward(grad_out)
+        return None, None, None
+
+
+class _Container(nn.Module):
+    """name-space node so parameters carry the reference's dotted names"""
+
+
+class RealiseModule(nn.Module):
+    model_type = "arch3"
+
+    def __init__(self, config, compute_dtype=None, seed=0, init_scheme="reference", tie=True):
+        super().__init__()
+        if not isinstance(config, RealiseConfig):
+            config = RealiseConfig(**{k: getattr(config, k) for k in RealiseConfig.DEFAULTS if hasattr(config, k)})
+        config.validate()
+        self.config = config
+        self.vocab_size = config.vocab_size
+        self.compute_dtype = compute_dtype or os.environ.get("REALISE_DTYPE", "bf16")
+        if self.compute_dtype not in _DTYPES:
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        self._tie = bool(tie)
+        self._ccfg = _capi.make_config(config, self.model_type, _DTYPES[self.compute_dtype][0], tie=self._tie)
+        self._entries, self._sizes, self._buckets = _capi.layout(self._ccfg)
+        self._engine = None
+        self._shadow = None
+        self._ws = None
+        self._ws_key = None
+        self._shadow_version = None
+        self._step_seed = int(seed) * 1000003 + 12345
+        self.assume_unit_loss_grad = False
+        self.grad_sync = None               # optional object with bucket_ready(i) / finish(), set by the DDP wrapper
+        self._last = None
+        # ---- arenas (CPU first, like the reference: Model(config) -> load -> .to(device)) ----
+        self._arenas = [torch.zeros(max(self._sizes[0], 1), dtype=torch.float32),
+                        torch.zeros(max(self._sizes[1], 1), dtype=torch.float32),
+                        torch.zeros(max(self._sizes[2], 1), dtype=torch.float32),
+                        torch.zeros(max(self._sizes[3], 1), dtype=torch.float32),
+                        torch.zeros(max(self._sizes[4], 1), dtype=torch.int64)]
+        self._grads = torch.zeros(max(self._sizes[0], 1), dtype=torch.float32)
+        self._anchor = torch.zeros((), requires_grad=True)
+        self._views = {}
+        self._register_views()
+        self.init_weights(seed=seed, scheme=init_scheme)
+
+    # ------------------------------------------------------------------ parameter plumbing
+    def _view(self, arena, off, shape):
+        n = int(np.prod(shape)) if len(shape) else 1
+        return self._arenas[arena][off:off + n].view(shape)
+
+    def _register_views(self):
+        seen = {}
+        for name, arena, off, shape in self._entries:
+            parts = name.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Container())
+                mod = mod._modules[p]
+            leaf = parts[-1]
+            key = (arena, off)
+            if arena in (_AR_TRAIN, _AR_UNUSED, _AR_FROZEN):
+                if key in seen:                       # tied classifier.weight
+                    param = seen[key]
+                else:
+                    param = nn.Parameter(self._view(arena, off, shape), requires_grad=(arena != _AR_FROZEN))
+                    seen[key] = param
+                if leaf in mod._parameters:
+                    del mod._parameters[leaf]
+                mod.register_parameter(leaf, param)
+                self._views[name] = (arena, off, shape, param)
+            else:
+                mod.register_buffer(leaf, self._view(arena, off, shape))
+                self._views[name] = (arena, off, shape, None)
+
+    def _rebind(self):
+        """after the arenas moved (``.to(device)``): point every parameter/buffer at its slice again"""
+        for name, (arena, off, shape, param) in self._views.items():
+            v = self._view(arena, off, shape)
+            if param is not None:
+                param.data = v
+                if param.grad is not None and arena == _AR_TRAIN:
+                    n = v.numel()
+                    param.grad = self._grads[off:off + n].view(shape)
+            else:
+                parts = name.split(".")
+                mod = self
+                for p in parts[:-1]:
+                    mod = mod._modules[p]
+                mod._buffers[parts[-1]] = v
+
+    def _apply(self, fn, recurse=True):
+        probe = fn(torch.zeros(1, dtype=torch.float32))
+        if probe.dtype != torch.float32:
+            raise RuntimeError("master parameters stay fp32; choose the compute dtype with compute_dtype='bf16'|'fp32'")
+        self._arenas = [fn(a) if a.is_floating_point() else a.to(probe.device) for a in self._arenas]
+        self._grads = fn(self._grads)
+        self._anchor = torch.zeros((), requires_grad=True, device=probe.device)
+        self._rebind()
+        self._drop_engine()
+        return self
+
+    def _drop_engine(self):
+        if self._engine is not None:
+            _capi.load().realise_engine_destroy(self._engine)
+        self._engine = None
+        self._shadow = None
+        self._ws = None
+        self._ws_key = None
+        self._shadow_version = None
+
+    def __del__(self):
+        try:
+            self._drop_engine()
+        except Exception:
+            pass
+
+    @property
+    def device(self):
+        return self._arenas[0].device
+
+    # ------------------------------------------------------------------ reference-facing API
+    def init_weights(self, seed=0, scheme="reference"):
+        """transformers/modeling_bert.py:496-506 + PyTorch defaults, from a torch-independent generator."""
+        glyph = None
+        with torch.no_grad():
+            for name, shape, kind in tensor_specs(self.config, self.model_type):
+                if name == "classifier.weight" and self._tie:
+                    continue
+                arena, off, shp, param = self._views[name]
+                if kind == "glyph":
+                    val = synth_glyph_table(shape[0], shape[1], shape[2], seed)
+                else:
+                    val = tensor_init(name, shape, kind, self.config, seed, scheme)
+                self._view(arena, off, shp).copy_(torch.from_numpy(np.asarray(val)).view(shp))
+
+    def tie_cls_weight(self):
+        """src/models.py:700-701.  The classifier is tied from construction in this implementation."""
+        if not self._tie:
+            raise RuntimeError("constructed with tie=False; build the module with tie=True to share the weight")
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = dict(state_dict)
+        if self._tie and "classifier.weight" in sd and "bert.embeddings.word_embeddings.weight" in sd:
+            del sd["classifier.weight"]        # the reference re-points it at the embedding after loading (run.py:431)
+        missing, unexpected = [], []
+        with torch.no_grad():
+            for name, (arena, off, shape, param) in self._views.items():
+                if name == "classifier.weight" and self._tie:
+                    continue
+                if name not in sd:
+                    missing.append(name)
+                    continue
+                src = sd.pop(name)
+                if tuple(src.shape) != tuple(shape):
+                    raise RuntimeError("size mismatch for %s: %s vs %s" % (name, tuple(src.shape), tuple(shape)))
+                self._view(arena, off, shape).copy_(src.to(self._arenas[arena].dtype))
+        unexpected = list(sd.keys())
+        if strict and (missing or unexpected):
+            raise RuntimeError("load_state_dict: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
+        self._shadow_version = None
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
+
+    @classmethod
+    def from_pretrained(cls, path, config=None, **kw):
+        """transformers/modeling_utils.py:254-492: config.json + pytorch_model.bin."""
+        if config is None:
+            config = RealiseConfig.from_pretrained(path)
+        model = cls(config, **kw)
+        sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        model.load_state_dict(sd, strict=False)
+        return model
+
+    def save_pretrained(self, d):
+        """transformers/modeling_utils.py:236-251."""
+        os.makedirs(d, exist_ok=True)
+        self.config.save_pretrained(d)
+        torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, os.path.join(d, "pytorch_model.bin"))
+
+    def build_glyce_embed_multifonts(self, table):
+        """src/models.py:737-795 renders fonts that are absent here (.MISSING_LARGE_BLOBS); accept a
+        pre-rendered [V, F, 32, 32] table instead."""
+        with torch.no_grad():
+            self.char_images_multifonts.copy_(torch.as_tensor(table, dtype=torch.float32))
+        self._shadow_version = None
+
+    @staticmethod
+    def build_batch(batch, tokenizer=None):
+        return batch
+
+    def zero_grad(self, set_to_none=False):
+        self._grads.zero_()
+        if set_to_none:
+            for p in self.parameters():
+                p.grad = None
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ over the flat gradient arena (run.py:207): two kernels."""
+        total = torch.linalg.vector_norm(self._grads)
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        self._grads.mul_(coef)
+        return total
+
+    # ------------------------------------------------------------------ engine management
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ensure_engine(self, B, S, Tp):
+        lib = _capi.load()
+        if self.device.type != "cuda":
+            raise _capi.RealiseHipError("the ReaLiSe HIP path needs a GPU: move the module with .to('cuda') "
+                                        "(there is no CPU fallback)")
+        if self._engine is None:
+            a = self._arenas
+            self._engine = lib.realise_engine_create(C.byref(self._ccfg), a[0].data_ptr(), self._grads.data_ptr(),
+                                                     a[1].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr())
+            if not self._engine:
+                raise _capi.RealiseHipError("realise_engine_create rejected the configuration")
+            nbytes = lib.realise_engine_shadow_bytes(self._engine)
+            self._shadow = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws = None
+        key = (B, S, Tp)
+        need = lib.realise_engine_workspace_bytes(self._engine, B, S, Tp)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _capi.check(lib.realise_engine_bind(self._engine, self._shadow.data_ptr(), self._ws.data_ptr(), self._ws.numel()),
+                        "realise_engine_bind")
+        self._ws_key = key
+        # operand shadows: always re-derived in training (any optimizer may have stepped, including ones that
+        # write through `.data`, which torch's version counter does not see); in eval only when a tracked change
+        # happened (load_state_dict, in-place ops on parameters).
+        ver = (self._arenas[0]._version, self._arenas[2]._version)
+        if self.training or self._shadow_version != ver:
+            _capi.check(lib.realise_engine_refresh_shadows(self._engine, self._stream()), "realise_engine_refresh_shadows")
+            self._shadow_version = ver
+
+    def mark_parameters_updated(self):
+        """call after mutating parameters through a path torch's version counter cannot see (raw pointers)"""
+        self._shadow_version = None
+
+    def tap(self, name):
+        """named internal activation of the last forward as a torch tensor (parity tests)"""
+        lib = _capi.load()
+        ptr, n = C.c_void_p(), C.c_int64()
+        _capi.check(lib.realise_engine_tap(self._engine, name.encode(), C.byref(ptr), C.byref(n)), "tap " + name)
+        esz = 2 if self.compute_dtype == "bf16" else 4
+        off = ptr.value - self._ws.data_ptr()
+        return self._ws[off:off + n.value * esz].view(_DTYPES[self.compute_dtype][1])
+
+    # ------------------------------------------------------------------ forward / backward
+    def _dev(self, t):
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(t)
+        return t.to(device=self.device, dtype=torch.int64).contiguous()
+
+    def forward(self, batch):
+        src = self._dev(batch["src_idx"])
+        B, S = src.shape
+        masks = self._dev(batch["masks"])
+        tgt = self._dev(batch["tgt_idx"]) if "tgt_idx" in batch else None
+        loss_masks = self._dev(batch["loss_masks"]) if tgt is not None else None
+        keep = [src, masks, tgt, loss_masks]
+        cb = _capi.Batch()
+        cb.B, cb.S, cb.Tp = B, S, 1
+        training = bool(self.training)
+        need_grad = training and tgt is not None and torch.is_grad_enabled()
+        cb.training = 1 if training else 0
+        cb.want_dlogits = 1 if need_grad else 0
+        self._step_seed += 1
+        cb.seed = self._step_seed & 0xFFFFFFFFFFFFFFFF
+        cb.src_idx, cb.masks = src.data_ptr(), masks.data_ptr()
+        cb.tgt_idx = tgt.data_ptr() if tgt is not None else None
+        cb.loss_masks = loss_masks.data_ptr() if loss_masks is not None else None
+        if self.model_type == "arch3":
+            pho_idx = self._dev(batch["pho_idx"])
+            lens = np.asarray(batch["pho_lens"], dtype=np.int32)         # stays a HOST list in the reference (run.py:189)
+            if pho_idx.shape[0] != B * S or lens.shape[0] != B * S:
+                raise ValueError("pho_idx / pho_lens must have B*S rows")
+            Tp = int(pho_idx.shape[1])
+            if lens.min() < 1 or lens.max() > Tp:
+                raise ValueError("pho_lens out of range")            # pack_padded_sequence would raise too
+            perm = np.argsort(-lens, kind="stable").astype(np.int32)
+            lens_sorted = lens[perm]
+            alive = (C.c_int32 * Tp)(*[int((lens > t).sum()) for t in range(Tp)])
+            perm_d = torch.from_numpy(perm).to(self.device)
+            lens_d = torch.from_numpy(np.ascontiguousarray(lens_sorted)).to(self.device)
+            keep += [pho_idx, perm_d, lens_d, alive]
+            cb.Tp = Tp
+            cb.pho_idx, cb.pho_perm, cb.pho_lens_sorted = pho_idx.data_ptr(), perm_d.data_ptr(), lens_d.data_ptr()
+            cb.n_alive = alive
+        self._ensure_engine(B, S, cb.Tp)
+        tdt = _DTYPES[self.compute_dtype][1]
+        logits = torch.empty((B, S, self.vocab_size), dtype=tdt, device=self.device)
+        loss = torch.zeros((), dtype=torch.float32, device=self.device) if tgt is not None else None
+        cb.logits_out = logits.data_ptr()
+        cb.loss_out = loss.data_ptr() if loss is not None else None
+        _capi.check(_capi.load().realise_engine_forward(self._engine, self._stream(), C.byref(cb)), "realise_engine_forward")
+        self._last = keep
+        if tgt is None:
+            return (logits,)
+        if need_grad:
+            loss = _EngineLoss.apply(self._anchor, loss, self)
+        return (loss, logits)
+
+    def _attach_grads(self):
+        for name, (arena, off, shape, param) in self._views.items():
+            if arena == _AR_TRAIN and param is not None and param.grad is None:
+                n = int(np.prod(shape))
+                param.grad = self._grads[off:off + n].view(shape)
+
+    def _run_backward(self, grad_out):
+        lib = _capi.load()
+        sentinel = self._views["classifier.bias"][3]
+        if sentinel.grad is None:          # grads were set to None by an optimizer: start from zero
+            self._grads.zero_()
+        if not self.assume_unit_loss_grad:
+            d = self.tap_dlogits()
+            d.mul_(grad_out.to(d.dtype))
+        st = self._stream()
+        n = len(self._buckets)
+        if self.grad_sync is None:
+            _capi.check(lib.realise_engine_backward(self._engine, st, 0, -1), "realise_engine_backward")
+        else:
+            for i in range(n):
+                _capi.check(lib.realise_engine_backward(self._engine, st, i, i), "realise_engine_backward")
+                self.grad_sync.bucket_ready(i)
+            self.grad_sync.finish()
+        self._attach_grads()
+
+    def tap_dlogits(self):
+        return self.tap("dlogits")
+
+    def bucket_views(self):
+        """gradient buckets (flat slices of the gradient arena) in backward completion order"""
+        return [self._grads[b0:b1] for b0, b1 in self._buckets]
+
+    def flat_parameters(self):
+        return self._arenas[0][:self._sizes[0]]
+
+    def flat_gradients(self):
+        return self._grads[:self._sizes[0]]
+
+    def flat_bn_buffers(self):
+        return self._arenas[3][:self._sizes[3]]
+
+
+class SpellBertPho2ResArch3(RealiseModule):
+    """src/models.py:652-870."""
+    model_type = "arch3"
+
+
+class SpellBert(RealiseModule):
+    """src/models.py:32-73 (BASELINE config 1: BERT + tied classifier)."""
+    model_type = "bert"
+
+
+MODEL_CLASSES = {          # src/run.py:40-51
+    "bert": SpellBert,
+    "bert-pho2-res-arch3": SpellBertPho2ResArch3,
+}
