@@ -337,7 +337,7 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
       tn_epilogue4(ep, I, J, i0 + wi * 64 + i * 16 + l15, j0 + wj * 64 + j * 16 + 4 * g, acc[i][j]);
 }
 
-static int g_tn_tr = 0;
+static int g_tn_tr = 1;   // ds_read_b64_tr_b16 verified on MI355X (tests/test_kernels_gpu.py::test_gemm_tn)
 void set_tn_transpose_read(int use_tr) { g_tn_tr = use_tr; }
 
 template <typename T, typename BLoader>

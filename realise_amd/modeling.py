@@ -192,6 +192,8 @@ class RealiseModule(nn.Module):
                     missing.append(name)
                     continue
                 src = sd.pop(name)
+                if src.numel() == 1 and len(shape) == 0:
+                    src = src.reshape(())
                 if tuple(src.shape) != tuple(shape):
                     raise RuntimeError("size mismatch for %s: %s vs %s" % (name, tuple(src.shape), tuple(shape)))
                 self._view(arena, off, shape).copy_(src.to(self._arenas[arena].dtype))

@@ -152,7 +152,7 @@ def test_gemm_tn(dt, tr, Pn, I, J):
         ref = a.float().t() @ b.float() + base
         close(out, ref, 3e-3 if dt == "bf16" else 1e-4, "gemm_tn %s tr=%d" % (dt, tr))
     finally:
-        lib.realise_set_tn_transpose_read(0)
+        lib.realise_set_tn_transpose_read(1)
 
 
 # ------------------------------------------------------------------------------------------ conv
@@ -373,4 +373,4 @@ def test_adamw_and_gradnorm_kernels(golden_dir):
     big = rnd((100003,), 71).to(dev())
     acc = torch.zeros((1,), device=dev())
     _capi.check(lib.realise_sumsq(stream(), P(big), big.numel(), P(acc)), "sumsq")
-    assert abs(acc.item() - (big.double() ** 2).sum().item()) < 1e-2
+    assert abs(acc.item() - (big.double() ** 2).sum().item()) < 2e-6 * acc.item()
