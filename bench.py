@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""Headline benchmark: train sentences/sec of the full ReaLiSe model (SpellBertPho2ResArch3,
+BASELINE.json configs[1]) at seq_len 128, batch 64 per GPU, bf16 MFMA compute, synthetic
+SIGHAN-shaped data, random-init weights.
+
+A step = forward + backward (+ gradient all-reduce when N > 1) + global-norm clip + AdamW +
+LR schedule, i.e. exactly the body of the reference's hot loop (src/run.py:186-211) minus the
+host-side logging.  Inputs are resident in HBM before the timed region starts.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` times the dominant kernel family (the bf16 MFMA NT GEMM:
+every nn.Linear forward / data gradient, classifier, GRU step) with HIP events recorded on the launch
+stream during the timed region; `cpu_baseline` times the CPU oracle (a port: oracle/realise_ref.py) on
+a bounded sample of the same workload on this box's host cores (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+FAMILIES = ["gemm_nt", "conv_nt", "gemm_tn", "conv_tn", "attn_fwd", "attn_bwd"]
+
+
+def fwd_flops_per_sentence(S, mean_len):
+    """BASELINE.md section 4 accounting (nominal dense forward FLOPs)."""
+    per_tok = 19 * (14155776 + 2 * 2 * S * 768) + 32452608 + 126418944 + 18432 + 7077888 * mean_len
+    return per_tok * S
+
+
+def cpu_baseline(sd_cpu, cfg, sample_b, S):
+    """the oracle (CPU restatement, fp32, all host cores): one train fwd+bwd on `sample_b` sentences"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import realise_ref as R
+    from realise_amd.data import synthetic_batch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))      # more threads than this only adds contention at this size
+    sd = {}
+    for k, v in sd_cpu.items():
+        t = v.clone()
+        if t.dtype == torch.float32 and k != "char_images_multifonts" and "running_" not in k:
+            t.requires_grad_(True)
+        sd[k] = t
+    sd["classifier.weight"] = sd["bert.embeddings.word_embeddings.weight"]
+    ocfg = dict(cfg)
+    ocfg["hidden_dropout_prob"] = 0.1
+    warm = synthetic_batch(1, 32, seed=99)
+    tw = time.perf_counter()
+    R.arch3_forward(sd, ocfg, warm, training=True)[0].backward()          # thread-pool / allocator warm-up
+    tw = time.perf_counter() - tw
+    if tw * (sample_b * S / 32.0) > 120.0:                                 # keep the default run bounded on slow hosts
+        return {"value": round((32.0 / S) / tw, 4), "unit": "sentences/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "oracle/realise_ref.py fp32 train forward+backward, 1 sentence x 32 tokens (cold) = %.1f s, scaled to seq_len %d" % (tw, S)}
+    batch = synthetic_batch(sample_b, S, seed=98)
+    t0 = time.perf_counter()
+    loss = R.arch3_forward(sd, ocfg, batch, training=True)[0]
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_b / dt, 4), "unit": "sentences/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/realise_ref.py fp32 train forward+backward (dropout on), %d sentences x seq_len %d, 1 iteration = %.1f s"
+                      % (sample_b, S, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from realise_amd import _capi
+    from realise_amd.config import RealiseConfig
+    from realise_amd.data import synthetic_batch
+    from realise_amd.ddp import DistributedDataParallel
+    from realise_amd.modeling import SpellBertPho2ResArch3
+    from realise_amd.optim import FusedAdamW, get_linear_schedule_with_warmup
+    lib = _capi.load()
+
+    cfg = RealiseConfig()                                   # full model: 12 + 4 + 3 layers, 3 fonts, dropout 0.1
+    model = SpellBertPho2ResArch3(cfg, compute_dtype=args.dtype, seed=0)
+    sd_cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(dev)
+    model.train()
+    model.assume_unit_loss_grad = True                      # plain loss.backward(), as in run.py:200
+    wrapped = DistributedDataParallel(model) if world > 1 else model
+    no_decay = ["bias", "LayerNorm.weight"]                 # run.py:146-151
+    groups = [{"params": [p for n, p in model.named_parameters() if p.requires_grad and not any(nd in n for nd in no_decay)],
+               "weight_decay": 0.0},
+              {"params": [p for n, p in model.named_parameters() if p.requires_grad and any(nd in n for nd in no_decay)],
+               "weight_decay": 0.0}]
+    opt = FusedAdamW(model, groups, lr=5e-5, eps=1e-8, max_grad_norm=1.0)         # train.sh / run.py:333-339
+    sched = get_linear_schedule_with_warmup(opt, 10000, 1000000)
+
+    batch = synthetic_batch(args.batch, args.seq, seed=1000 + rank)
+    mean_len = float(sum(batch["pho_lens"])) / len(batch["pho_lens"])
+    for k in ("src_idx", "tgt_idx", "masks", "loss_masks", "pho_idx"):
+        batch[k] = batch[k].to(dev)
+    tr_loss = torch.zeros((), device=dev)
+
+    def step():
+        loss = wrapped(batch)[0]
+        loss.backward()
+        tr_loss.add_(loss.detach())
+        opt.step()
+        sched.step()
+        model.zero_grad()
+
+    for _ in range(args.warmup):
+        step()
+    profile = (rank == 0) and not args.no_profile
+    if profile:
+        _capi.check(lib.realise_profile_enable(args.steps * 1200 + 64), "realise_profile_enable")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(tr_loss.item()) / max(1, args.steps + args.warmup)
+
+    fams = {}
+    if profile:
+        cnt, ms, work = C.c_longlong(), C.c_double(), C.c_double()
+        for i, name in enumerate(FAMILIES):
+            lib.realise_profile_read(i, C.byref(cnt), C.byref(ms), C.byref(work))
+            if cnt.value:
+                fams[name] = {"launches_per_step": cnt.value / args.steps, "ms_per_step": ms.value / args.steps,
+                              "avg_launch_us": 1e3 * ms.value / cnt.value,
+                              "tflops": work.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0}
+        lib.realise_profile_disable()
+
+    if rank == 0:
+        sent = world * args.batch * args.steps
+        step_flops = 3.0 * fwd_flops_per_sentence(args.seq, mean_len) * args.batch
+        out = {
+            "metric": "train sentences/sec (seq_len=128)",
+            "value": round(sent / elapsed, 2),
+            "unit": "sentences/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]%s: full ReaLiSe SpellBertPho2ResArch3 (12+4+3 BERT layers, pinyin GRU, "
+                                   "3-font glyph ResNet, gate, tied 21128-way classifier), train step = fwd+bwd%s+clip+AdamW, "
+                                   "dropout 0.1, random-init weights, SIGHAN-shaped synthetic batch"
+                                   % ("" if world == 1 else " x%d GPUs (configs[2])" % world,
+                                      "" if world == 1 else "+RCCL all-reduce"),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "seq_len": args.seq,
+                       "parallelism": "dp%d" % world, "mean_pinyin_len": round(mean_len, 3), "mean_loss": round(final_loss, 4)},
+            "model_flops_per_step_per_gpu": step_flops,
+            "model_mfma_util": round(step_flops / (elapsed / args.steps) / (PEAK_BF16_TFLOPS * 1e12), 4),
+        }
+        if "gemm_nt" in fams:
+            f = fams["gemm_nt"]
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16, DenseLoader> (v_mfma_f32_16x16x32_bf16)",
+                               "achieved": round(f["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(f["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "avg_launch_us": round(f["avg_launch_us"], 2),
+                               "launches_per_step": f["launches_per_step"],
+                               "flops_per_launch": round(f["tflops"] * 1e12 * f["avg_launch_us"] * 1e-6)}
+            out["kernel_families"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in fams.items()}
+        if sd_cpu is not None:
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, args.cpu_sample, args.seq)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,12 +58,14 @@ int realise_gemm_nt(void* stream, int dtype, const void* A, int64_t lda, const v
 /* Same with A gathered on the fly: nn.Conv2d forward / input gradient (src/char_cnn.py:15-28). */
 int realise_conv_nt(void* stream, int dtype, const realise_conv_geom* a, const void* B, int64_t ldb,
                     int M, int N, int K, const realise_epilogue* ep);
-/* out[I,J] += sum_p A[p,i] * B[p,j] (fp32, atomic) - nn.Linear weight gradient. */
+/* out[I,J] += sum_p A[p,i] * B[p,j] (fp32) - nn.Linear weight gradient.  The reduction over p is split
+ * over workgroups; `scratch` (fp32, scratch_elems >= I*J, ideally several times that) receives the partial
+ * slabs that a second kernel folds into `out`.  scratch == NULL falls back to fp32 atomics. */
 int realise_gemm_tn(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
-                    int P, int I, int J, float* out, int64_t ldo);
+                    int P, int I, int J, float* out, int64_t ldo, float* scratch, int64_t scratch_elems);
 /* Conv2d weight gradient into the reference's [Co][Ci][KH][KW] layout. */
 int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const realise_conv_geom* b,
-                    int P, int Co, int Ci, float* out);
+                    int P, int Co, int Ci, float* out, float* scratch, int64_t scratch_elems);
 /* 1: ds_read_b64_tr_b16 transposed operand reads in the TN kernel (bf16), 0: 16-bit LDS gathers. */
 void realise_set_tn_transpose_read(int enable);
 
@@ -124,6 +126,8 @@ int64_t realise_engine_workspace_bytes(const realise_engine* e, int B, int S, in
 int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_t workspace_bytes);
 /* re-derive the compute-dtype operand copies from the fp32 masters (after any parameter update) */
 int realise_engine_refresh_shadows(realise_engine* e, void* stream);
+/* the frozen glyph table (arena 2) changed: rebuild its NHWC operand image at the next refresh */
+void realise_engine_invalidate_frozen(realise_engine* e);
 
 typedef struct {
   int32_t B, S, Tp;
@@ -158,6 +162,13 @@ int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, in
                   float beta2, float eps, float weight_decay, int64_t step, int correct_bias,
                   const float* grad_norm_sq, float max_grad_norm);
 int realise_fill_f32(void* stream, float* p, float value, int64_t n);
+
+/* Per-launch timing of the MFMA kernel families with HIP events on the launch stream (bench.py roofline).
+ * family: 0 gemm_nt, 1 conv_nt (implicit im2col), 2 gemm_tn, 3 conv_tn, 4 attention fwd, 5 attention bwd.
+ * total_work = algorithmic FLOPs (2*M*N*K per GEMM launch). */
+int realise_profile_enable(int max_launches);
+void realise_profile_disable(void);
+int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work);
 
 const char* realise_version(void);
 

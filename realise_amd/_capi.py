@@ -47,8 +47,8 @@ SYMBOLS = {
     "realise_version": (C.c_char_p, []),
     "realise_gemm_nt": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
     "realise_conv_nt": (_I, [_P, _I, C.POINTER(ConvGeom), _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
-    "realise_gemm_tn": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, _P, _L]),
-    "realise_conv_tn": (_I, [_P, _I, _P, _L, C.POINTER(ConvGeom), _I, _I, _I, _P]),
+    "realise_gemm_tn": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, _P, _L, _P, _L]),
+    "realise_conv_tn": (_I, [_P, _I, _P, _L, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _L]),
     "realise_set_tn_transpose_read": (None, [_I]),
     "realise_attention_fwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _U, _U, _F]),
     "realise_attention_bwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _U, _U, _F]),
@@ -68,12 +68,16 @@ SYMBOLS = {
     "realise_engine_workspace_bytes": (_L, [_P, _I, _I, _I]),
     "realise_engine_bind": (_I, [_P, _P, _P, _L]),
     "realise_engine_refresh_shadows": (_I, [_P, _P]),
+    "realise_engine_invalidate_frozen": (None, [_P]),
     "realise_engine_forward": (_I, [_P, _P, C.POINTER(Batch)]),
     "realise_engine_backward": (_I, [_P, _P, _I, _I]),
     "realise_engine_tap": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_L)]),
     "realise_sumsq": (_I, [_P, _P, _L, _P]),
     "realise_adamw": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _I, _P, _F]),
     "realise_fill_f32": (_I, [_P, _P, _F, _L]),
+    "realise_profile_enable": (_I, [_I]),
+    "realise_profile_disable": (None, []),
+    "realise_profile_read": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -15,6 +15,7 @@
 // Operands contracted over the sequence dimension (V^T, dO^T, Q^T, K^T) are kept in LDS in a
 // [64][S] sequence-contiguous image with a 16-byte row pad (conflict-free ds_read_b64).
 #include "attention.h"
+#include "prof.h"
 
 namespace rl {
 
@@ -447,6 +448,7 @@ int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
   const size_t lds = G::KT_BYTES + G::TT_BYTES + SMAX * sizeof(float);
   static bool once = false;
   if (!once) { set_lds(attn_fwd_kernel<T>, lds); once = true; }
+  ProfScope ps(st, PK_ATTN_FWD, 4.0 * B * nh * (double)S * S * 64);
   hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(B * nh), dim3(256), lds, st, q, k, v, ldq, mask_add, ctx, ldc, lse, B, nh, S,
                      drop_seed, drop_thresh, drop_scale);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
@@ -462,6 +464,7 @@ int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
   const size_t lds2 = 2 * G::KT_BYTES + G::TT_BYTES + SMAX * sizeof(float);
   static bool once = false;
   if (!once) { set_lds(attn_bwd_dkv_kernel<T>, lds1); set_lds(attn_bwd_dq_kernel<T>, lds2); once = true; }
+  ProfScope ps(st, PK_ATTN_BWD, 10.0 * B * nh * (double)S * S * 64);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(B * nh), dim3(256), lds1, st, q, k, v, ldq, mask_add, ctx, dctx, ldc,
                      lse, rowdot, dk, dv, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(B * nh), dim3(256), lds2, st, q, k, v, ldq, mask_add, dctx, ldc, lse,

@@ -7,6 +7,7 @@
 #include "gemm.h"
 #include "layout.h"
 #include "ops.h"
+#include "prof.h"
 
 using namespace rl;
 
@@ -24,7 +25,8 @@ template <typename T> EpiParams<T> to_epi(const realise_epilogue* e) {
 template <typename T> ConvLoader<T> to_geom(const realise_conv_geom* g) {
   ConvLoader<T> c;
   c.src = (const T*)g->src; c.img_index = g->img_index; c.rows = g->rows; c.Hr = g->Hr; c.Wr = g->Wr; c.Hs = g->Hs; c.Ws = g->Ws;
-  c.C = g->C; c.KH = g->KH; c.KW = g->KW; c.stride = g->stride; c.pad = g->pad; c.mode = g->mode; c.K = g->KH * g->KW * g->C;
+  c.C = g->C; c.KH = g->KH; c.KW = g->KW; c.stride = g->stride; c.pad = g->pad; c.mode = g->mode;
+  c.finalize();
   return c;
 }
 }  // namespace
@@ -50,18 +52,19 @@ int realise_conv_nt(void* stream, int dtype, const realise_conv_geom* a, const v
   return RL_ERR_ARG;
 }
 int realise_gemm_tn(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int P, int I, int J,
-                    float* out, int64_t ldo) {
+                    float* out, int64_t ldo, float* scratch, int64_t scratch_elems) {
   hipStream_t st = (hipStream_t)stream;
-  TnEpi te; te.out = out; te.ldo = ldo;
+  TnEpi te; te.out = out; te.ldo = ldo; te.slab = scratch; te.slab_elems = scratch_elems;
   if (dtype == REALISE_BF16) return gemm_tn<bf16_t>(st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, P, I, J, te);
   if (dtype == REALISE_F32) return gemm_tn<float>(st, (const float*)A, lda, (const float*)B, ldb, P, I, J, te);
   return RL_ERR_ARG;
 }
 int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const realise_conv_geom* b, int P, int Co, int Ci,
-                    float* out) {
+                    float* out, float* scratch, int64_t scratch_elems) {
   hipStream_t st = (hipStream_t)stream;
   if (!b) return RL_ERR_ARG;
   TnEpi te; te.mode = TN_CONVW; te.out = out; te.Cin = Ci; te.Cpad = b->C; te.KHW = b->KH * b->KW;
+  te.slab = scratch; te.slab_elems = scratch_elems;
   const int J = b->KH * b->KW * b->C;
   if (dtype == REALISE_BF16) return gemm_tn_conv<bf16_t>(st, (const bf16_t*)A, lda, to_geom<bf16_t>(b), P, Co, J, te);
   if (dtype == REALISE_F32) return gemm_tn_conv<float>(st, (const float*)A, lda, to_geom<float>(b), P, Co, J, te);
@@ -183,6 +186,7 @@ int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_
   return e ? e->impl->bind(shadow, workspace, workspace_bytes) : RL_ERR_ARG;
 }
 int realise_engine_refresh_shadows(realise_engine* e, void* stream) { return e ? e->impl->refresh_shadows((hipStream_t)stream) : RL_ERR_ARG; }
+void realise_engine_invalidate_frozen(realise_engine* e) { if (e) e->impl->invalidate_frozen(); }
 int realise_engine_forward(realise_engine* e, void* stream, const realise_batch* batch) {
   return (e && batch) ? e->impl->forward((hipStream_t)stream, *batch) : RL_ERR_ARG;
 }
@@ -203,6 +207,12 @@ int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, in
     bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   }
   return adamw_flat((hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_norm_sq, max_grad_norm);
+}
+int realise_profile_enable(int max_launches) { return prof_enable(max_launches); }
+void realise_profile_disable(void) { prof_disable(); }
+int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work) {
+  if (kernel_family < 0 || kernel_family >= PK_COUNT || !count || !total_ms || !total_work) return RL_ERR_ARG;
+  return prof_read(kernel_family, count, total_ms, total_work);
 }
 int realise_fill_f32(void* stream, float* p, float value, int64_t n) { return fill_f32((hipStream_t)stream, p, value, n); }
 

@@ -11,6 +11,7 @@ struct EngineBase {
   virtual int64_t workspace_bytes(int B, int S, int Tp) = 0;
   virtual int bind(void* shadow, void* workspace, int64_t bytes) = 0;
   virtual int refresh_shadows(hipStream_t st) = 0;
+  virtual void invalidate_frozen() = 0;
   virtual int forward(hipStream_t st, const realise_batch& b) = 0;
   virtual int backward(hipStream_t st, int first, int last) = 0;
   virtual int get_tap(const char* name, void** ptr, int64_t* numel) = 0;

@@ -20,6 +20,7 @@ namespace rl {
 
 #define RL_TRY(expr) do { const int _rc = (expr); if (_rc != RL_OK) { fprintf(stderr, "[realise_hip] %s failed (%d) at %s:%d\n", #expr, _rc, __FILE__, __LINE__); return _rc; } } while (0)
 
+static constexpr int64_t TN_SLAB_ELEMS = 16LL << 20;   // fp32 partial slabs of the split weight-gradient reductions (64 MiB)
 static inline int64_t al256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 struct Bump {
   int64_t off = 0;
@@ -67,7 +68,7 @@ template <typename T> struct Engine : EngineBase {
     int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
     int64_t bn_sums;
     // backward scratch
-    int64_t gA, gB, gC, gE, gD, gF, rowdot, X1, X2, X3, dz;
+    int64_t gA, gB, gC, gE, gD, gF, rowdot, X1, X2, X3, dz, tn_slab;
     int64_t gru_dh, gru_dgi, gru_dgh, gru_onehot, gru_dtable;
     int64_t r_dout, r_dc2, r_dcs, r_dh1, r_dc1, r_dx;
   } pl;
@@ -155,9 +156,12 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(conv_weight_shadow<T>(st, pp(o.w2), o.cout, o.cout, 9, o.cout, o.cout, sp<T>(s.w2f), sp<T>(s.w2d)));
         RL_TRY(conv_weight_shadow<T>(st, pp(o.ws), o.cout, o.cin, 1, s.cin_pad, s.cin_pad, sp<T>(s.wsf), sp<T>(s.wsd)));
       }
-      // the glyph table is frozen (requires_grad=False, models.py:679): rebuilt on every refresh anyway,
-      // it only changes through load_state_dict / build_glyce_embed*
-      RL_TRY(glyph_shadow<T>(st, FZ + L.glyph, V, cfg.num_fonts, cfg.glyph_size * cfg.glyph_size, 8, sp<T>(sh_glyph)));
+      // the glyph table is frozen (requires_grad=False, models.py:679): its NHWC image is rebuilt only after
+      // invalidate_frozen() (load_state_dict / build_glyce_embed*)
+      if (!glyph_built) {
+        RL_TRY(glyph_shadow<T>(st, FZ + L.glyph, V, cfg.num_fonts, cfg.glyph_size * cfg.glyph_size, 8, sp<T>(sh_glyph)));
+        glyph_built = true;
+      }
     }
     return RL_OK;
   }
@@ -196,6 +200,7 @@ template <typename T> struct Engine : EngineBase {
     // shared backward scratch
     p.gA = b.take(Tk * H * e); p.gB = b.take(Tk * H * e); p.gC = b.take(Tk * H * e); p.gE = b.take(Tk * H * e);
     p.gD = b.take(Tk * I * e); p.gF = b.take(Tk * 3 * H * e); p.rowdot = b.take((int64_t)B * nh * S * 4);
+    p.tn_slab = b.take(TN_SLAB_ELEMS * 4);
     tap("d_x0", p.gB, Tk * H);
     if (cfg.model_type == 1) {
       plan_stack(p.pho, cfg.pho_layers, "pho_model");
@@ -242,9 +247,11 @@ template <typename T> struct Engine : EngineBase {
     return p.total;
   }
   int bind(void* shadow, void* workspace, int64_t bytes) override {
+    if (shadow != (void*)sh) glyph_built = false;
     sh = (char*)shadow; ws = (char*)workspace; ws_bytes = bytes; pl = Plan(); have_fwd = false;
     return RL_OK;
   }
+  void invalidate_frozen() override { glyph_built = false; }
   int get_tap(const char* name, void** ptr, int64_t* numel) override {
     auto it = taps.find(name);
     if (it == taps.end() || !ws) return RL_ERR_ARG;
@@ -340,13 +347,13 @@ template <typename T> struct Engine : EngineBase {
       }
       const T* dso = d3.thresh ? gC : gB;
       RL_TRY(bias_grad<T>(st, dso, H, Tk, H, gp(o.out_b)));
-      { TnEpi te; te.out = gp(o.out_w); te.ldo = I; RL_TRY(gemm_tn<T>(st, dso, H, wp<T>(t.post), I, Tk, H, I, te)); }
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(o.out_w); te.ldo = I; RL_TRY(gemm_tn<T>(st, dso, H, wp<T>(t.post), I, Tk, H, I, te)); }
       {  // d pre = (d s2' . W_out) * gelu'(pre)
         EpiParams<T> ep; ep.mode = EPI_GELU_BWD; ep.out = gD; ep.ldo = I; ep.aux = wp<T>(t.pre); ep.ldaux = I;
         RL_TRY(gemm_nt<T>(st, dso, H, sp<T>(w.out_wT), H, Tk, I, H, ep));
       }
       RL_TRY(bias_grad<T>(st, gD, I, Tk, I, gp(o.in_b)));
-      { TnEpi te; te.out = gp(o.in_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gD, I, wp<T>(t.y1), H, Tk, I, H, te)); }
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(o.in_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gD, I, wp<T>(t.y1), H, Tk, I, H, te)); }
       {  // d y1 = d s2 + d pre . W_in
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gB; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
@@ -359,7 +366,7 @@ template <typename T> struct Engine : EngineBase {
       }
       const T* dsa = d2.thresh ? gC : gA;
       RL_TRY(bias_grad<T>(st, dsa, H, Tk, H, gp(o.ao_b)));
-      { TnEpi te; te.out = gp(o.ao_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dsa, H, wp<T>(t.ctx), H, Tk, H, H, te)); }
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(o.ao_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dsa, H, wp<T>(t.ctx), H, Tk, H, H, te)); }
       {  // d ctx = d s1' . W_ao
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gE; ep.ldo = H;
         RL_TRY(gemm_nt<T>(st, dsa, H, sp<T>(w.ao_wT), H, Tk, H, H, ep));
@@ -370,7 +377,7 @@ template <typename T> struct Engine : EngineBase {
                            wp<float>(pl.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale));
       }
       RL_TRY(bias_grad<T>(st, gF, 3 * H, Tk, 3 * H, gp(o.qkv_b)));
-      { TnEpi te; te.out = gp(o.qkv_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gF, 3 * H, x_in, H, Tk, 3 * H, H, te)); }
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(o.qkv_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gF, 3 * H, x_in, H, Tk, 3 * H, H, te)); }
       {  // d x_in = d s1 + d qkv . W_qkv
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, gF, 3 * H, sp<T>(w.qkv_wT), 3 * H, Tk, H, 3 * H, ep));
@@ -465,7 +472,7 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), pp(o.bns.g), sums,
                              Pn, Co, dcs, gp(o.bns.g), gp(o.bns.b)));
       // conv2 (3x3 s1): weight grad and data grad
-      { TnEpi te; te.mode = TN_CONVW; te.out = gp(o.w2); te.Cin = Co; te.Cpad = Co; te.KHW = 9;
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w2); te.Cin = Co; te.Cpad = Co; te.KHW = 9;
         RL_TRY(gemm_tn_conv<T>(st, dc2, Co, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0), Pn, Co, 9 * Co, te)); }
       { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = dh1; ep.ldo = Co;
         RL_TRY(gemm_nt_conv<T>(st, geom(dc2, nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 1), sp<T>(s.w2d), 9 * Co, Pn, Co, 9 * Co, ep)); }
@@ -475,9 +482,9 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(bn_bwd_apply<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), pp(o.bn1.g), sums,
                              Pn, Co, dc1, gp(o.bn1.g), gp(o.bn1.b)));
       // conv1 (3x3 s2) and shortcut (1x1 s2) weight grads
-      { TnEpi te; te.mode = TN_CONVW; te.out = gp(o.w1); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 9;
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w1); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 9;
         RL_TRY(gemm_tn_conv<T>(st, dc1, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 3, 2, 1, 0), Pn, Co, 9 * Cin, te)); }
-      { TnEpi te; te.mode = TN_CONVW; te.out = gp(o.ws); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 1;
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.ws); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 1;
         RL_TRY(gemm_tn_conv<T>(st, dcs, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 1, 2, 0, 0), Pn, Co, Cin, te)); }
       if (k > 0) {   // d x_in = dgrad(conv1) + dgrad(shortcut); the glyph table itself is frozen
         const int Pin = pl.blk[k - 1].Pout;
@@ -529,10 +536,10 @@ template <typename T> struct Engine : EngineBase {
       a.rzn = wp<T>(pl.gru_rzn) + (int64_t)t * N * 3 * H; a.dout = dout; a.dh = wp<T>(pl.gru_dh); a.dgi = wp<T>(pl.gru_dgi);
       a.dgh = wp<T>(pl.gru_dgh); a.onehot = wp<T>(pl.gru_onehot);
       RL_TRY(gru_step_bwd<T>(st, a));
-      { TnEpi te; te.out = dtable; te.ldo = 3 * H; RL_TRY(gemm_tn<T>(st, a.onehot, 64, a.dgi, 3 * H, n, 64, 3 * H, te)); }
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = dtable; te.ldo = 3 * H; RL_TRY(gemm_tn<T>(st, a.onehot, 64, a.dgi, 3 * H, n, 64, 3 * H, te)); }
       RL_TRY(bias_grad<T>(st, a.dgh, 3 * H, n, 3 * H, gp(L.gru_b_hh)));
       if (t > 0) {
-        { TnEpi te; te.out = gp(L.gru_w_hh); te.ldo = H; RL_TRY(gemm_tn<T>(st, a.dgh, 3 * H, hs_prev, H, n, 3 * H, H, te)); }
+        { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(L.gru_w_hh); te.ldo = H; RL_TRY(gemm_tn<T>(st, a.dgh, 3 * H, hs_prev, H, n, 3 * H, H, te)); }
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = a.dh; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, a.dgh, 3 * H, sp<T>(sh_gru_hhT), 3 * H, n, H, 3 * H, ep));
       }
@@ -612,7 +619,7 @@ template <typename T> struct Engine : EngineBase {
     const T* top = cfg.model_type == 1 ? wp<T>(pl.outb.layers.back().y2) : wp<T>(pl.bert.layers.back().y2);
     const T* cls_in = dfin.thresh ? wp<T>(pl.out_d) : top;
     RL_TRY(bias_grad<T>(st, dl, V, Tk, V, gp(L.cls_b)));
-    { TnEpi te; te.out = gp(L.cls_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dl, V, cls_in, H, Tk, V, H, te)); }
+    { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(L.cls_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dl, V, cls_in, H, Tk, V, H, te)); }
     { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H;
       RL_TRY(gemm_nt<T>(st, dl, V, sp<T>(sh_cls_wT), V, Tk, H, V, ep)); }
     if (dfin.thresh) RL_TRY(dropout_apply<T>(st, gA, gA, Tk, H, dfin));

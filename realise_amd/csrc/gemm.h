@@ -30,17 +30,23 @@ template <typename T> struct EpiParams {
 };
 
 // ---- operand loaders ---------------------------------------------------------------------------
+// A loader maps (row, k) of a logical K-contiguous operand to the global address of a 16-byte chunk
+// (or to a zero page when out of range), for direct-to-LDS staging.  Ctx = per-row state, KPos =
+// per-column state that is advanced incrementally from K-tile to K-tile (no integer divisions in
+// the main loop).
 template <typename T> struct DenseLoader {
   const T* base;
   int64_t ld;
   int rows, K;
   struct Ctx { const T* p; };
+  struct KPos { int k; };
   __device__ __forceinline__ Ctx prepare(int row) const {
     Ctx c; c.p = (row < rows) ? base + (int64_t)row * ld : nullptr; return c;
   }
-  __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
-    if (c.p != nullptr && k < K) return *(const uint4*)(c.p + k);
-    return make_uint4(0, 0, 0, 0);
+  __device__ __forceinline__ KPos kpos(int k) const { KPos q; q.k = k; return q; }
+  __device__ __forceinline__ void advance(KPos& q, int dk) const { q.k += dk; }
+  __device__ __forceinline__ const void* addr(const Ctx& c, const KPos& q, const void* zero) const {
+    return (c.p != nullptr && q.k < K) ? (const void*)(c.p + q.k) : zero;
   }
 };
 
@@ -52,34 +58,63 @@ template <typename T> struct ConvLoader {
   const T* src;
   const int64_t* img_index;
   int rows, Hr, Wr, Hs, Ws, C, KH, KW, stride, pad, mode, K;
+  int hw_shift, w_shift;      // log2(Hr*Wr), log2(Wr) when both are powers of two, else -1 (set by finalize())
   struct Ctx { const T* img; int y, x; };
+  struct KPos { int kh, kw, ch, k; };
+  void finalize() {
+    K = KH * KW * C;
+    hw_shift = w_shift = -1;
+    const int hw = Hr * Wr;
+    if (hw > 0 && (hw & (hw - 1)) == 0 && (Wr & (Wr - 1)) == 0) {
+      hw_shift = 0; while ((1 << hw_shift) < hw) ++hw_shift;
+      w_shift = 0; while ((1 << w_shift) < Wr) ++w_shift;
+    }
+  }
   __device__ __forceinline__ Ctx prepare(int row) const {
     Ctx c; c.img = nullptr; c.y = 0; c.x = 0;
     if (row < rows) {
-      const int hw = Hr * Wr;
-      const int n = row / hw, rem = row - n * hw;
-      c.y = rem / Wr; c.x = rem - c.y * Wr;
+      int n, rem;
+      if (hw_shift >= 0) {
+        n = row >> hw_shift; rem = row & ((1 << hw_shift) - 1);
+        c.y = rem >> w_shift; c.x = rem & ((1 << w_shift) - 1);
+      } else {
+        const int hw = Hr * Wr;
+        n = row / hw; rem = row - n * hw;
+        c.y = rem / Wr; c.x = rem - c.y * Wr;
+      }
       const int64_t ns = img_index ? img_index[n] : (int64_t)n;
       c.img = src + ns * Hs * Ws * C;
     }
     return c;
   }
-  __device__ __forceinline__ uint4 load(const Ctx& c, int k) const {
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    if (c.img == nullptr || k >= K) return z;
-    const int tap = k / C, ch = k - tap * C;
-    const int kh = tap / KW, kw = tap - kh * KW;
+  __device__ __forceinline__ KPos kpos(int k) const {
+    KPos q; q.k = k;
+    const int tap = k / C;
+    q.ch = k - tap * C; q.kh = tap / KW; q.kw = tap - q.kh * KW;
+    return q;
+  }
+  __device__ __forceinline__ void advance(KPos& q, int dk) const {
+    q.k += dk; q.ch += dk;
+    while (q.ch >= C) { q.ch -= C; if (++q.kw == KW) { q.kw = 0; ++q.kh; } }
+  }
+  __device__ __forceinline__ const void* addr(const Ctx& c, const KPos& q, const void* zero) const {
+    if (c.img == nullptr || q.k >= K) return zero;
     int sy, sx;
     if (mode == 0) {
-      sy = c.y * stride + kh - pad; sx = c.x * stride + kw - pad;
+      sy = c.y * stride + q.kh - pad; sx = c.x * stride + q.kw - pad;
     } else {
-      const int ty = c.y + pad - kh, tx = c.x + pad - kw;
-      if (ty < 0 || tx < 0) return z;
-      sy = ty / stride; sx = tx / stride;
-      if (sy * stride != ty || sx * stride != tx) return z;
+      const int ty = c.y + pad - q.kh, tx = c.x + pad - q.kw;
+      if (ty < 0 || tx < 0) return zero;
+      if (stride == 2) {
+        if ((ty | tx) & 1) return zero;
+        sy = ty >> 1; sx = tx >> 1;
+      } else {
+        sy = ty / stride; sx = tx / stride;
+        if (sy * stride != ty || sx * stride != tx) return zero;
+      }
     }
-    if (sy < 0 || sy >= Hs || sx < 0 || sx >= Ws) return z;
-    return *(const uint4*)(c.img + ((int64_t)(sy * Ws + sx) * C + ch));
+    if (sy < 0 || sy >= Hs || sx < 0 || sx >= Ws) return zero;
+    return (const void*)(c.img + ((int64_t)(sy * Ws + sx) * C + q.ch));
   }
 };
 
@@ -87,10 +122,14 @@ template <typename T> struct ConvLoader {
 enum TnMode { TN_PLAIN = 0, TN_CONVW = 1 };
 struct TnEpi {
   int mode = TN_PLAIN;
-  float* out = nullptr;     // fp32, atomically accumulated
+  float* out = nullptr;     // fp32, accumulated (out += result)
   int64_t ldo = 0;
   float alpha = 1.0f;
   int Cin = 0, Cpad = 0, KHW = 0;   // TN_CONVW: j = tap*Cpad + ci -> out[(i*Cin + ci)*KHW + tap]
+  // split-reduction scratch: when the reduction is split over several workgroups each writes a dense fp32
+  // [I][J] partial slab here and a second kernel folds the slabs into `out` (no atomics).  nullptr -> atomics.
+  float* slab = nullptr;
+  int64_t slab_elems = 0;
 };
 
 // C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)

@@ -1,18 +1,20 @@
 // MFMA GEMM kernels for gfx950 (CDNA4):
 //   gemm_nt : C[M,N]  = A[M,K] . B[N,K]^T, fused epilogues   (Linear fwd, dgrad on W^T shadows,
 //             classifier, GRU recurrent step, implicit-im2col conv fwd / dgrad)      K2 K4 K5 K6 K8 K12
-//   gemm_tn : C[I,J] += sum_p A[p,i] B[p,j], fp32 atomics, split over p             K14 weight grads
+//   gemm_tn : C[I,J] += sum_p A[p,i] B[p,j]  (weight gradients, K14)
 // One code path for both numerics modes: T = bf16 (v_mfma_f32_16x16x32_bf16, speed mode) and
 // T = float (v_mfma_f32_16x16x4_f32, exact-fp32 parity mode).
 //
-// Tile: 128x128 per 256-thread workgroup (4 waves, 2x2, 64x64 per wave = 4x4 MFMA tiles),
-// K-tile = one 128-byte LDS row per operand row (64 bf16 / 32 f32), double-buffered in LDS,
-// register-staged (global -> VGPR issued before the MFMA block, VGPR -> LDS after it, one
-// barrier per K-tile).  LDS rows are XOR-swizzled at 16-byte granularity so both the
-// ds_write_b128 staging stores and the ds_read_b128 operand reads are bank-conflict free.
-// Operands are passed to the MFMA swapped (B-fragment first) so each lane ends up with 4
-// CONSECUTIVE OUTPUT COLUMNS of one row: epilogue loads/stores are 8-16 B per lane.
+// Structure (both kernels): 256-thread workgroup = WA x WB waves of a 64x64 output each (4x4 MFMA
+// tiles per wave).  Operand tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR round
+// trip, no ds_write pass); the LDS image of one wave-instruction is lane-linear (1 KiB), so the XOR
+// swizzle that makes the operand reads bank-conflict free is applied to the per-lane SOURCE address,
+// and out-of-range chunks (row / K tails, conv zero padding) read a 16-byte zero page.  Two LDS
+// stages, one barrier per K-tile: the loads of tile t+1 are in flight while tile t is multiplied.
+// Operands are passed to the MFMA swapped (B-fragment first) so each lane ends up with 4 CONSECUTIVE
+// OUTPUT COLUMNS of one row: epilogue loads/stores are 8-16 B per lane.
 #include "gemm.h"
+#include "prof.h"
 
 namespace rl {
 
@@ -20,8 +22,12 @@ template <typename T> struct Geo;
 template <> struct Geo<bf16_t> { static constexpr int BK = 64, VEC = 8, KSTEPS = 2; };
 template <> struct Geo<float> { static constexpr int BK = 32, VEC = 4, KSTEPS = 8; };
 
-static constexpr int BM = 128, BN = 128;
-static constexpr int TILE_BYTES = 128 * 128;
+__device__ uint4 g_zero16[4];
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 template <typename T>
 __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, int row, int col, floatx4 v) {
@@ -47,14 +53,6 @@ __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, 
       v += load4<T>(ep.aux + (int64_t)row * ep.ldaux + col);
       store4<T>(ep.out + (int64_t)row * ep.ldo + col, v);
     } break;
-    case EPI_QKV: {
-      const int H = ep.nh * 64;
-      const int which = col / H, rem = col - which * H;
-      const int head = rem >> 6, d = rem & 63;
-      const int b = row / ep.S, s = row - b * ep.S;
-      T* o = ep.out + (int64_t)which * ep.qkv_plane + ((int64_t)(b * ep.nh + head) * ep.S + s) * 64 + d;
-      store4<T>(o, v);
-    } break;
     case EPI_GELU_BWD: {
       const floatx4 x = load4<T>(ep.aux + (int64_t)row * ep.ldaux + col);
 #pragma unroll
@@ -67,28 +65,37 @@ __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, 
   }
 }
 
-template <typename T, typename ALoader>
+// =================================================================================================
+// NT.  WM x WN waves: (2,2) -> 128x128 tile; (4,1) -> 256x64 tile for the 64-channel glyph convs.
+// K-tile = one 128-byte LDS row per operand row (64 bf16 / 32 f32), chunk c of row r stored at chunk
+// (c ^ (r & 7)) (KTile): conflict-free ds_read_b128 operand reads.
+// =================================================================================================
+template <typename T, typename ALoader, int WM, int WN>
 __global__ void __launch_bounds__(256, 2)
 gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, int ntiles, EpiParams<T> ep) {
   typedef typename MmaOf<T>::type Mma;
   typedef Geo<T> G;
-  typedef KTile<T, G::BK> LT;
+  constexpr int BM_ = 64 * WM, BN_ = 64 * WN;
+  constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = BM_ / 32, NB = BN_ / 32;        // 1-KiB wave-instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave - wm * WN;
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int sc = tid & 7, sr = tid >> 3;      // staging: 8 x 16-byte chunks per row, 32 rows per pass
+  const int m0 = tm * BM_, n0 = tn * BN_;
+  const void* zero = (const void*)g_zero16;
+  const int lrow = lane >> 3;                        // row inside the 8-row group written by one instruction
+  const int kchunk = ((lane & 7) ^ lrow) * G::VEC;   // logical K offset of the chunk this lane fetches
 
-  typename ALoader::Ctx actx[4];
-  typename DenseLoader<T>::Ctx bctx[4];
+  typename ALoader::Ctx actx[NA];
+  typename DenseLoader<T>::Ctx bctx[NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    actx[i] = la.prepare(m0 + sr + 32 * i);
-    bctx[i] = lb.prepare(n0 + sr + 32 * i);
-  }
-  uint4 ar[4], br[4];
+  for (int j = 0; j < NA; ++j) actx[j] = la.prepare(m0 + (wave * NA + j) * 8 + lrow);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) bctx[j] = lb.prepare(n0 + (wave * NB + j) * 8 + lrow);
+  typename ALoader::KPos aq = la.kpos(kchunk);
+  typename DenseLoader<T>::KPos bq = lb.kpos(kchunk);
   const int nk = (K + G::BK - 1) / G::BK;
 
   floatx4 acc[4][4];
@@ -97,28 +104,24 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  {
-    const int k = sc * G::VEC;
+  auto issue = [&](int stage) {                      // fetch the K-tile (aq, bq) point at, then advance them
+    char* base = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ar[i] = la.load(actx[i], k); br[i] = lb.load(bctx[i], k); }
+    for (int j = 0; j < NA; ++j) glds16(la.addr(actx[j], aq, zero), base + (wave * NA + j) * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(uint4*)(smem + LT::off(sr + 32 * i, sc)) = ar[i];
-      *(uint4*)(smem + TILE_BYTES + LT::off(sr + 32 * i, sc)) = br[i];
-    }
-  }
-  __syncthreads();
+    for (int j = 0; j < NB; ++j) glds16(lb.addr(bctx[j], bq, zero), base + A_BYTES + (wave * NB + j) * 1024);
+    la.advance(aq, G::BK);
+    lb.advance(bq, G::BK);
+  };
 
+  issue(0);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk);
-    if (more) {
-      const int k = (kt + 1) * G::BK + sc * G::VEC;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { ar[i] = la.load(actx[i], k); br[i] = lb.load(bctx[i], k); }
-    }
-    const char* As = smem + cur * 2 * TILE_BYTES;
-    const char* Bs = As + TILE_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // tile kt landed for every wave; stage cur^1 is free
+    if (kt + 1 < nk) issue(cur ^ 1);
+    const char* As = smem + cur * STAGE;
+    const char* Bs = As + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       typename Mma::Frag a[4], b[4];
@@ -132,18 +135,8 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = Mma::mma(b[j], a[i], acc[i][j]);
     }
-    if (more) {
-      char* An = smem + (cur ^ 1) * 2 * TILE_BYTES;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *(uint4*)(An + LT::off(sr + 32 * i, sc)) = ar[i];
-        *(uint4*)(An + TILE_BYTES + LT::off(sr + 32 * i, sc)) = br[i];
-      }
-    }
-    __syncthreads();
     cur ^= 1;
   }
-
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -151,35 +144,43 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
       epilogue4<T>(ep, M, N, m0 + wm * 64 + i * 16 + l15, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j]);
 }
 
-template <typename T, typename ALoader>
-static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb, int M, int N, int K,
-                     const EpiParams<T>& ep) {
-  if (M <= 0 || N <= 0 || K <= 0) return RL_OK;
-  if ((N & 3) || (K % Geo<T>::VEC) || (ldb % Geo<T>::VEC)) return RL_ERR_ARG;
-  DenseLoader<T> lb{B, ldb, N, K};
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+template <typename T, typename ALoader, int WM, int WN>
+static int launch_nt_tile(hipStream_t st, const ALoader& la, const DenseLoader<T>& lb, int M, int N, int K, const EpiParams<T>& ep) {
+  constexpr int BM_ = 64 * WM, BN_ = 64 * WN;
+  const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_;
   const int ntiles = tiles_m * tiles_n;
-  const size_t lds = 4 * TILE_BYTES;
+  const size_t lds = 2 * (size_t)(BM_ + BN_) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, ALoader>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, ALoader, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<T, ALoader>), dim3(ntiles), dim3(256), lds, st, la, lb, M, N, K, tiles_n, ntiles, ep);
+  ProfScope ps(st, sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos) ? PK_GEMM_NT : PK_CONV_NT, 2.0 * M * N * K);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, ALoader, WM, WN>), dim3(ntiles), dim3(256), lds, st, la, lb, M, N, K, tiles_n, ntiles, ep);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
+template <typename T, typename ALoader>
+static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep) {
+  if (M <= 0 || N <= 0 || K <= 0) return RL_OK;
+  if ((N & 3) || (K % Geo<T>::VEC) || (ldb % Geo<T>::VEC)) return RL_ERR_ARG;
+  DenseLoader<T> lb{B, ldb, N, K};
+  if (N <= 64) return launch_nt_tile<T, ALoader, 4, 1>(st, la, lb, M, N, K, ep);
+  return launch_nt_tile<T, ALoader, 2, 2>(st, la, lb, M, N, K, ep);
+}
+
 template <typename T>
-int gemm_nt(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K,
-            const EpiParams<T>& ep) {
+int gemm_nt(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep) {
   if (lda % Geo<T>::VEC) return RL_ERR_ARG;
   DenseLoader<T> la{A, lda, M, K};
   return launch_nt<T, DenseLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }
 template <typename T>
-int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la, const T* B, int64_t ldb, int M, int N, int K,
-                 const EpiParams<T>& ep) {
-  if (la.C % Geo<T>::VEC) return RL_ERR_ARG;
+int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la_, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep) {
+  if (la_.C % Geo<T>::VEC) return RL_ERR_ARG;
+  ConvLoader<T> la = la_;
+  la.finalize();
+  if (la.K != K) return RL_ERR_ARG;
   return launch_nt<T, ConvLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }
 template int gemm_nt<bf16_t>(hipStream_t, const bf16_t*, int64_t, const bf16_t*, int64_t, int, int, int, const EpiParams<bf16_t>&);
@@ -190,28 +191,36 @@ template int gemm_nt_conv<float>(hipStream_t, const ConvLoader<float>&, const fl
 // =================================================================================================
 // TN: C[I,J] += sum_p A[p,i] * B[p,j].  Operand tiles are staged in their natural layout
 // ([p][feature], feature contiguous) and transposed on the LDS read: ds_read_b64_tr_b16 for bf16
-// (TR = true), 16-bit gathers otherwise; a single ds_read_b32 per operand for the fp32 atom.
+// (TR = true; 16-bit gathers otherwise), one ds_read_b32 per operand for the fp32 atom.  The
+// reduction dimension is split over workgroups to fill the chip; partial results go to dense fp32
+// slabs that a second kernel folds into the gradient (no atomics; a single split accumulates in
+// place).  WI x WJ waves: (2,2) -> 128x128 outputs; (1,4) -> 64x256 for the 64-channel glyph convs.
 // =================================================================================================
 template <typename T> struct TnGeo;
-template <> struct TnGeo<bf16_t> { static constexpr int BP = 32, ROWB = 256, CPR = 16, RPP = 16, PASSES = 2, VEC = 8, KSTEPS = 1; };
-template <> struct TnGeo<float> { static constexpr int BP = 32, ROWB = 512, CPR = 32, RPP = 8, PASSES = 4, VEC = 4, KSTEPS = 8; };
+template <> struct TnGeo<bf16_t> { static constexpr int BP = 64, KSTEPS = 2, VEC = 8; };
+template <> struct TnGeo<float> { static constexpr int BP = 32, KSTEPS = 8, VEC = 4; };
 
-template <typename T> __device__ __forceinline__ int tn_swz(int p);
-template <> __device__ __forceinline__ int tn_swz<bf16_t>(int p) { return ((p >> 3) & 3) << 5; }
-template <> __device__ __forceinline__ int tn_swz<float>(int p) { return (p & 1) << 6; }
+// Byte XOR applied to the column offset of reduction row p (keeps 16-byte chunks intact).  bf16: one
+// ds_read_b64_tr_b16 half-wave touches rows {p0..p0+3} and {p0+8..p0+11} at the same 32-byte column block;
+// the XOR spreads those 8 rows over 8 distinct 32-byte slots of the 256-byte bank row (4 slots when the
+// tile row is only 128 bytes).  fp32: lanes 0-31 read rows p, p+1 -> two 64-byte halves.
+template <typename T, int RP> __device__ __forceinline__ int tn_swz(int p) {
+  if constexpr (sizeof(T) == 2) return (((p & 3) | (((p >> 3) & 1) << 2)) << 5) & (RP - 1);
+  else return ((p & 1) << 6) & (RP - 1);
+}
 
-template <bool TR>
-__device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int col0, int l15, int g) {
+template <bool TR, int RP>
+__device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int ks, int col0, int l15, int g) {
   if constexpr (TR) {
-    // 16-lane group g reads the [4 p][16 col] block rows 8g+4h .. +3; lane q of the group points at
+    // 16-lane group g reads the [4 p][16 col] blocks at rows 8g+4h .. +3; lane q of the group points at
     // row (q >> 2), columns 4*(q & 3) .. +3 and receives column q, 4 consecutive p.
     typedef short4_t __attribute__((address_space(3))) * lds_s4;
     short4_t h[2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      const int p = 8 * g + 4 * hh + (l15 >> 2);
-      const int colb = ((col0 + 4 * (l15 & 3)) * 2) ^ tn_swz<bf16_t>(p);
-      h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + p * 256 + colb));
+      const int p = ks * 32 + 8 * g + 4 * hh + (l15 >> 2);
+      const int colb = ((col0 + 4 * (l15 & 3)) * 2) ^ tn_swz<bf16_t, RP>(p);
+      h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + p * RP + colb));
     }
     typedef __attribute__((ext_vector_type(8))) short short8_t;
     short8_t r = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
@@ -221,49 +230,82 @@ __device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int col0, int
     ushort8_t r;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int p = 8 * g + e;
-      r[e] = *(const unsigned short*)(tile + p * 256 + (((col0 + l15) * 2) ^ tn_swz<bf16_t>(p)));
+      const int p = ks * 32 + 8 * g + e;
+      r[e] = *(const unsigned short*)(tile + p * RP + (((col0 + l15) * 2) ^ tn_swz<bf16_t, RP>(p)));
     }
     return __builtin_bit_cast(bf16x8_t, r);
   }
 }
 
-__device__ __forceinline__ void tn_epilogue4(const TnEpi& ep, int I, int J, int i, int j, floatx4 v) {
-  if (i >= I) return;
+enum TnOut { TN_OUT_DIRECT = 0, TN_OUT_SLAB = 1, TN_OUT_ATOMIC = 2 };
+
+__device__ __forceinline__ int64_t tn_out_index(const TnEpi& ep, int i, int j) {   // -1: padding column
+  if (ep.mode == TN_PLAIN) return (int64_t)i * ep.ldo + j;
+  const int tap = j / ep.Cpad, ci = j - tap * ep.Cpad;
+  return ci < ep.Cin ? ((int64_t)i * ep.Cin + ci) * ep.KHW + tap : -1;
+}
+
+__device__ __forceinline__ void tn_epilogue4(const TnEpi& ep, int how, int split, int I, int J, int i, int j, floatx4 v) {
+  if (i >= I || j >= J) return;
+  if (how == TN_OUT_SLAB) {                       // dense [split][I][J]; J % 4 == 0
+    *(floatx4*)(ep.slab + ((int64_t)split * I + i) * J + j) = v;
+    return;
+  }
+  v *= ep.alpha;
+  if (how == TN_OUT_DIRECT && ep.mode == TN_PLAIN && (ep.ldo & 3) == 0) {
+    floatx4* o = (floatx4*)(ep.out + (int64_t)i * ep.ldo + j);
+    *o = *o + v;
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int jj = j + r;
-    if (jj >= J) continue;
-    const float x = v[r] * ep.alpha;
-    if (ep.mode == TN_PLAIN) {
-      atomicAdd(ep.out + (int64_t)i * ep.ldo + jj, x);
-    } else {
-      const int tap = jj / ep.Cpad, ci = jj - tap * ep.Cpad;
-      if (ci < ep.Cin) atomicAdd(ep.out + ((int64_t)i * ep.Cin + ci) * ep.KHW + tap, x);
-    }
+    const int64_t idx = tn_out_index(ep, i, j + r);
+    if (idx < 0) continue;
+    if (how == TN_OUT_DIRECT) ep.out[idx] += v[r];
+    else atomicAdd(ep.out + idx, v[r]);
   }
 }
 
-template <typename T, typename BLoader, bool TR>
+template <typename T, typename BLoader, bool TR, int WI, int WJ>
 __global__ void __launch_bounds__(256, 2)
 gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, int J, int tiles_j, int ntiles,
-               int pchunk, TnEpi ep) {
+               int pchunk, int how, TnEpi ep) {
   typedef typename MmaOf<T>::type Mma;
   typedef TnGeo<T> G;
-  constexpr int TILEB = G::BP * G::ROWB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A tile, B tile)
+  constexpr int BI = 64 * WI, BJ = 64 * WJ;
+  constexpr int RPA = BI * (int)sizeof(T), RPB = BJ * (int)sizeof(T);         // row pitches (bytes)
+  constexpr int A_BYTES = G::BP * RPA, B_BYTES = G::BP * RPB, STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = A_BYTES / 4096, NB = B_BYTES / 4096;                     // 1-KiB instructions per wave per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  const int wi = wave >> 1, wj = wave & 1;
+  const int wi = wave / WJ, wj = wave - wi * WJ;
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
-  const int i0 = ti * 128, j0 = tj * 128;
+  const int i0 = ti * BI, j0 = tj * BJ;
   const int p_begin = blockIdx.y * pchunk;
   const int p_end = min(P, p_begin + pchunk);
-  if (p_begin >= p_end) return;
-  const int sc = tid % G::CPR, sr = tid / G::CPR;
-  const int acol = i0 + sc * G::VEC, bcol = j0 + sc * G::VEC;
-  const bool a_ok = acol < I;
-  uint4 ar[G::PASSES], br[G::PASSES];
+  const void* zero = (const void*)g_zero16;
+
+  // per-lane chunk coordinates are the same for every reduction tile: only the row base moves
+  int apl[NA], bpl[NB];
+  const T* acol[NA];
+  typename BLoader::KPos bq[NB];
+  bool bok[NB];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    const int off = (wave * NA + q) * 1024 + lane * 16;
+    apl[q] = off / RPA;
+    const int col = i0 + ((off % RPA) ^ tn_swz<T, RPA>(apl[q])) / (int)sizeof(T);
+    acol[q] = col < I ? A + col : nullptr;
+  }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    const int off = (wave * NB + q) * 1024 + lane * 16;
+    bpl[q] = off / RPB;
+    const int col = j0 + ((off % RPB) ^ tn_swz<T, RPB>(bpl[q])) / (int)sizeof(T);
+    bok[q] = col < J;
+    bq[q] = lb.kpos(bok[q] ? col : 0);
+  }
 
   floatx4 acc[4][4];
 #pragma unroll
@@ -271,41 +313,34 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  auto gload = [&](int pt) {
+  auto issue = [&](int pt, int stage) {
+    char* base = smem + stage * STAGE;
 #pragma unroll
-    for (int s = 0; s < G::PASSES; ++s) {
-      const int p = pt + sr + s * G::RPP;
-      const bool ok = p < p_end;
-      ar[s] = (ok && a_ok) ? *(const uint4*)(A + (int64_t)p * lda + acol) : make_uint4(0, 0, 0, 0);
-      if (ok && bcol < J) {
-        typename BLoader::Ctx c = lb.prepare(p);
-        br[s] = lb.load(c, bcol);
-      } else {
-        br[s] = make_uint4(0, 0, 0, 0);
-      }
+    for (int q = 0; q < NA; ++q) {
+      const int p = pt + apl[q];
+      const void* src = (p < p_end && acol[q] != nullptr) ? (const void*)(acol[q] + (int64_t)p * lda) : zero;
+      glds16(src, base + (wave * NA + q) * 1024);
     }
-  };
-  auto sstore = [&](int stage) {
-    char* At = smem + stage * 2 * TILEB;
-    char* Bt = At + TILEB;
 #pragma unroll
-    for (int s = 0; s < G::PASSES; ++s) {
-      const int pl = sr + s * G::RPP;
-      const int off = pl * G::ROWB + ((sc * 16) ^ tn_swz<T>(pl));
-      *(uint4*)(At + off) = ar[s];
-      *(uint4*)(Bt + off) = br[s];
+    for (int q = 0; q < NB; ++q) {
+      const int p = pt + bpl[q];
+      const void* src = zero;
+      if (p < p_end && bok[q]) {
+        const typename BLoader::Ctx c = lb.prepare(p);
+        src = lb.addr(c, bq[q], zero);
+      }
+      glds16(src, base + A_BYTES + (wave * NB + q) * 1024);
     }
   };
 
-  gload(p_begin);
-  sstore(0);
-  __syncthreads();
+  if (p_begin < p_end) issue(p_begin, 0);
   int cur = 0;
   for (int pt = p_begin; pt < p_end; pt += G::BP) {
-    const bool more = pt + G::BP < p_end;
-    if (more) gload(pt + G::BP);
-    const char* At = smem + cur * 2 * TILEB;
-    const char* Bt = At + TILEB;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pt + G::BP < p_end) issue(pt + G::BP, cur ^ 1);
+    const char* At = smem + cur * STAGE;
+    const char* Bt = At + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       typename Mma::Frag a[4], b[4];
@@ -313,12 +348,12 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
       for (int f = 0; f < 4; ++f) {
         const int ca = wi * 64 + f * 16, cb = wj * 64 + f * 16;
         if constexpr (sizeof(T) == 2) {
-          a[f] = tn_frag_bf16<TR>(At, ca, l15, g);
-          b[f] = tn_frag_bf16<TR>(Bt, cb, l15, g);
+          a[f] = tn_frag_bf16<TR, RPA>(At, ks, ca, l15, g);
+          b[f] = tn_frag_bf16<TR, RPB>(Bt, ks, cb, l15, g);
         } else {
           const int p = ks * 4 + g;
-          a[f] = *(const float*)(At + p * G::ROWB + (((ca + l15) * 4) ^ tn_swz<float>(p)));
-          b[f] = *(const float*)(Bt + p * G::ROWB + (((cb + l15) * 4) ^ tn_swz<float>(p)));
+          a[f] = *(const float*)(At + p * RPA + (((ca + l15) * 4) ^ tn_swz<float, RPA>(p)));
+          b[f] = *(const float*)(Bt + p * RPB + (((cb + l15) * 4) ^ tn_swz<float, RPB>(p)));
         }
       }
 #pragma unroll
@@ -326,42 +361,87 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = Mma::mma(b[j], a[i], acc[i][j]);
     }
-    if (more) sstore(cur ^ 1);
-    __syncthreads();
     cur ^= 1;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      tn_epilogue4(ep, I, J, i0 + wi * 64 + i * 16 + l15, j0 + wj * 64 + j * 16 + 4 * g, acc[i][j]);
+      tn_epilogue4(ep, how, blockIdx.y, I, J, i0 + wi * 64 + i * 16 + l15, j0 + wj * 64 + j * 16 + 4 * g, acc[i][j]);
+}
+
+// out(mapped) += alpha * sum_s slab[s][i][j]
+__global__ void __launch_bounds__(256) tn_fold_kernel(TnEpi ep, int nsplit, int I, int J) {
+  const int64_t n4 = (int64_t)I * J / 4;
+  const int64_t plane = (int64_t)I * J;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    floatx4 s = *(const floatx4*)(ep.slab + e * 4);
+    for (int k = 1; k < nsplit; ++k) s += *(const floatx4*)(ep.slab + k * plane + e * 4);
+    s *= ep.alpha;
+    const int i = (int)((e * 4) / J), j = (int)((e * 4) - (int64_t)i * J);
+    if (ep.mode == TN_PLAIN && (ep.ldo & 3) == 0) {
+      floatx4* o = (floatx4*)(ep.out + (int64_t)i * ep.ldo + j);
+      *o = *o + s;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t idx = tn_out_index(ep, i, j + r);
+        if (idx >= 0) ep.out[idx] += s[r];
+      }
+    }
+  }
 }
 
 static int g_tn_tr = 1;   // ds_read_b64_tr_b16 verified on MI355X (tests/test_kernels_gpu.py::test_gemm_tn)
 void set_tn_transpose_read(int use_tr) { g_tn_tr = use_tr; }
+
+template <typename T, typename BLoader, int WI, int WJ>
+static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader& lb, int P, int I, int J, const TnEpi& ep) {
+  typedef TnGeo<T> G;
+  constexpr int BI = 64 * WI, BJ = 64 * WJ;
+  const int tiles_i = (I + BI - 1) / BI, tiles_j = (J + BJ - 1) / BJ, ntiles = tiles_i * tiles_j;
+  int nsplit = (512 + ntiles - 1) / ntiles;                 // ~2 workgroups per CU
+  const int max_split = (P + 4 * G::BP - 1) / (4 * G::BP);
+  if (nsplit > max_split) nsplit = max_split;
+  if (ep.slab != nullptr) {
+    const int64_t cap = ep.slab_elems / ((int64_t)I * J);
+    if (nsplit > cap) nsplit = (int)cap;
+  }
+  if (nsplit < 1) nsplit = 1;
+  int pchunk = (P + nsplit - 1) / nsplit;
+  pchunk = ((pchunk + G::BP - 1) / G::BP) * G::BP;
+  nsplit = (P + pchunk - 1) / pchunk;
+  const int how = nsplit == 1 ? TN_OUT_DIRECT : (ep.slab != nullptr ? TN_OUT_SLAB : TN_OUT_ATOMIC);
+  const size_t lds = 2 * (size_t)G::BP * (BI + BJ) * sizeof(T);
+  dim3 grid(ntiles, nsplit);
+  {
+    ProfScope ps(st, sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos) ? PK_GEMM_TN : PK_CONV_TN, 2.0 * P * I * J);
+    if (sizeof(T) == 2 && g_tn_tr) {
+      static bool a1 = false;
+      if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, true, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
+      hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, true, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, pchunk, how, ep);
+    } else {
+      static bool a2 = false;
+      if (!a2) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, false, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
+      hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, false, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, pchunk, how, ep);
+    }
+    if (how == TN_OUT_SLAB) {
+      const int64_t n4 = (int64_t)I * J / 4;
+      int blocks = (int)((n4 + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(tn_fold_kernel, dim3(blocks), dim3(256), 0, st, ep, nsplit, I, J);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+}
 
 template <typename T, typename BLoader>
 static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb, int P, int I, int J, const TnEpi& ep) {
   if (P <= 0 || I <= 0 || J <= 0) return RL_OK;
   typedef TnGeo<T> G;
   if ((lda % G::VEC) || (I % G::VEC) || (J % G::VEC)) return RL_ERR_ARG;
-  const int tiles_i = (I + 127) / 128, tiles_j = (J + 127) / 128, ntiles = tiles_i * tiles_j;
-  // split the reduction so the grid fills the chip (~4 workgroups per CU), chunks multiple of BP
-  int nsplit = (1024 + ntiles - 1) / ntiles;
-  const int max_split = (P + 4 * G::BP - 1) / (4 * G::BP);
-  if (nsplit > max_split) nsplit = max_split;
-  if (nsplit < 1) nsplit = 1;
-  int pchunk = (P + nsplit - 1) / nsplit;
-  pchunk = ((pchunk + G::BP - 1) / G::BP) * G::BP;
-  nsplit = (P + pchunk - 1) / pchunk;
-  const size_t lds = 4 * (size_t)G::BP * G::ROWB;
-  dim3 grid(ntiles, nsplit);
-  if (sizeof(T) == 2 && g_tn_tr) {
-    hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, true>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, pchunk, ep);
-  } else {
-    hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, false>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, pchunk, ep);
-  }
-  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+  if (I <= 64) return launch_tn_tile<T, BLoader, 1, 4>(st, A, lda, lb, P, I, J, ep);
+  return launch_tn_tile<T, BLoader, 2, 2>(st, A, lda, lb, P, I, J, ep);
 }
 
 template <typename T>
@@ -371,8 +451,11 @@ int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, in
   return launch_tn<T, DenseLoader<T>>(st, A, lda, lb, P, I, J, ep);
 }
 template <typename T>
-int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& lb, int P, int I, int J, const TnEpi& ep) {
-  if (lb.C % TnGeo<T>::VEC) return RL_ERR_ARG;
+int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& lb_, int P, int I, int J, const TnEpi& ep) {
+  if (lb_.C % TnGeo<T>::VEC) return RL_ERR_ARG;
+  ConvLoader<T> lb = lb_;
+  lb.finalize();
+  if (lb.K != J) return RL_ERR_ARG;
   return launch_tn<T, ConvLoader<T>>(st, A, lda, lb, P, I, J, ep);
 }
 template int gemm_tn<bf16_t>(hipStream_t, const bf16_t*, int64_t, const bf16_t*, int64_t, int, int, int, const TnEpi&);

@@ -145,17 +145,18 @@ gru_table_bwd_w_kernel(const float* __restrict__ dt, int ldt, const float* __res
 }
 __global__ void __launch_bounds__(256)
 gru_table_bwd_e_kernel(const float* __restrict__ dt, int ldt, const float* __restrict__ w_ih, int V, int H, float* d_emb) {
-  const int v = blockIdx.y;                                              // grid (H/256, V)
+  const int v = blockIdx.y;                                              // grid (H/256, V, 3H/128)
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= H || v == 0) return;                                          // padding_idx = 0 row gets no gradient
   float s = 0.f;
-  for (int j = 0; j < 3 * H; ++j) s += dt[(int64_t)v * ldt + j] * w_ih[(int64_t)j * H + k];
+  const int j0 = blockIdx.z * 128, j1 = min(3 * H, j0 + 128);
+  for (int j = j0; j < j1; ++j) s += dt[(int64_t)v * ldt + j] * w_ih[(int64_t)j * H + k];
   atomicAdd(d_emb + (int64_t)v * H + k, s);
 }
 int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const float* emb, const float* w_ih, int V, int H,
                   float* d_emb, float* d_w_ih, float* d_b_ih) {
   hipLaunchKernelGGL(gru_table_bwd_w_kernel, dim3(3 * H), dim3(256), 0, st, dtable, ld_dtable, emb, V, H, d_w_ih, d_b_ih);
-  hipLaunchKernelGGL(gru_table_bwd_e_kernel, dim3((H + 255) / 256, V), dim3(256), 0, st, dtable, ld_dtable, w_ih, V, H, d_emb);
+  hipLaunchKernelGGL(gru_table_bwd_e_kernel, dim3((H + 255) / 256, V, (3 * H + 127) / 128), dim3(256), 0, st, dtable, ld_dtable, w_ih, V, H, d_emb);
   return RL_LAUNCH_CHECK();
 }
 

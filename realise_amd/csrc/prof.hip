@@ -1,0 +1,58 @@
+#include "prof.h"
+#include <vector>
+
+namespace rl {
+namespace {
+struct Rec { int kid; double work; size_t e0; };
+bool g_on = false;
+std::vector<hipEvent_t> g_ev;
+std::vector<Rec> g_recs;
+size_t g_used = 0;
+bool g_open = false;
+}  // namespace
+
+int prof_enable(int max_launches) {
+  prof_disable();
+  g_ev.resize((size_t)max_launches * 2);
+  for (auto& e : g_ev)
+    if (hipEventCreate(&e) != hipSuccess) return 2;
+  g_recs.clear();
+  g_recs.reserve(max_launches);
+  g_used = 0;
+  g_on = true;
+  return 0;
+}
+void prof_disable() {
+  for (auto& e : g_ev) (void)hipEventDestroy(e);
+  g_ev.clear();
+  g_recs.clear();
+  g_used = 0;
+  g_on = false;
+  g_open = false;
+}
+void prof_begin(hipStream_t st, int kid, double work) {
+  g_open = false;
+  if (!g_on || g_used + 2 > g_ev.size()) return;
+  (void)hipEventRecord(g_ev[g_used], st);
+  g_recs.push_back({kid, work, g_used});
+  g_open = true;
+}
+void prof_end(hipStream_t st) {
+  if (!g_open) return;
+  (void)hipEventRecord(g_ev[g_used + 1], st);
+  g_used += 2;
+  g_open = false;
+}
+int prof_read(int kid, long long* count, double* total_ms, double* total_work) {
+  *count = 0; *total_ms = 0.0; *total_work = 0.0;
+  if (!g_on) return 1;
+  if (g_used >= 2) (void)hipEventSynchronize(g_ev[g_used - 1]);
+  for (const Rec& r : g_recs) {
+    if (r.kid != kid || r.e0 + 2 > g_used) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_ev[r.e0], g_ev[r.e0 + 1]) != hipSuccess) continue;
+    *count += 1; *total_ms += ms; *total_work += r.work;
+  }
+  return 0;
+}
+}  // namespace rl

@@ -148,6 +148,7 @@ class RealiseModule(nn.Module):
         self._ws = None
         self._ws_key = None
         self._shadow_version = None
+        self._frozen_version = None
 
     def __del__(self):
         try:
@@ -201,6 +202,7 @@ class RealiseModule(nn.Module):
         if strict and (missing or unexpected):
             raise RuntimeError("load_state_dict: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
         self._shadow_version = None
+        self._frozen_version = None
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     @classmethod
@@ -225,6 +227,7 @@ class RealiseModule(nn.Module):
         with torch.no_grad():
             self.char_images_multifonts.copy_(torch.as_tensor(table, dtype=torch.float32))
         self._shadow_version = None
+        self._frozen_version = None
 
     @staticmethod
     def build_batch(batch, tokenizer=None):
@@ -261,6 +264,7 @@ class RealiseModule(nn.Module):
             nbytes = lib.realise_engine_shadow_bytes(self._engine)
             self._shadow = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws = None
+            self._frozen_version = None
         key = (B, S, Tp)
         need = lib.realise_engine_workspace_bytes(self._engine, B, S, Tp)
         if self._ws is None or self._ws.numel() < need:
@@ -272,6 +276,9 @@ class RealiseModule(nn.Module):
         # write through `.data`, which torch's version counter does not see); in eval only when a tracked change
         # happened (load_state_dict, in-place ops on parameters).
         ver = (self._arenas[0]._version, self._arenas[2]._version)
+        if getattr(self, "_frozen_version", None) != ver[1]:
+            lib.realise_engine_invalidate_frozen(self._engine)
+            self._frozen_version = ver[1]
         if self.training or self._shadow_version != ver:
             _capi.check(lib.realise_engine_refresh_shadows(self._engine, self._stream()), "realise_engine_refresh_shadows")
             self._shadow_version = ver

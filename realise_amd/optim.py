@@ -1,0 +1,90 @@
+"""Fused AdamW + linear warm-up schedule over the module's flat arenas.
+
+Mirrors ``transformers/optimization.py:87-169`` (decoupled weight decay applied after the Adam
+update, optional bias correction) and ``clip_grad_norm_`` (src/run.py:207) as two kernels per
+step instead of ~4000 tiny ones: sum-of-squares of the gradient arena, then one AdamW sweep that
+applies the clip coefficient on the fly (no host synchronisation anywhere).
+"""
+import ctypes as C
+
+import torch
+
+from . import _capi
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """Drop-in for the reference's ``AdamW(optimizer_grouped_parameters, lr=, eps=)`` (run.py:146-153)
+    when the parameters belong to ONE RealiseModule.  Parameter groups keep their own lr /
+    weight_decay (the trainer's decay / no-decay split); groups whose hyper-parameters agree are
+    stepped with a single launch over the whole arena."""
+
+    def __init__(self, module, params=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True,
+                 max_grad_norm=None):
+        self.module = getattr(module, "module", module)
+        if params is None:
+            params = [p for p in self.module.parameters() if p.requires_grad]
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)
+        super().__init__(params, defaults)
+        self.max_grad_norm = max_grad_norm
+        flat = self.module.flat_parameters()
+        self._m = torch.zeros_like(flat)
+        self._v = torch.zeros_like(flat)
+        self._norm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self._step = 0
+        self._ranges = None
+
+    def _param_ranges(self):
+        """(offset, numel) of every trainable parameter of each group inside the arena"""
+        if self._ranges is None:
+            by_id = {}
+            for name, (arena, off, shape, p) in self.module._views.items():
+                if arena == 0 and p is not None:
+                    by_id[id(p)] = (off, p.numel())
+            self._ranges = [[by_id[id(p)] for p in g["params"] if id(p) in by_id] for g in self.param_groups]
+        return self._ranges
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        lib = _capi.load()
+        mod = self.module
+        st = C.c_void_p(torch.cuda.current_stream(mod.device).cuda_stream)
+        self._step += 1
+        flat_p, flat_g = mod.flat_parameters(), mod.flat_gradients()
+        norm_ptr, max_norm = None, 0.0
+        if self.max_grad_norm is not None:
+            self._norm_sq.zero_()
+            _capi.check(lib.realise_sumsq(st, flat_g.data_ptr(), flat_g.numel(), self._norm_sq.data_ptr()), "realise_sumsq")
+            norm_ptr, max_norm = self._norm_sq.data_ptr(), float(self.max_grad_norm)
+        g0 = self.param_groups[0]
+        uniform = all(g["lr"] == g0["lr"] and g["weight_decay"] == g0["weight_decay"] and g["eps"] == g0["eps"]
+                      and g["betas"] == g0["betas"] for g in self.param_groups)
+        covered = sum(n for rng in self._param_ranges() for _, n in rng)
+        n_train = sum(p.numel() for name, (a, o, s, p) in mod._views.items() if a == 0 and p is not None and name != "classifier.weight")
+        if uniform and covered >= n_train:
+            _capi.check(lib.realise_adamw(st, flat_p.data_ptr(), flat_g.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                                          flat_p.numel(), g0["lr"], g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"],
+                                          self._step, 1 if g0["correct_bias"] else 0, norm_ptr, max_norm), "realise_adamw")
+        else:
+            for g, rng in zip(self.param_groups, self._param_ranges()):
+                for off, n in rng:
+                    _capi.check(lib.realise_adamw(st, flat_p.data_ptr() + 4 * off, flat_g.data_ptr() + 4 * off,
+                                                  self._m.data_ptr() + 4 * off, self._v.data_ptr() + 4 * off, n, g["lr"],
+                                                  g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._step,
+                                                  1 if g["correct_bias"] else 0, norm_ptr, max_norm), "realise_adamw")
+        mod.mark_parameters_updated()
+
+    def grad_norm(self):
+        """global L2 norm measured by the last step() (device tensor; reading it synchronises)"""
+        return self._norm_sq.sqrt()
+
+    def zero_grad(self, set_to_none=False):
+        self.module.zero_grad(set_to_none=False)
+
+
+def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, last_epoch=-1):
+    """transformers/optimization.py:45-54"""
+    def lr_lambda(current_step):
+        if current_step < num_warmup_steps:
+            return float(current_step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - current_step) / float(max(1, num_training_steps - num_warmup_steps)))
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda, last_epoch)
