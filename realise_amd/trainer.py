@@ -1,0 +1,94 @@
+"""Thin trainer reproducing the call sites of the reference's ``src/run.py`` around the hot path:
+``make_features`` (run.py:68-101), ``data_helper`` (run.py:104-123), the hot loop (run.py:184-211) and
+``evaluate`` (run.py:239-280, minus the string metric which needs SIGHAN data).  Everything between
+``model(batch)`` and ``optimizer.step()`` runs in librealise_hip.so.
+"""
+import random
+
+import torch
+
+from .ddp import DistributedDataParallel
+from .optim import FusedAdamW, get_linear_schedule_with_warmup
+
+
+def make_features(examples, max_seq_length):
+    """run.py:68-101: pad to max_seq_length; masks = 1 on [CLS] chars [SEP]; loss_masks = 1 on chars only."""
+    batch = {k: [] for k in ("id", "src", "tgt", "tokens_size", "lengths", "src_idx", "tgt_idx", "masks", "loss_masks")}
+    for e in examples:
+        n = len(e["src_idx"])
+        if n > max_seq_length:
+            raise ValueError("sequence longer than max_seq_length")
+        pad = max_seq_length - n
+        for k in ("id", "src", "tgt", "tokens_size", "lengths"):
+            batch[k].append(e.get(k))
+        batch["src_idx"].append(list(e["src_idx"]) + [0] * pad)
+        batch["tgt_idx"].append(list(e["tgt_idx"]) + [0] * pad)
+        batch["masks"].append([1] * n + [0] * pad)
+        batch["loss_masks"].append([0] + [1] * e["lengths"] + [0] * (max_seq_length - 1 - e["lengths"]))
+    for k in ("src_idx", "tgt_idx", "masks", "loss_masks"):
+        batch[k] = torch.tensor(batch[k], dtype=torch.long)
+    return batch
+
+
+def data_helper(items, batch_size, max_seq_length, build_batch, tokenizer=None, is_eval=False, seed=None):
+    """run.py:104-123: shuffle (train), then yield feature batches."""
+    items = list(items)
+    if not is_eval:
+        (random.Random(seed) if seed is not None else random).shuffle(items)
+    for i in range(0, len(items), batch_size):
+        yield build_batch(make_features(items[i:i + batch_size], max_seq_length), tokenizer)
+
+
+def shard(items, rank, world):
+    """run.py:130-137: rank r keeps items r, r+W, ... (tail dropped so every rank sees the same count)."""
+    n = len(items) // world * world
+    return items[rank:n:world]
+
+
+def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.0,
+          warmup_steps=0, max_grad_norm=1.0, device="cuda", distributed=False, build_batch=None, tokenizer=None,
+          log_every=0, seed=17):
+    """the hot loop of run.py:125-237 with the fused optimizer; returns the mean loss."""
+    build_batch = build_batch or type(model).build_batch
+    model.to(device)
+    wrapped = DistributedDataParallel(model) if distributed else model
+    no_decay = ["bias", "LayerNorm.weight"]
+    groups = [{"params": [p for n, p in model.named_parameters() if p.requires_grad and not any(nd in n for nd in no_decay)],
+               "weight_decay": weight_decay},
+              {"params": [p for n, p in model.named_parameters() if p.requires_grad and any(nd in n for nd in no_decay)],
+               "weight_decay": 0.0}]
+    opt = FusedAdamW(model, groups, lr=lr, eps=adam_epsilon, max_grad_norm=max_grad_norm)
+    steps_total = max(1, (len(items) + batch_size - 1) // batch_size * epochs)
+    sched = get_linear_schedule_with_warmup(opt, warmup_steps, steps_total)
+    tr_loss = torch.zeros((), device=device)
+    step = 0
+    model.zero_grad()
+    for ep in range(epochs):
+        for batch in data_helper(items, batch_size, max_seq_length, build_batch, tokenizer, seed=seed + ep):
+            model.train()
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    batch[k] = v.to(device)
+            loss = wrapped(batch)[0]
+            loss.backward()
+            tr_loss += loss.detach()
+            opt.step()
+            sched.step()
+            model.zero_grad()
+            step += 1
+            if log_every and step % log_every == 0:
+                print("Step: %d, LR: %.3e, Loss: %.5f" % (step, sched.get_last_lr()[0], tr_loss.item() / step))
+    return tr_loss.item() / max(1, step)
+
+
+@torch.no_grad()
+def evaluate(model, items, *, batch_size=64, max_seq_length=128, device="cuda", build_batch=None, tokenizer=None):
+    """run.py:239-280: mean eval loss and the arg-max ids (only ids leave the device)."""
+    build_batch = build_batch or type(model).build_batch
+    model.eval()
+    losses, preds = [], []
+    for batch in data_helper(items, batch_size, max_seq_length, build_batch, tokenizer, is_eval=True):
+        loss, logits = model(batch)[:2]
+        losses.append(loss.detach())
+        preds.append(logits.argmax(-1).cpu())
+    return torch.stack(losses).mean().item(), torch.cat(preds)

@@ -1,0 +1,64 @@
+"""Host-side logic around the path (CPU): feature padding / masks (run.py:68-101), sharding (run.py:130-137),
+the synthetic SIGHAN-shaped batch generator, and the deterministic weight generator."""
+import numpy as np
+import torch
+
+from realise_amd.config import RealiseConfig
+from realise_amd.data import synthetic_batch
+from realise_amd.init import init_state_dict_numpy, tensor_init
+from realise_amd.trainer import data_helper, make_features, shard
+
+
+def _item(i, n):
+    ids = [101] + list(range(700, 700 + n)) + [102]
+    return {"id": i, "src": "x" * n, "tgt": "x" * n, "tokens_size": [1] * n, "src_idx": ids, "tgt_idx": ids, "lengths": n}
+
+
+def test_make_features_masks_match_reference_layout():
+    b = make_features([_item(0, 3), _item(1, 5)], 10)
+    assert b["src_idx"].shape == (2, 10) and b["src_idx"].dtype == torch.long
+    assert b["masks"].tolist() == [[1] * 5 + [0] * 5, [1] * 7 + [0] * 3]
+    assert b["loss_masks"].tolist() == [[0, 1, 1, 1] + [0] * 6, [0, 1, 1, 1, 1, 1] + [0] * 4]     # chars only, run.py:86-92
+    assert b["lengths"] == [3, 5]
+
+
+def test_shard_and_data_helper():
+    items = [_item(i, 4) for i in range(11)]
+    s0, s1 = shard(items, 0, 2), shard(items, 1, 2)
+    assert [e["id"] for e in s0] == [0, 2, 4, 6, 8] and [e["id"] for e in s1] == [1, 3, 5, 7, 9]       # tail dropped
+    batches = list(data_helper(items, 4, 8, lambda b, t: b, is_eval=True))
+    assert [len(b["id"]) for b in batches] == [4, 4, 3]
+    a = [b["id"] for b in data_helper(items, 4, 8, lambda b, t: b, seed=3)]
+    c = [b["id"] for b in data_helper(items, 4, 8, lambda b, t: b, seed=3)]
+    assert a == c and sorted(sum(a, [])) == list(range(11))
+
+
+def test_synthetic_batch_is_sighan_shaped_and_deterministic():
+    b1, b2 = synthetic_batch(4, 32, seed=5), synthetic_batch(4, 32, seed=5)
+    for k in ("src_idx", "tgt_idx", "masks", "loss_masks", "pho_idx"):
+        assert torch.equal(b1[k], b2[k])
+    assert b1["pho_lens"] == b2["pho_lens"] and len(b1["pho_lens"]) == 4 * 32
+    src, m, lm = b1["src_idx"], b1["masks"], b1["loss_masks"]
+    assert (src[:, 0] == 101).all()
+    for r in range(4):
+        L = int(m[r].sum()) - 2
+        assert src[r, L + 1] == 102 and (src[r, L + 2:] == 0).all()
+        assert lm[r].tolist() == [0] + [1] * L + [0] * (32 - 1 - L)
+    lens = np.array(b1["pho_lens"]).reshape(4, 32)
+    assert ((lens >= 1) & (lens <= 7)).all()
+    assert (lens[m.numpy() == 0] == 1).all()                       # PAD -> 'U'
+    pho = b1["pho_idx"]
+    assert pho.shape[0] == 128 and pho.shape[1] == lens.max()
+    assert ((pho > 0).sum(1).numpy() == lens.reshape(-1)).all()    # zero padded past each length
+
+
+def test_weight_generator_is_reproducible_and_named():
+    cfg = RealiseConfig(num_hidden_layers=1)
+    a = tensor_init("bert.encoder.layer.0.output.dense.weight", (768, 3072), "normal", cfg, seed=1)
+    b = tensor_init("bert.encoder.layer.0.output.dense.weight", (768, 3072), "normal", cfg, seed=1)
+    c = tensor_init("bert.encoder.layer.0.intermediate.dense.weight", (768, 3072), "normal", cfg, seed=1)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert abs(a.std() - 0.02) < 1e-3                             # initializer_range, modeling_bert.py:496-506
+    sd = init_state_dict_numpy(cfg, "bert", seed=0)
+    assert sd["classifier.weight"] is sd["bert.embeddings.word_embeddings.weight"]
+    assert float(sd["bert.embeddings.LayerNorm.weight"].min()) == 1.0 and float(np.abs(sd["classifier.bias"]).max()) == 0.0
