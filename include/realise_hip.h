@@ -62,7 +62,8 @@ int realise_conv_nt(void* stream, int dtype, const realise_conv_geom* a, const v
  * over workgroups; `scratch` (fp32, scratch_elems >= I*J, ideally several times that) receives the partial
  * slabs that a second kernel folds into `out`.  scratch == NULL falls back to fp32 atomics. */
 int realise_gemm_tn(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
-                    int P, int I, int J, float* out, int64_t ldo, float* scratch, int64_t scratch_elems);
+                    int P, int I, int J, float* out, int64_t ldo, float* scratch, int64_t scratch_elems,
+                    float* colsum_out /* nullable: colsum_out[i] += sum_p A[p,i], the matching bias gradient */);
 /* Conv2d weight gradient into the reference's [Co][Ci][KH][KW] layout. */
 int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const realise_conv_geom* b,
                     int P, int Co, int Ci, float* out, float* scratch, int64_t scratch_elems);

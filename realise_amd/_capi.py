@@ -47,7 +47,7 @@ SYMBOLS = {
     "realise_version": (C.c_char_p, []),
     "realise_gemm_nt": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
     "realise_conv_nt": (_I, [_P, _I, C.POINTER(ConvGeom), _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
-    "realise_gemm_tn": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, _P, _L, _P, _L]),
+    "realise_gemm_tn": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, _P, _L, _P, _L, _P]),
     "realise_conv_tn": (_I, [_P, _I, _P, _L, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _L]),
     "realise_set_tn_transpose_read": (None, [_I]),
     "realise_attention_fwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _U, _U, _F]),

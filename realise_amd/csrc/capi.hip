@@ -52,9 +52,9 @@ int realise_conv_nt(void* stream, int dtype, const realise_conv_geom* a, const v
   return RL_ERR_ARG;
 }
 int realise_gemm_tn(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int P, int I, int J,
-                    float* out, int64_t ldo, float* scratch, int64_t scratch_elems) {
+                    float* out, int64_t ldo, float* scratch, int64_t scratch_elems, float* colsum_out) {
   hipStream_t st = (hipStream_t)stream;
-  TnEpi te; te.out = out; te.ldo = ldo; te.slab = scratch; te.slab_elems = scratch_elems;
+  TnEpi te; te.out = out; te.ldo = ldo; te.slab = scratch; te.slab_elems = scratch_elems; te.colsum = colsum_out;
   if (dtype == REALISE_BF16) return gemm_tn<bf16_t>(st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, P, I, J, te);
   if (dtype == REALISE_F32) return gemm_tn<float>(st, (const float*)A, lda, (const float*)B, ldb, P, I, J, te);
   return RL_ERR_ARG;

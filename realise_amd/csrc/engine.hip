@@ -346,14 +346,12 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(ln_bwd<T>(st, ln));
       }
       const T* dso = d3.thresh ? gC : gB;
-      RL_TRY(bias_grad<T>(st, dso, H, Tk, H, gp(o.out_b)));
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(o.out_w); te.ldo = I; RL_TRY(gemm_tn<T>(st, dso, H, wp<T>(t.post), I, Tk, H, I, te)); }
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(o.out_b); te.out = gp(o.out_w); te.ldo = I; RL_TRY(gemm_tn<T>(st, dso, H, wp<T>(t.post), I, Tk, H, I, te)); }
       {  // d pre = (d s2' . W_out) * gelu'(pre)
         EpiParams<T> ep; ep.mode = EPI_GELU_BWD; ep.out = gD; ep.ldo = I; ep.aux = wp<T>(t.pre); ep.ldaux = I;
         RL_TRY(gemm_nt<T>(st, dso, H, sp<T>(w.out_wT), H, Tk, I, H, ep));
       }
-      RL_TRY(bias_grad<T>(st, gD, I, Tk, I, gp(o.in_b)));
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(o.in_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gD, I, wp<T>(t.y1), H, Tk, I, H, te)); }
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(o.in_b); te.out = gp(o.in_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gD, I, wp<T>(t.y1), H, Tk, I, H, te)); }
       {  // d y1 = d s2 + d pre . W_in
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gB; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
@@ -365,8 +363,7 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(ln_bwd<T>(st, ln));
       }
       const T* dsa = d2.thresh ? gC : gA;
-      RL_TRY(bias_grad<T>(st, dsa, H, Tk, H, gp(o.ao_b)));
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(o.ao_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dsa, H, wp<T>(t.ctx), H, Tk, H, H, te)); }
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(o.ao_b); te.out = gp(o.ao_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dsa, H, wp<T>(t.ctx), H, Tk, H, H, te)); }
       {  // d ctx = d s1' . W_ao
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gE; ep.ldo = H;
         RL_TRY(gemm_nt<T>(st, dsa, H, sp<T>(w.ao_wT), H, Tk, H, H, ep));
@@ -376,8 +373,7 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(attn_bwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), gE, H, wp<float>(t.lse),
                            wp<float>(pl.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale));
       }
-      RL_TRY(bias_grad<T>(st, gF, 3 * H, Tk, 3 * H, gp(o.qkv_b)));
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(o.qkv_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gF, 3 * H, x_in, H, Tk, 3 * H, H, te)); }
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(o.qkv_b); te.out = gp(o.qkv_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gF, 3 * H, x_in, H, Tk, 3 * H, H, te)); }
       {  // d x_in = d s1 + d qkv . W_qkv
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, gF, 3 * H, sp<T>(w.qkv_wT), 3 * H, Tk, H, 3 * H, ep));
@@ -618,8 +614,7 @@ template <typename T> struct Engine : EngineBase {
     const DropParams dfin = site(5000, cfg.hidden_dropout);
     const T* top = cfg.model_type == 1 ? wp<T>(pl.outb.layers.back().y2) : wp<T>(pl.bert.layers.back().y2);
     const T* cls_in = dfin.thresh ? wp<T>(pl.out_d) : top;
-    RL_TRY(bias_grad<T>(st, dl, V, Tk, V, gp(L.cls_b)));
-    { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(L.cls_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dl, V, cls_in, H, Tk, V, H, te)); }
+    { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(L.cls_b); te.out = gp(L.cls_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dl, V, cls_in, H, Tk, V, H, te)); }
     { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H;
       RL_TRY(gemm_nt<T>(st, dl, V, sp<T>(sh_cls_wT), V, Tk, H, V, ep)); }
     if (dfin.thresh) RL_TRY(dropout_apply<T>(st, gA, gA, Tk, H, dfin));

@@ -130,6 +130,9 @@ struct TnEpi {
   // [I][J] partial slab here and a second kernel folds the slabs into `out` (no atomics).  nullptr -> atomics.
   float* slab = nullptr;
   int64_t slab_elems = 0;
+  // optional fused column sums of the A operand: colsum[i] += alpha * sum_p A[p,i]  (the bias gradient that goes
+  // with a Linear weight gradient), computed by one extra ones-vector MFMA per A fragment in the j-tile-0 workgroups
+  float* colsum = nullptr;
 };
 
 // C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)

@@ -312,6 +312,19 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // fused bias gradient: waves owning distinct i-ranges of the tj == 0 tiles also multiply their A fragments by ones
+  const bool do_colsum = (ep.colsum != nullptr) && (tj == 0) && (wj == 0);
+  floatx4 csum[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) csum[f] = floatx4{0.f, 0.f, 0.f, 0.f};
+  typename Mma::Frag ones;
+  if constexpr (sizeof(T) == 2) {
+    typedef __attribute__((ext_vector_type(8))) short short8_t;
+    const short8_t o = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    ones = __builtin_bit_cast(bf16x8_t, o);
+  } else {
+    ones = 1.0f;
+  }
 
   auto issue = [&](int pt, int stage) {
     char* base = smem + stage * STAGE;
@@ -360,6 +373,10 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = Mma::mma(b[j], a[i], acc[i][j]);
+      if (do_colsum) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) csum[f] = Mma::mma(ones, a[f], csum[f]);   // every row of the result = sum_p A[p, i]
+      }
     }
     cur ^= 1;
   }
@@ -368,6 +385,13 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       tn_epilogue4(ep, how, blockIdx.y, I, J, i0 + wi * 64 + i * 16 + l15, j0 + wj * 64 + j * 16 + 4 * g, acc[i][j]);
+  if (do_colsum && g == 0) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const int i = i0 + wi * 64 + f * 16 + l15;
+      if (i < I) atomicAdd(ep.colsum + i, csum[f][0] * ep.alpha);
+    }
+  }
 }
 
 // out(mapped) += alpha * sum_s slab[s][i][j]

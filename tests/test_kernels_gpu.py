@@ -150,8 +150,10 @@ def test_gemm_tn(dt, tr, Pn, I, J, scratch):
         base = rnd((I, J), 13).to(dev())
         out = base.clone()
         slab = torch.empty(8 * I * J if scratch else 1, device=dev())        # split reduction: slabs+fold vs atomics
+        cs = torch.full((I,), 0.5, device=dev())
         _capi.check(lib.realise_gemm_tn(stream(), code, P(a), I, P(b), J, Pn, I, J, P(out), J,
-                                        P(slab) if scratch else None, slab.numel() if scratch else 0), "gemm_tn")
+                                        P(slab) if scratch else None, slab.numel() if scratch else 0, P(cs)), "gemm_tn")
+        close(cs, a.float().sum(0) + 0.5, 3e-3 if dt == "bf16" else 2e-4, "fused column sums (bias gradient)")
         ref = a.float().t() @ b.float() + base
         close(out, ref, 3e-3 if dt == "bf16" else 2e-4, "gemm_tn %s tr=%d" % (dt, tr))
     finally:

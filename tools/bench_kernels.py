@@ -42,7 +42,7 @@ def bench_tn(P, I, J, variant):
     out = torch.zeros(I, J, device=dev)
     slab = torch.empty(16 << 20, device=dev)
     sp, sn = (slab.data_ptr(), slab.numel()) if variant == 2 else (None, 0)
-    us = timeit(lambda: lib.realise_gemm_tn(st(), 1, a.data_ptr(), I, b.data_ptr(), J, P, I, J, out.data_ptr(), J, sp, sn))
+    us = timeit(lambda: lib.realise_gemm_tn(st(), 1, a.data_ptr(), I, b.data_ptr(), J, P, I, J, out.data_ptr(), J, sp, sn, None))
     return us, 2.0 * P * I * J / us / 1e6
 
 
