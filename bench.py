@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--cpu-sample", type=int, default=16)
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
 

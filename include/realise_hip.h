@@ -69,6 +69,8 @@ int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const r
                     int P, int Co, int Ci, float* out, float* scratch, int64_t scratch_elems);
 /* 1: ds_read_b64_tr_b16 transposed operand reads in the TN kernel (bf16), 0: 16-bit LDS gathers. */
 void realise_set_tn_transpose_read(int enable);
+/* A/B knob: allow the 128x96 NT tile chosen by the chip-balance heuristic (default 1) */
+void realise_set_nt_allow_n96(int on);
 
 /* BertSelfAttention core (modeling_bert.py:239-260): softmax(QK^T/8 + mask_add) -> dropout -> .V
  * q/k/v: [B*S][ldq] token-major, head h at columns 64h..64h+63; ctx [B*S][ldc]; lse [B][nh][S]. */

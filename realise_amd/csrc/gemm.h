@@ -148,6 +148,7 @@ int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, in
 template <typename T>
 int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& lb, int P, int I, int J, const TnEpi& ep);
 
-void set_tn_transpose_read(int use_tr);   // 1: ds_read_b64_tr_b16 operand reads (bf16), 0: 16-bit LDS gathers
+void set_tn_transpose_read(int use_tr);
+void set_nt_allow_n96(int on);            // allow the 128x96 NT tile (chip-balance heuristic), default on
 
 }  // namespace rl

@@ -70,16 +70,18 @@ __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, 
 // K-tile = one 128-byte LDS row per operand row (64 bf16 / 32 f32), chunk c of row r stored at chunk
 // (c ^ (r & 7)) (KTile): conflict-free ds_read_b128 operand reads.
 // =================================================================================================
-template <typename T, typename ALoader, int WM, int WN>
-__global__ void __launch_bounds__(256, 2)
+template <typename T, typename ALoader, int WM, int WN, int NSTAGE, int NF>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE == 2) ? 2 : 1)
 gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, int ntiles, EpiParams<T> ep) {
   typedef typename MmaOf<T>::type Mma;
   typedef Geo<T> G;
-  constexpr int BM_ = 64 * WM, BN_ = 64 * WN;
+  constexpr int BM_ = 64 * WM, BN_ = 16 * NF * WN;       // each wave: 64 rows x (16*NF) columns
   constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE = A_BYTES + B_BYTES;
-  constexpr int NA = BM_ / 32, NB = BN_ / 32;        // 1-KiB wave-instructions per wave per tile
+  constexpr int NW = WM * WN;
+  constexpr int NA = BM_ / (8 * NW), NB = BN_ / (8 * NW);   // 1-KiB (8-row) wave-instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (SGPR): LDS bases stay scalar
   const int wm = wave / WN, wn = wave - wm * WN;
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -97,66 +99,113 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
   typename ALoader::KPos aq = la.kpos(kchunk);
   typename DenseLoader<T>::KPos bq = lb.kpos(kchunk);
   const int nk = (K + G::BK - 1) / G::BK;
+  // Fast addressing when no chunk can fall off the K end: each lane keeps one 64-bit source pointer per
+  // wave-instruction and just adds the K-tile stride (0 for lanes parked on the zero page).
+  constexpr bool kDenseA = sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
+  const bool fast = (K % G::BK) == 0;
+  const char* pa[NA];
+  const char* pb[NB];
+  int inca[NA], incb[NB];
+  if (fast) {
+    if constexpr (kDenseA) {
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const void* p0 = la.addr(actx[j], aq, zero);
+        pa[j] = (const char*)p0; inca[j] = (p0 != zero) ? G::BK * (int)sizeof(T) : 0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const void* p0 = lb.addr(bctx[j], bq, zero);
+      pb[j] = (const char*)p0; incb[j] = (p0 != zero) ? G::BK * (int)sizeof(T) : 0;
+    }
+  }
 
-  floatx4 acc[4][4];
+  floatx4 acc[4][NF];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NF; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue = [&](int stage) {                      // fetch the K-tile (aq, bq) point at, then advance them
+  auto issue = [&](int stage) {                      // fetch the next K-tile, then advance the positions
     char* base = smem + stage * STAGE;
+    if (kDenseA && fast) {
 #pragma unroll
-    for (int j = 0; j < NA; ++j) glds16(la.addr(actx[j], aq, zero), base + (wave * NA + j) * 1024);
+      for (int j = 0; j < NA; ++j) { glds16(pa[j], base + (wave * NA + j) * 1024); pa[j] += inca[j]; }
+    } else {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) glds16(lb.addr(bctx[j], bq, zero), base + A_BYTES + (wave * NB + j) * 1024);
-    la.advance(aq, G::BK);
-    lb.advance(bq, G::BK);
+      for (int j = 0; j < NA; ++j) glds16(la.addr(actx[j], aq, zero), base + (wave * NA + j) * 1024);
+      la.advance(aq, G::BK);
+    }
+    if (fast) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) { glds16(pb[j], base + A_BYTES + (wave * NB + j) * 1024); pb[j] += incb[j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) glds16(lb.addr(bctx[j], bq, zero), base + A_BYTES + (wave * NB + j) * 1024);
+      lb.advance(bq, G::BK);
+    }
   };
 
-  issue(0);
-  int cur = 0;
+  // NSTAGE-deep ring: tiles kt .. kt+NSTAGE-2 are in flight while tile kt is awaited.  LDS-DMA completion is
+  // tracked by vmcnt, so the wait is a COUNTED vmcnt (leave the younger tiles outstanding) followed by a raw
+  // s_barrier (a __syncthreads() here would drain vmcnt to 0 and serialise the pipeline).
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                  // tile kt landed for every wave; stage cur^1 is free
-    if (kt + 1 < nk) issue(cur ^ 1);
-    const char* As = smem + cur * STAGE;
+    if (NSTAGE == 2 || kt + 1 >= nk) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (NSTAGE == 3 || kt + 2 >= nk) {
+      if constexpr (NA + NB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (NA + NB == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else if constexpr (NA + NB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if constexpr (NA + NB == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                     // tile kt landed for every wave; stage (kt-1) % NSTAGE is free
+    asm volatile("" ::: "memory");
+    if (kt + NSTAGE - 1 < nk) issue((kt + NSTAGE - 1) % NSTAGE);
+    const char* As = smem + (kt % NSTAGE) * STAGE;
     const char* Bs = As + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
-      typename Mma::Frag a[4], b[4];
+      typename Mma::Frag a[4], b[NF];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = ktile_frag<T, G::BK>(As, wm * 64 + i * 16 + l15, ks, g);
-        b[i] = ktile_frag<T, G::BK>(Bs, wn * 64 + i * 16 + l15, ks, g);
-      }
+      for (int i = 0; i < 4; ++i) a[i] = ktile_frag<T, G::BK>(As, wm * 64 + i * 16 + l15, ks, g);
+#pragma unroll
+      for (int j = 0; j < NF; ++j) b[j] = ktile_frag<T, G::BK>(Bs, wn * 16 * NF + j * 16 + l15, ks, g);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Mma::mma(b[j], a[i], acc[i][j]);
+        for (int j = 0; j < NF; ++j) acc[i][j] = Mma::mma(b[j], a[i], acc[i][j]);
     }
-    cur ^= 1;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      epilogue4<T>(ep, M, N, m0 + wm * 64 + i * 16 + l15, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j]);
+    for (int j = 0; j < NF; ++j)
+      epilogue4<T>(ep, M, N, m0 + wm * 64 + i * 16 + l15, n0 + wn * 16 * NF + j * 16 + 4 * g, acc[i][j]);
 }
 
-template <typename T, typename ALoader, int WM, int WN>
+static int g_nt_n96 = 1;             // allow 128x96 tiles (tuning / A-B knob)
+void set_nt_allow_n96(int on) { g_nt_n96 = on; }
+
+template <typename T, typename ALoader, int WM, int WN, int NSTAGE = 2, int NF = 4>
 static int launch_nt_tile(hipStream_t st, const ALoader& la, const DenseLoader<T>& lb, int M, int N, int K, const EpiParams<T>& ep) {
-  constexpr int BM_ = 64 * WM, BN_ = 64 * WN;
+  constexpr int BM_ = 64 * WM, BN_ = 16 * NF * WN;
   const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_;
   const int ntiles = tiles_m * tiles_n;
-  const size_t lds = 2 * (size_t)(BM_ + BN_) * 128;
+  const size_t lds = NSTAGE * (size_t)(BM_ + BN_) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, ALoader, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   ProfScope ps(st, sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos) ? PK_GEMM_NT : PK_CONV_NT, 2.0 * M * N * K);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, ALoader, WM, WN>), dim3(ntiles), dim3(256), lds, st, la, lb, M, N, K, tiles_n, ntiles, ep);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF>), dim3(ntiles), dim3(64 * WM * WN), lds, st, la, lb, M, N, K, tiles_n, ntiles, ep);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -166,6 +215,16 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
   if ((N & 3) || (K % Geo<T>::VEC) || (ldb % Geo<T>::VEC)) return RL_ERR_ARG;
   DenseLoader<T> lb{B, ldb, N, K};
   if (N <= 64) return launch_nt_tile<T, ALoader, 4, 1>(st, la, lb, M, N, K, ep);
+  // Tile width by chip balance: 256 CUs x 2 resident workgroups.  The column count per tile (128 or 96) is chosen to
+  // minimise  width x f(tiles per CU)  with f(1) = 1 and f(n) = 0.75 n (two co-resident tiles overlap each other's
+  // stalls): e.g. M = 8192, N = 768 -> 8 x 96 columns = 512 tiles, two per CU on every CU, instead of 384 tiles of
+  // 128 columns (half the CUs run two, half run one): +25 % measured (tools/bench_nt_variants.py).
+  auto cost = [&](int bn) {
+    const long tiles = (long)((M + 127) / 128) * ((N + bn - 1) / bn);
+    const long tpc = (tiles + 255) / 256;
+    return bn * (tpc == 1 ? 1.0 : 0.75 * (double)tpc);
+  };
+  if (g_nt_n96 && cost(96) < cost(128)) return launch_nt_tile<T, ALoader, 2, 2, 2, 3>(st, la, lb, M, N, K, ep);
   return launch_nt_tile<T, ALoader, 2, 2>(st, la, lb, M, N, K, ep);
 }
 
@@ -277,7 +336,8 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
   constexpr int A_BYTES = G::BP * RPA, B_BYTES = G::BP * RPB, STAGE = A_BYTES + B_BYTES;
   constexpr int NA = A_BYTES / 4096, NB = B_BYTES / 4096;                     // 1-KiB instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave / WJ, wj = wave - wi * WJ;
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
@@ -326,21 +386,52 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
     ones = 1.0f;
   }
 
+  // Fast addressing for full reduction tiles: one 64-bit source pointer per wave-instruction, advanced by a
+  // constant (0 for lanes parked on the zero page); the checked path handles a ragged last tile.
+  constexpr bool kDenseB = sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
+  const char* pa[NA];
+  const char* pb[NB];
+  int64_t inca[NA], incb[NB];
+#pragma unroll
+  for (int q = 0; q < NA; ++q) {
+    pa[q] = acol[q] != nullptr ? (const char*)(acol[q] + (int64_t)(p_begin + apl[q]) * lda) : (const char*)zero;
+    inca[q] = acol[q] != nullptr ? (int64_t)G::BP * lda * (int64_t)sizeof(T) : 0;
+  }
+  if constexpr (kDenseB) {
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const typename BLoader::Ctx c0 = lb.prepare(0);
+      const typename BLoader::Ctx c1 = lb.prepare(1);
+      const char* r0 = (const char*)lb.addr(c0, bq[q], zero);
+      const char* r1 = (const char*)lb.addr(c1, bq[q], zero);
+      const int64_t ldb_bytes = r1 - r0;                                       // row pitch of the dense B operand
+      pb[q] = bok[q] ? r0 + (int64_t)(p_begin + bpl[q]) * ldb_bytes : (const char*)zero;
+      incb[q] = bok[q] ? (int64_t)G::BP * ldb_bytes : 0;
+    }
+  }
   auto issue = [&](int pt, int stage) {
     char* base = smem + stage * STAGE;
+    const bool full = pt + G::BP <= p_end;
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-      const int p = pt + apl[q];
-      const void* src = (p < p_end && acol[q] != nullptr) ? (const void*)(acol[q] + (int64_t)p * lda) : zero;
+      const void* src = pa[q];
+      if (!full && pt + apl[q] >= p_end) src = zero;
       glds16(src, base + (wave * NA + q) * 1024);
+      pa[q] += inca[q];
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-      const int p = pt + bpl[q];
       const void* src = zero;
-      if (p < p_end && bok[q]) {
-        const typename BLoader::Ctx c = lb.prepare(p);
-        src = lb.addr(c, bq[q], zero);
+      if constexpr (kDenseB) {
+        src = pb[q];
+        if (!full && pt + bpl[q] >= p_end) src = zero;
+        pb[q] += incb[q];
+      } else {
+        const int p = pt + bpl[q];
+        if (p < p_end && bok[q]) {
+          const typename BLoader::Ctx c = lb.prepare(p);
+          src = lb.addr(c, bq[q], zero);
+        }
       }
       glds16(src, base + A_BYTES + (wave * NB + q) * 1024);
     }

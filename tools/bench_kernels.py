@@ -30,6 +30,7 @@ def epi(out, ldo):
 
 
 def bench_nt(M, N, K, variant):
+    lib.realise_set_nt_allow_n96(0 if variant == 1 else 1)
     a = torch.randn(M, K, device=dev).bfloat16(); b = torch.randn(N, K, device=dev).bfloat16()
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     e = epi(out, N)
@@ -54,6 +55,7 @@ def geom(src, rows, Hr, Hs, Cc, k, stride, pad, mode):
 
 
 def bench_conv(N, Hin, Cin, Co, k, stride, pad, variant):
+    lib.realise_set_nt_allow_n96(0 if variant == 1 else 1)
     Hout = (Hin + 2 * pad - k) // stride + 1
     x = torch.randn(N, Hin, Hin, Cin, device=dev).bfloat16()
     w = torch.randn(Co, k * k * Cin, device=dev).bfloat16()
@@ -71,7 +73,7 @@ def bench_conv(N, Hin, Cin, Co, k, stride, pad, variant):
     return us_f, fl / us_f / 1e6, us_w, fl / us_w / 1e6
 
 
-print("== NT GEMM (M,N,K): us / TFLOPs  [TN/wgrad: v1 = atomics fallback | v2 = slabs + fold]")
+print("== NT GEMM (M,N,K): us / TFLOPs  [NT/conv fwd: v1 = 128x128 tiles only | v2 = 128x96 allowed;  TN/wgrad: v1 = atomics | v2 = slabs + fold]")
 for shp in [(8192, 2304, 768), (8192, 768, 768), (8192, 3072, 768), (8192, 768, 3072), (8192, 21128, 768), (8192, 768, 21128),
             (8192, 768, 2304), (3000, 2304, 768)]:
     r1, r2 = bench_nt(*shp, 1), bench_nt(*shp, 2)
