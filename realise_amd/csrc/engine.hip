@@ -67,6 +67,7 @@ template <typename T> struct Engine : EngineBase {
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
     int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
     int64_t bn_sums;
+    int64_t gu_first, gu_flag, gu_ids, gu_counts, gu_inv, gu_bounds, seg_acc;   // glyph dedup
     // backward scratch
     int64_t gA, gB, gC, gE, gD, gF, rowdot, X1, X2, X3, dz, tn_slab;
     int64_t gru_dh, gru_dgi, gru_dgh, gru_onehot, gru_dtable;
@@ -225,6 +226,8 @@ template <typename T> struct Engine : EngineBase {
         hin = a.Hout;
       }
       p.bn_sums = b.take(2 * 1024 * 4);
+      p.gu_first = b.take((int64_t)V * 4); p.gu_flag = b.take(Tk * 4); p.gu_ids = b.take(Tk * 8); p.gu_counts = b.take(Tk * 4);
+      p.gu_inv = b.take(Tk * 4); p.gu_bounds = b.take(64); p.seg_acc = b.take(Tk * H * 4);
       p.res_xhat = b.take(Tk * H * e); p.res_rstd = b.take(Tk * 4); p.res_h = b.take(Tk * H * e);
       p.gate_mean = b.take((int64_t)B * H * 4); p.gate_msum = b.take(B * 4 + 256); p.gate_g = b.take(Tk * 16);
       p.fused = b.take(Tk * H * e);
@@ -394,19 +397,31 @@ template <typename T> struct Engine : EngineBase {
   }
 
   // ---------------------------------------------------------------- glyph ResNet (char_cnn.py)
-  ConvLoader<T> geom(const T* src, const int64_t* index, int rows, int Hr, int Hs, int C, int ksz, int stride, int pad, int mode) const {
+  // rows_dev: device-side bound on the row space (glyph dedup: #distinct ids x pixels per image of that map)
+  ConvLoader<T> geom(const T* src, const int64_t* index, int rows, int Hr, int Hs, int C, int ksz, int stride, int pad, int mode,
+                     const int* rows_dev) const {
     ConvLoader<T> g;
-    g.src = src; g.img_index = index; g.rows = rows; g.Hr = Hr; g.Wr = Hr; g.Hs = Hs; g.Ws = Hs; g.C = C;
+    g.src = src; g.img_index = index; g.rows = rows; g.rows_dev = rows_dev; g.Hr = Hr; g.Wr = Hr; g.Hs = Hs; g.Ws = Hs; g.C = C;
     g.KH = ksz; g.KW = ksz; g.stride = stride; g.pad = pad; g.mode = mode; g.K = ksz * ksz * C;
     return g;
   }
-  int bn_forward(hipStream_t st, const T* x, int Pn, int C, const BnOff& o, const BnAct& a) {
+  // glyph dedup bookkeeping of block k's output map: device row bound, multiplicities, pixels per image
+  RowBound rbound(int k) const {
+    RowBound rb;
+    rb.rows_dev = wp<int>(pl.gu_bounds) + 1 + k;
+    rb.counts = wp<float>(pl.gu_counts);
+    rb.hw = pl.blk[k].Hout * pl.blk[k].Hout;
+    return rb;
+  }
+  // Pn = B*S*Hout^2 is the TRUE sample count of the statistics (every token counts, PADs included, as in the
+  // reference); the kernels visit only the distinct glyphs and weight them by their multiplicity.
+  int bn_forward(hipStream_t st, const T* x, int Pn, int C, const BnOff& o, const BnAct& a, const RowBound& rb) {
     if (last.training) {
       float* sums = wp<float>(pl.bn_sums);
       RL_TRY(fill_f32(st, sums, 0.f, 2 * C));
-      RL_TRY(col_sum<T>(st, x, Pn, C, sums));
+      RL_TRY(col_sum<T>(st, x, Pn, C, sums, rb));
       RL_TRY(bn_finalize_mean(st, sums, C, Pn, wp<float>(a.mean)));
-      RL_TRY(col_sumsq_centered<T>(st, x, Pn, C, wp<float>(a.mean), sums + C));
+      RL_TRY(col_sumsq_centered<T>(st, x, Pn, C, wp<float>(a.mean), sums + C, rb));
       RL_TRY(bn_finalize_train(st, wp<float>(a.mean), sums + C, C, Pn, pp(o.g), pp(o.b), 1e-5f, 0.1f, BF + o.rmean, BF + o.rvar,
                                wp<float>(a.rstd), wp<float>(a.scale), wp<float>(a.shift)));
       RL_TRY(add_i64(st, BI + o.nbt, 1, 1));
@@ -416,38 +431,47 @@ template <typename T> struct Engine : EngineBase {
     return RL_OK;
   }
   int resnet_forward(hipStream_t st, const int64_t* ids, const T** out) {
-    const int N = pl.B * pl.S;
+    // The glyph stack of a token depends only on its id, so the ResNet runs once per DISTINCT id of the batch
+    // (order of first occurrence) and BatchNorm weights each glyph by its multiplicity: identical statistics
+    // to the reference's dense [B*S, F, 32, 32] pass, a fraction of the work (PAD alone is ~1/3 of the rows).
+    {
+      HwList hw; hw.n = 5;
+      for (int k = 0; k < 5; ++k) hw.v[k] = pl.blk[k].Hout * pl.blk[k].Hout;
+      RL_TRY(glyph_unique(st, ids, pl.B * pl.S, V, wp<int>(pl.gu_first), wp<int>(pl.gu_flag), wp<int64_t>(pl.gu_ids),
+                          wp<float>(pl.gu_counts), wp<int>(pl.gu_inv), wp<int>(pl.gu_bounds), hw));
+    }
     const T* x = sp<T>(sh_glyph);
-    const int64_t* index = ids;
+    const int64_t* index = wp<int64_t>(pl.gu_ids);
     for (int k = 0; k < 5; ++k) {
       const BlockOff& o = L.blocks[k];
       const BlockSh& s = sh_blk[k];
       BlockAct& a = pl.blk[k];
       const int Co = o.cout, Cin = s.cin_pad, Pn = a.Pout;
+      const RowBound rb = rbound(k);
       EpiParams<T> ep; ep.mode = EPI_STORE; ep.ldo = Co;
       // residual_function.0: 3x3 stride 2 pad 1 (char_cnn.py:16)
       ep.out = wp<T>(a.c1);
-      RL_TRY(gemm_nt_conv<T>(st, geom(x, index, Pn, a.Hout, a.Hin, Cin, 3, 2, 1, 0), sp<T>(s.w1f), 9 * Cin, Pn, Co, 9 * Cin, ep));
-      RL_TRY(bn_forward(st, wp<T>(a.c1), Pn, Co, o.bn1, a.bn1));
-      RL_TRY(bn_apply<T>(st, wp<T>(a.c1), wp<float>(a.bn1.scale), wp<float>(a.bn1.shift), nullptr, nullptr, nullptr, wp<T>(a.h1), Pn, Co, 1));
+      RL_TRY(gemm_nt_conv<T>(st, geom(x, index, Pn, a.Hout, a.Hin, Cin, 3, 2, 1, 0, rb.rows_dev), sp<T>(s.w1f), 9 * Cin, Pn, Co, 9 * Cin, ep));
+      RL_TRY(bn_forward(st, wp<T>(a.c1), Pn, Co, o.bn1, a.bn1, rb));
+      RL_TRY(bn_apply<T>(st, wp<T>(a.c1), wp<float>(a.bn1.scale), wp<float>(a.bn1.shift), nullptr, nullptr, nullptr, wp<T>(a.h1), Pn, Co, 1, rb));
       // residual_function.3: 3x3 stride 1 pad 1 (char_cnn.py:19)
       ep.out = wp<T>(a.c2);
-      RL_TRY(gemm_nt_conv<T>(st, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0), sp<T>(s.w2f), 9 * Co, Pn, Co, 9 * Co, ep));
-      RL_TRY(bn_forward(st, wp<T>(a.c2), Pn, Co, o.bn2, a.bn2));
+      RL_TRY(gemm_nt_conv<T>(st, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0, rb.rows_dev), sp<T>(s.w2f), 9 * Co, Pn, Co, 9 * Co, ep));
+      RL_TRY(bn_forward(st, wp<T>(a.c2), Pn, Co, o.bn2, a.bn2, rb));
       // shortcut: 1x1 stride 2 (char_cnn.py:26-28)
       ep.out = wp<T>(a.cs);
-      RL_TRY(gemm_nt_conv<T>(st, geom(x, index, Pn, a.Hout, a.Hin, Cin, 1, 2, 0, 0), sp<T>(s.wsf), Cin, Pn, Co, Cin, ep));
-      RL_TRY(bn_forward(st, wp<T>(a.cs), Pn, Co, o.bns, a.bns));
+      RL_TRY(gemm_nt_conv<T>(st, geom(x, index, Pn, a.Hout, a.Hin, Cin, 1, 2, 0, 0, rb.rows_dev), sp<T>(s.wsf), Cin, Pn, Co, Cin, ep));
+      RL_TRY(bn_forward(st, wp<T>(a.cs), Pn, Co, o.bns, a.bns, rb));
       RL_TRY(bn_apply<T>(st, wp<T>(a.c2), wp<float>(a.bn2.scale), wp<float>(a.bn2.shift), wp<T>(a.cs), wp<float>(a.bns.scale),
-                         wp<float>(a.bns.shift), wp<T>(a.out), Pn, Co, 1));
+                         wp<float>(a.bns.shift), wp<T>(a.out), Pn, Co, 1, rb));
       x = wp<T>(a.out);
       index = nullptr;
     }
     *out = x;
     return RL_OK;
   }
-  // d_out: gradient w.r.t. block-5 output [N,768]
-  int resnet_backward(hipStream_t st, const int64_t* ids, const T* d_top) {
+  // d_top: gradient w.r.t. block-5 output per DISTINCT glyph [U,768] (already summed over the tokens sharing it)
+  int resnet_backward(hipStream_t st, const T* d_top) {
     float* sums = wp<float>(pl.bn_sums);
     const T* d_out = d_top;
     for (int k = 4; k >= 0; --k) {
@@ -455,40 +479,42 @@ template <typename T> struct Engine : EngineBase {
       const BlockSh& s = sh_blk[k];
       BlockAct& a = pl.blk[k];
       const int Co = o.cout, Cin = s.cin_pad, Pn = a.Pout;
+      const RowBound rb = rbound(k);
       const T* x_in = k > 0 ? wp<T>(pl.blk[k - 1].out) : sp<T>(sh_glyph);
-      const int64_t* index = k > 0 ? nullptr : ids;
+      const int64_t* index = k > 0 ? nullptr : wp<int64_t>(pl.gu_ids);
       T* dc2 = wp<T>(pl.r_dc2); T* dcs = wp<T>(pl.r_dcs); T* dh1 = wp<T>(pl.r_dh1); T* dc1 = wp<T>(pl.r_dc1);
       // out = relu(bn2(c2) + bns(cs))
       RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));
-      RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), Pn, Co, sums));
+      RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), Pn, Co, sums, rb));
       RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), pp(o.bn2.g), sums,
-                             Pn, Co, dc2, gp(o.bn2.g), gp(o.bn2.b)));
+                             Pn, Co, dc2, gp(o.bn2.g), gp(o.bn2.b), rb, Pn));
       RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));
-      RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), Pn, Co, sums));
+      RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), Pn, Co, sums, rb));
       RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), pp(o.bns.g), sums,
-                             Pn, Co, dcs, gp(o.bns.g), gp(o.bns.b)));
+                             Pn, Co, dcs, gp(o.bns.g), gp(o.bns.b), rb, Pn));
       // conv2 (3x3 s1): weight grad and data grad
       { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w2); te.Cin = Co; te.Cpad = Co; te.KHW = 9;
-        RL_TRY(gemm_tn_conv<T>(st, dc2, Co, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0), Pn, Co, 9 * Co, te)); }
+        RL_TRY(gemm_tn_conv<T>(st, dc2, Co, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0, rb.rows_dev), Pn, Co, 9 * Co, te)); }
       { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = dh1; ep.ldo = Co;
-        RL_TRY(gemm_nt_conv<T>(st, geom(dc2, nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 1), sp<T>(s.w2d), 9 * Co, Pn, Co, 9 * Co, ep)); }
+        RL_TRY(gemm_nt_conv<T>(st, geom(dc2, nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 1, rb.rows_dev), sp<T>(s.w2d), 9 * Co, Pn, Co, 9 * Co, ep)); }
       // h1 = relu(bn1(c1))
       RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));
-      RL_TRY(bn_bwd_reduce<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), Pn, Co, sums));
+      RL_TRY(bn_bwd_reduce<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), Pn, Co, sums, rb));
       RL_TRY(bn_bwd_apply<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), pp(o.bn1.g), sums,
-                             Pn, Co, dc1, gp(o.bn1.g), gp(o.bn1.b)));
+                             Pn, Co, dc1, gp(o.bn1.g), gp(o.bn1.b), rb, Pn));
       // conv1 (3x3 s2) and shortcut (1x1 s2) weight grads
       { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w1); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 9;
-        RL_TRY(gemm_tn_conv<T>(st, dc1, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 3, 2, 1, 0), Pn, Co, 9 * Cin, te)); }
+        RL_TRY(gemm_tn_conv<T>(st, dc1, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 3, 2, 1, 0, rb.rows_dev), Pn, Co, 9 * Cin, te)); }
       { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.ws); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 1;
-        RL_TRY(gemm_tn_conv<T>(st, dcs, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 1, 2, 0, 0), Pn, Co, Cin, te)); }
+        RL_TRY(gemm_tn_conv<T>(st, dcs, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 1, 2, 0, 0, rb.rows_dev), Pn, Co, Cin, te)); }
       if (k > 0) {   // d x_in = dgrad(conv1) + dgrad(shortcut); the glyph table itself is frozen
         const int Pin = pl.blk[k - 1].Pout;
+        const int* in_bound = rbound(k - 1).rows_dev;
         T* dx = (d_out == wp<T>(pl.r_dx)) ? wp<T>(pl.r_dout) : wp<T>(pl.r_dx);
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = dx; ep.ldo = Cin;
-        RL_TRY(gemm_nt_conv<T>(st, geom(dc1, nullptr, Pin, a.Hin, a.Hout, Co, 3, 2, 1, 1), sp<T>(s.w1d), 9 * Co, Pin, Cin, 9 * Co, ep));
+        RL_TRY(gemm_nt_conv<T>(st, geom(dc1, nullptr, Pin, a.Hin, a.Hout, Co, 3, 2, 1, 1, in_bound), sp<T>(s.w1d), 9 * Co, Pin, Cin, 9 * Co, ep));
         ep.accumulate = 1;
-        RL_TRY(gemm_nt_conv<T>(st, geom(dcs, nullptr, Pin, a.Hin, a.Hout, Co, 1, 2, 0, 1), sp<T>(s.wsd), Co, Pin, Cin, Co, ep));
+        RL_TRY(gemm_nt_conv<T>(st, geom(dcs, nullptr, Pin, a.Hin, a.Hout, Co, 1, 2, 0, 1, in_bound), sp<T>(s.wsd), Co, Pin, Cin, Co, ep));
         d_out = dx;
       }
     }
@@ -581,7 +607,8 @@ template <typename T> struct Engine : EngineBase {
       const T* res = nullptr;
       RL_TRY(resnet_forward(st, b.src_idx, &res));
       {
-        LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = res; ln.gamma = pp(L.res_ln_g); ln.beta = pp(L.res_ln_b); ln.eps = cfg.ln_eps;
+        LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = res; ln.row_index = wp<int>(pl.gu_inv);      // token t reads its glyph's row
+        ln.gamma = pp(L.res_ln_g); ln.beta = pp(L.res_ln_b); ln.eps = cfg.ln_eps;
         ln.y = wp<T>(pl.res_h); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
         RL_TRY(ln_fwd<T>(st, ln));
       }
@@ -649,9 +676,11 @@ template <typename T> struct Engine : EngineBase {
         g.dW = gp(L.gate_w); g.dbias = gp(L.gate_b);
         RL_TRY(gate_bwd<T>(st, g));
         LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = wp<T>(pl.X3); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
-        ln.gamma = pp(L.res_ln_g); ln.dx = wp<T>(pl.r_dout); ln.dgamma = gp(L.res_ln_g); ln.dbeta = gp(L.res_ln_b);
+        ln.gamma = pp(L.res_ln_g); ln.dx = wp<T>(pl.gE); ln.dgamma = gp(L.res_ln_g); ln.dbeta = gp(L.res_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
-        RL_TRY(resnet_backward(st, last.src_idx, wp<T>(pl.r_dout)));
+        // per-token gradient -> per-distinct-glyph gradient (sum over the tokens that share the glyph)
+        RL_TRY(segment_sum<T>(st, wp<T>(pl.gE), wp<int>(pl.gu_inv), Tk, H, wp<float>(pl.seg_acc), wp<T>(pl.r_dout), wp<int>(pl.gu_bounds)));
+        RL_TRY(resnet_backward(st, wp<T>(pl.r_dout)));
       } break;
       case 2: {   // pho_model + GRU
         T* g2 = wp<T>(pl.X2);

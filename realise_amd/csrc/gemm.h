@@ -40,6 +40,7 @@ template <typename T> struct DenseLoader {
   int rows, K;
   struct Ctx { const T* p; };
   struct KPos { int k; };
+  __device__ __forceinline__ void clamp_rows() {}
   __device__ __forceinline__ Ctx prepare(int row) const {
     Ctx c; c.p = (row < rows) ? base + (int64_t)row * ld : nullptr; return c;
   }
@@ -59,8 +60,10 @@ template <typename T> struct ConvLoader {
   const int64_t* img_index;
   int rows, Hr, Wr, Hs, Ws, C, KH, KW, stride, pad, mode, K;
   int hw_shift, w_shift;      // log2(Hr*Wr), log2(Wr) when both are powers of two, else -1 (set by finalize())
+  const int* rows_dev = nullptr;   // optional device-side row bound (glyph dedup: #distinct ids * pixels per image)
   struct Ctx { const T* img; int y, x; };
   struct KPos { int kh, kw, ch, k; };
+  __device__ __forceinline__ void clamp_rows() { if (rows_dev != nullptr) rows = min(rows, *rows_dev); }
   void finalize() {
     K = KH * KW * C;
     hw_shift = w_shift = -1;

@@ -86,6 +86,8 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM_, n0 = tn * BN_;
+  la.clamp_rows();
+  if (m0 >= la.rows) return;                          // device-side row bound (block-uniform, before any barrier)
   const void* zero = (const void*)g_zero16;
   const int lrow = lane >> 3;                        // row inside the 8-row group written by one instruction
   const int kchunk = ((lane & 7) ^ lrow) * G::VEC;   // logical K offset of the chunk this lane fetches
@@ -342,8 +344,9 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
   const int tile = xcd_remap(blockIdx.x, ntiles);
   const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
   const int i0 = ti * BI, j0 = tj * BJ;
+  lb.clamp_rows();
   const int p_begin = blockIdx.y * pchunk;
-  const int p_end = min(P, p_begin + pchunk);
+  const int p_end = max(p_begin, min(min(P, lb.rows), p_begin + pchunk));   // rows past a device-side bound contribute zero
   const void* zero = (const void*)g_zero16;
 
   // per-lane chunk coordinates are the same for every reduction tile: only the row base moves

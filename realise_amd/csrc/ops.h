@@ -7,6 +7,16 @@ namespace rl {
 
 struct DropParams { uint32_t seed = 0, thresh = 0; float scale = 1.0f; };
 
+// Device-side row bound + per-image multiplicity for the glyph branch, which runs once per DISTINCT token id of the
+// batch: effective rows = min(P, *rows_dev); weight(row) = counts[row / hw] (the number of tokens sharing that glyph).
+struct RowBound {
+  const int* rows_dev = nullptr;
+  const float* counts = nullptr;
+  int hw = 1;
+};
+__device__ __forceinline__ int rb_rows(const RowBound& b, int P) { return b.rows_dev ? min(P, *b.rows_dev) : P; }
+__device__ __forceinline__ float rb_weight(const RowBound& b, int row) { return b.counts ? b.counts[row / b.hw] : 1.0f; }
+
 int mask_to_additive(hipStream_t st, const int64_t* masks, float* out, int n);
 
 // ---- LayerNorm (K1, K4 tail, K10) ------------------------------------------------------------
@@ -14,6 +24,7 @@ template <typename T> struct LnFwdArgs {
   int rows = 0, H = 0, S = 1;
   int in_mode = 0;                 // 0: x ; 1: word[ids] + pos + type0 ; 2: x + pos + type0
   const T* x = nullptr;
+  const int* row_index = nullptr;  // in_mode 0: read row row_index[r] of x instead of row r (glyph dedup gather)
   const int64_t* ids = nullptr;
   const float* word = nullptr;
   const float* pos = nullptr;      // position table [P][H]
@@ -106,8 +117,8 @@ int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const floa
                   float* d_emb, float* d_w_ih, float* d_b_ih);
 
 // ---- BatchNorm over NHWC activations [P][C] (K9) -------------------------------------------------
-template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out);
-template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out);
+template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out, RowBound rb = RowBound());
+template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out, RowBound rb = RowBound());
 // train-mode finalize: stats -> (mean, rstd, scale, shift), running-stat update (unbiased var, momentum)
 int bn_finalize_mean(hipStream_t st, const float* sum, int C, int P, float* mean);
 int bn_finalize_train(hipStream_t st, const float* mean, const float* sqsum, int C, int P, const float* gamma, const float* beta,
@@ -117,17 +128,27 @@ int bn_finalize_eval(hipStream_t st, int C, const float* gamma, const float* bet
 // y = [relu]( x1*sc1 + sh1 [+ x2*sc2 + sh2] )
 template <typename T>
 int bn_apply(hipStream_t st, const T* x1, const float* sc1, const float* sh1, const T* x2, const float* sc2, const float* sh2,
-             T* y, int P, int C, int relu);
+             T* y, int P, int C, int relu, RowBound rb = RowBound());
 // sums[0..C) += sum g ; sums[C..2C) += sum g*xhat  with g = dy * (relu_src > 0)
 template <typename T>
 int bn_bwd_reduce(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd, int P, int C,
-                  float* sums);
-// dx = gamma*rstd*(g - sum_g/P - xhat*sum_gx/P); dgamma += sum_gx ; dbeta += sum_g
+                  float* sums, RowBound rb = RowBound());
+// dx = gamma*rstd*(g - w*sum_g/N - w*xhat*sum_gx/N); dgamma += sum_gx ; dbeta += sum_g   (w = multiplicity, N = n_stat)
 template <typename T>
 int bn_bwd_apply(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd,
-                 const float* gamma, const float* sums, int P, int C, T* dx, float* dgamma, float* dbeta);
+                 const float* gamma, const float* sums, int P, int C, T* dx, float* dgamma, float* dbeta,
+                 RowBound rb = RowBound(), int n_stat = 0);
 // g = dy * (relu_src > 0)
 template <typename T> int relu_bwd(hipStream_t st, const T* dy, const T* relu_src, T* g, int64_t n);
+
+// ---- glyph dedup (the ResNet input depends only on the token id) ------------------------------------
+// ids[T] -> uniq_ids[<=T] (order of first occurrence), counts[slot], inv[t] = slot of token t, and bounds[0] = U,
+// bounds[1+k] = U * hw[k] for k < nhw.  first_scratch: V ints, flag_scratch: T ints.
+struct HwList { int n = 0; int v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+int glyph_unique(hipStream_t st, const int64_t* ids, int T_, int V, int* first_scratch, int* flag_scratch, int64_t* uniq_ids,
+                 float* counts, int* inv, int* bounds, HwList hw);
+// out[u][c] = sum over tokens t with inv[t] == u of x[t][c]   (fp32 scratch `acc` of T*C floats, out rows >= U untouched)
+template <typename T> int segment_sum(hipStream_t st, const T* x, const int* inv, int T_, int C, float* acc, T* out, const int* nuniq_dev);
 
 // ---- weight shadows (operand copies in the compute dtype) ----------------------------------------
 template <typename T> int cast_copy(hipStream_t st, const float* src, T* dst, int64_t n);

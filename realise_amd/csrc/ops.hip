@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs<T> a) {
     if (c < H) {
       floatx4 x;
       if (a.in_mode == 1) x = *(const floatx4*)(a.word + tok * H + c);
-      else x = load4<T>(a.x + (int64_t)row * H + c);
+      else x = load4<T>(a.x + (int64_t)(a.row_index ? a.row_index[row] : row) * H + c);
       if (a.in_mode != 0) x += *(const floatx4*)(a.pos + (int64_t)prow * H + c) + *(const floatx4*)(a.type0 + c);
       v[i] = x;
       sum += x[0] + x[1] + x[2] + x[3];
@@ -212,10 +212,12 @@ template int embed_bwd<float>(hipStream_t, const float*, const int64_t*, int, in
 // Column reductions over a row-major [rows][C] matrix: 32 threads x 4 columns wide, 8 row lanes.
 // ---------------------------------------------------------------------------------------------
 template <typename F>
-__global__ void __launch_bounds__(256) col_reduce_kernel(F f, int rows, int C, int rows_per_block, float* out0, float* out1) {
+__global__ void __launch_bounds__(256) col_reduce_kernel(F f, int rows_max, int C, int rows_per_block, float* out0, float* out1,
+                                                          RowBound rb) {
   __shared__ floatx4 red[2][8][32];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int col = (blockIdx.x * 32 + cx) * 4;
+  const int rows = rb_rows(rb, rows_max);
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
   floatx4 a0 = floatx4{0.f, 0.f, 0.f, 0.f}, a1 = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(F f, int rows, int C, i
   }
 }
 template <typename F>
-static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float* out0, float* out1) {
+static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float* out0, float* out1, RowBound rb = RowBound()) {
   if (rows <= 0 || C <= 0) return RL_OK;
   if (C & 3) return RL_ERR_ARG;
   const int gx = (C + 127) / 128;
@@ -244,7 +246,7 @@ static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float*
   int rpb = (rows + gy - 1) / gy;
   if (rpb < 64) rpb = 64;
   gy = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, rpb, out0, out1);
+  hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, rpb, out0, out1, rb);
   return RL_LAUNCH_CHECK();
 }
 
@@ -260,26 +262,32 @@ template <typename T> int bias_grad(hipStream_t st, const T* dy, int64_t ld, int
 template int bias_grad<bf16_t>(hipStream_t, const bf16_t*, int64_t, int, int, float*);
 template int bias_grad<float>(hipStream_t, const float*, int64_t, int, int, float*);
 
-template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out) {
-  SumF<T> f{x, (int64_t)C};
-  return launch_col_reduce(st, f, P, C, out, nullptr);
-}
-template int col_sum<bf16_t>(hipStream_t, const bf16_t*, int, int, float*);
-template int col_sum<float>(hipStream_t, const float*, int, int, float*);
-
-template <typename T> struct SumSqCF {
-  const T* x; int64_t ld; const float* mean;
+template <typename T> struct WSumF {
+  const T* x; int64_t ld; RowBound rb;
   __device__ __forceinline__ void operator()(int r, int c, floatx4& a0, floatx4&) const {
-    const floatx4 d = load4<T>(x + (int64_t)r * ld + c) - *(const floatx4*)(mean + c);
-    a0 += d * d;
+    a0 += load4<T>(x + (int64_t)r * ld + c) * rb_weight(rb, r);
   }
 };
-template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out) {
-  SumSqCF<T> f{x, (int64_t)C, mean};
-  return launch_col_reduce(st, f, P, C, out, nullptr);
+template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out, RowBound rb) {
+  WSumF<T> f{x, (int64_t)C, rb};
+  return launch_col_reduce(st, f, P, C, out, nullptr, rb);
 }
-template int col_sumsq_centered<bf16_t>(hipStream_t, const bf16_t*, int, int, const float*, float*);
-template int col_sumsq_centered<float>(hipStream_t, const float*, int, int, const float*, float*);
+template int col_sum<bf16_t>(hipStream_t, const bf16_t*, int, int, float*, RowBound);
+template int col_sum<float>(hipStream_t, const float*, int, int, float*, RowBound);
+
+template <typename T> struct SumSqCF {
+  const T* x; int64_t ld; const float* mean; RowBound rb;
+  __device__ __forceinline__ void operator()(int r, int c, floatx4& a0, floatx4&) const {
+    const floatx4 d = load4<T>(x + (int64_t)r * ld + c) - *(const floatx4*)(mean + c);
+    a0 += d * d * rb_weight(rb, r);
+  }
+};
+template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out, RowBound rb) {
+  SumSqCF<T> f{x, (int64_t)C, mean, rb};
+  return launch_col_reduce(st, f, P, C, out, nullptr, rb);
+}
+template int col_sumsq_centered<bf16_t>(hipStream_t, const bf16_t*, int, int, const float*, float*, RowBound);
+template int col_sumsq_centered<float>(hipStream_t, const float*, int, int, const float*, float*, RowBound);
 
 template <typename T> struct BnBwdF {
   const T* dy; const T* relu_src; const T* x; const float* mean; const float* rstd; int64_t ld;
@@ -297,12 +305,12 @@ template <typename T> struct BnBwdF {
 };
 template <typename T>
 int bn_bwd_reduce(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd, int P, int C,
-                  float* sums) {
+                  float* sums, RowBound rb) {
   BnBwdF<T> f{dy, relu_src, x, mean, rstd, (int64_t)C};
-  return launch_col_reduce(st, f, P, C, sums, sums + C);
+  return launch_col_reduce(st, f, P, C, sums, sums + C, rb);
 }
-template int bn_bwd_reduce<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, int, int, float*);
-template int bn_bwd_reduce<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, int, int, float*);
+template int bn_bwd_reduce<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, int, int, float*, RowBound);
+template int bn_bwd_reduce<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, int, int, float*, RowBound);
 
 // ---------------------------------------------------------------------------------------------
 // Dropout as a stand-alone map (the one before the classifier, models.py:858)
@@ -563,5 +571,94 @@ template <typename T> int gate_bwd(hipStream_t st, const GateArgs<T>& a) {
 }
 template int gate_bwd<bf16_t>(hipStream_t, const GateArgs<bf16_t>&);
 template int gate_bwd<float>(hipStream_t, const GateArgs<float>&);
+
+// ---------------------------------------------------------------------------------------------
+// Glyph dedup: distinct token ids of the batch in order of first occurrence (deterministic).
+// ---------------------------------------------------------------------------------------------
+__global__ void gu_clear_kernel(int* first, int V, float* counts, int T_) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < V) first[i] = 0x7fffffff;
+  if (i < T_) counts[i] = 0.f;
+}
+__global__ void gu_first_kernel(const int64_t* __restrict__ ids, int T_, int* first) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < T_) atomicMin(first + (int)ids[t], t);
+}
+// single workgroup: exclusive scan of is_first over t -> slot of every first occurrence
+__global__ void __launch_bounds__(1024) gu_scan_kernel(const int64_t* __restrict__ ids, int T_, const int* __restrict__ first,
+                                                       int* slot_of_t, int64_t* uniq_ids, int* bounds, HwList hw) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < T_; base += 1024) {
+    const int t = base + threadIdx.x;
+    const int flag = (t < T_ && first[(int)ids[t]] == t) ? 1 : 0;
+    int v = flag;                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(v, o, 64); if (lane >= o) v += n; }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    const int excl = off + v - flag;
+    if (t < T_) {
+      slot_of_t[t] = flag ? excl : -1;
+      if (flag) uniq_ids[excl] = ids[t];
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = off + v;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int U = carry;
+    bounds[0] = U;
+    for (int k = 0; k < hw.n; ++k) bounds[1 + k] = U * hw.v[k];
+  }
+}
+__global__ void gu_final_kernel(const int64_t* __restrict__ ids, int T_, const int* __restrict__ first, const int* __restrict__ slot_of_t,
+                                int* inv, float* counts) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T_) return;
+  const int s = slot_of_t[first[(int)ids[t]]];
+  inv[t] = s;
+  atomicAdd(counts + s, 1.0f);
+}
+int glyph_unique(hipStream_t st, const int64_t* ids, int T_, int V, int* first_scratch, int* flag_scratch, int64_t* uniq_ids,
+                 float* counts, int* inv, int* bounds, HwList hw) {
+  const int n = V > T_ ? V : T_;
+  hipLaunchKernelGGL(gu_clear_kernel, dim3((n + 255) / 256), dim3(256), 0, st, first_scratch, V, counts, T_);
+  hipLaunchKernelGGL(gu_first_kernel, dim3((T_ + 255) / 256), dim3(256), 0, st, ids, T_, first_scratch);
+  hipLaunchKernelGGL(gu_scan_kernel, dim3(1), dim3(1024), 0, st, ids, T_, first_scratch, flag_scratch, uniq_ids, bounds, hw);
+  hipLaunchKernelGGL(gu_final_kernel, dim3((T_ + 255) / 256), dim3(256), 0, st, ids, T_, first_scratch, flag_scratch, inv, counts);
+  return RL_LAUNCH_CHECK();
+}
+
+template <typename T>
+__global__ void segsum_scatter_kernel(const T* __restrict__ x, const int* __restrict__ inv, int T_, int C, float* acc) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int t = blockIdx.y;
+  if (c >= C) return;
+  const floatx4 v = load4<T>(x + (int64_t)t * C + c);
+  float* o = acc + (int64_t)inv[t] * C + c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) atomicAdd(o + j, v[j]);
+}
+template <typename T>
+__global__ void segsum_cast_kernel(const float* __restrict__ acc, T* __restrict__ out, int C, const int* __restrict__ nuniq) {
+  const int64_t n = (int64_t)(*nuniq) * C;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4)
+    store4<T>(out + i, *(const floatx4*)(acc + i));
+}
+template <typename T> int segment_sum(hipStream_t st, const T* x, const int* inv, int T_, int C, float* acc, T* out, const int* nuniq_dev) {
+  if (C & 3) return RL_ERR_ARG;
+  (void)hipMemsetAsync(acc, 0, (size_t)T_ * C * sizeof(float), st);
+  hipLaunchKernelGGL((segsum_scatter_kernel<T>), dim3((C / 4 + 63) / 64, T_), dim3(64), 0, st, x, inv, T_, C, acc);
+  hipLaunchKernelGGL((segsum_cast_kernel<T>), dim3(1024), dim3(256), 0, st, acc, out, C, nuniq_dev);
+  return RL_LAUNCH_CHECK();
+}
+template int segment_sum<bf16_t>(hipStream_t, const bf16_t*, const int*, int, int, float*, bf16_t*, const int*);
+template int segment_sum<float>(hipStream_t, const float*, const int*, int, int, float*, float*, const int*);
 
 }  // namespace rl

@@ -209,7 +209,8 @@ int bn_finalize_eval(hipStream_t st, int C, const float* gamma, const float* bet
 template <typename T>
 __global__ void bn_apply_kernel(const T* __restrict__ x1, const float* __restrict__ sc1, const float* __restrict__ sh1,
                                 const T* __restrict__ x2, const float* __restrict__ sc2, const float* __restrict__ sh2,
-                                T* __restrict__ y, int64_t n, int C, int relu) {
+                                T* __restrict__ y, int P, int C, int relu, RowBound rb) {
+  const int64_t n = (int64_t)rb_rows(rb, P) * C;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
     const int c = (int)(i % C);
     floatx4 v = load4<T>(x1 + i) * *(const floatx4*)(sc1 + c) + *(const floatx4*)(sh1 + c);
@@ -224,21 +225,23 @@ __global__ void bn_apply_kernel(const T* __restrict__ x1, const float* __restric
 static inline int ew_blocks(int64_t n4) { int64_t b = (n4 + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 template <typename T>
 int bn_apply(hipStream_t st, const T* x1, const float* sc1, const float* sh1, const T* x2, const float* sc2, const float* sh2,
-             T* y, int P, int C, int relu) {
+             T* y, int P, int C, int relu, RowBound rb) {
   if (C & 3) return RL_ERR_ARG;
   const int64_t n = (int64_t)P * C;
-  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, x1, sc1, sh1, x2, sc2, sh2, y, n, C, relu);
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, x1, sc1, sh1, x2, sc2, sh2, y, P, C, relu, rb);
   return RL_LAUNCH_CHECK();
 }
-template int bn_apply<bf16_t>(hipStream_t, const bf16_t*, const float*, const float*, const bf16_t*, const float*, const float*, bf16_t*, int, int, int);
-template int bn_apply<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int, int);
+template int bn_apply<bf16_t>(hipStream_t, const bf16_t*, const float*, const float*, const bf16_t*, const float*, const float*, bf16_t*, int, int, int, RowBound);
+template int bn_apply<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int, int, RowBound);
 
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ relu_src, const T* __restrict__ x,
                                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sums, int64_t n, int C, float inv_p, T* __restrict__ dx) {
+                                    const float* __restrict__ sums, int P, int C, float inv_p, T* __restrict__ dx, RowBound rb) {
+  const int64_t n = (int64_t)rb_rows(rb, P) * C;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
     const int c = (int)(i % C);
+    const float w = rb_weight(rb, (int)(i / C));
     floatx4 g = load4<T>(dy + i);
     if (relu_src != nullptr) {
       const floatx4 o = load4<T>(relu_src + i);
@@ -247,7 +250,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
     }
     const floatx4 rs = *(const floatx4*)(rstd + c);
     const floatx4 xh = (load4<T>(x + i) - *(const floatx4*)(mean + c)) * rs;
-    const floatx4 m1 = *(const floatx4*)(sums + c) * inv_p, m2 = *(const floatx4*)(sums + C + c) * inv_p;
+    const floatx4 m1 = *(const floatx4*)(sums + c) * (inv_p * w), m2 = *(const floatx4*)(sums + C + c) * (inv_p * w);
     store4<T>(dx + i, *(const floatx4*)(gamma + c) * rs * (g - m1 - xh * m2));
   }
 }
@@ -257,16 +260,16 @@ __global__ void bn_param_grad_kernel(const float* sums, int C, float* dgamma, fl
 }
 template <typename T>
 int bn_bwd_apply(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd,
-                 const float* gamma, const float* sums, int P, int C, T* dx, float* dgamma, float* dbeta) {
+                 const float* gamma, const float* sums, int P, int C, T* dx, float* dgamma, float* dbeta, RowBound rb, int n_stat) {
   if (C & 3) return RL_ERR_ARG;
   const int64_t n = (int64_t)P * C;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, dy, relu_src, x, mean, rstd, gamma,
-                     sums, n, C, 1.0f / (float)P, dx);
+                     sums, P, C, 1.0f / (float)(n_stat > 0 ? n_stat : P), dx, rb);
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
   return RL_LAUNCH_CHECK();
 }
-template int bn_bwd_apply<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, const float*, const float*, int, int, bf16_t*, float*, float*);
-template int bn_bwd_apply<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, float*);
+template int bn_bwd_apply<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, const float*, const float*, int, int, bf16_t*, float*, float*, RowBound, int);
+template int bn_bwd_apply<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, const float*, const float*, int, int, float*, float*, float*, RowBound, int);
 
 template <typename T>
 __global__ void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ src, T* __restrict__ g, int64_t n) {
