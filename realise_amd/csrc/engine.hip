@@ -228,6 +228,8 @@ template <typename T> struct Engine : EngineBase {
       p.bn_sums = b.take(2 * 1024 * 4);
       p.gu_first = b.take((int64_t)V * 4); p.gu_flag = b.take(Tk * 4); p.gu_ids = b.take(Tk * 8); p.gu_counts = b.take(Tk * 4);
       p.gu_inv = b.take(Tk * 4); p.gu_bounds = b.take(64); p.seg_acc = b.take(Tk * H * 4);
+      tap("glyph.bounds", p.gu_bounds, 64 / (int64_t)sizeof(T)); tap("glyph.inv", p.gu_inv, Tk * 4 / (int64_t)sizeof(T));
+      tap("glyph.counts", p.gu_counts, Tk * 4 / (int64_t)sizeof(T)); tap("glyph.ids", p.gu_ids, Tk * 8 / (int64_t)sizeof(T));
       p.res_xhat = b.take(Tk * H * e); p.res_rstd = b.take(Tk * 4); p.res_h = b.take(Tk * H * e);
       p.gate_mean = b.take((int64_t)B * H * 4); p.gate_msum = b.take(B * 4 + 256); p.gate_g = b.take(Tk * 16);
       p.fused = b.take(Tk * H * e);

@@ -83,11 +83,14 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform (SGPR): LDS bases stay scalar
   const int wm = wave / WN, wn = wave - wm * WN;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
+  // A device-side row bound (glyph dedup) shrinks the tile grid: the XCD remap is applied to the LIVE tiles only, so the
+  // surplus workgroups exit at once and the live ones still spread over all 8 XCDs.
+  la.clamp_rows();
+  const int live = ((la.rows + BM_ - 1) / BM_) * tiles_n;
+  if ((int)blockIdx.x >= live) return;
+  const int tile = xcd_remap(blockIdx.x, live < ntiles ? live : ntiles);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * BM_, n0 = tn * BN_;
-  la.clamp_rows();
-  if (m0 >= la.rows) return;                          // device-side row bound (block-uniform, before any barrier)
   const void* zero = (const void*)g_zero16;
   const int lrow = lane >> 3;                        // row inside the 8-row group written by one instruction
   const int kchunk = ((lane & 7) ^ lrow) * G::VEC;   // logical K offset of the chunk this lane fetches
@@ -345,8 +348,10 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
   const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
   const int i0 = ti * BI, j0 = tj * BJ;
   lb.clamp_rows();
+  const int Pe = min(P, lb.rows);                      // device-side row bound (glyph dedup): re-split the live rows evenly
+  if (Pe < P) pchunk = (((Pe + (int)gridDim.y - 1) / (int)gridDim.y + G::BP - 1) / G::BP) * G::BP;
   const int p_begin = blockIdx.y * pchunk;
-  const int p_end = max(p_begin, min(min(P, lb.rows), p_begin + pchunk));   // rows past a device-side bound contribute zero
+  const int p_end = max(p_begin, min(Pe, p_begin + pchunk));
   const void* zero = (const void*)g_zero16;
 
   // per-lane chunk coordinates are the same for every reduction tile: only the row base moves

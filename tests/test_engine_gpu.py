@@ -199,3 +199,28 @@ def test_bert_only_config1_shapes_and_contract():
         del batch["tgt_idx"]
         out = m(batch)
         assert len(out) == 1 and out[0].shape == (8, 64, 21128)
+
+
+def test_glyph_dedup_bookkeeping():
+    """the ResNet runs once per distinct token id: slots in order of first occurrence, multiplicities, inverse map"""
+    from realise_amd.data import synthetic_batch
+    cfg = RealiseConfig(num_hidden_layers=1)
+    batch = synthetic_batch(8, 64, seed=21)
+    m = SpellBertPho2ResArch3(cfg, compute_dtype="bf16", seed=2).to("cuda").eval()
+    with torch.no_grad():
+        m(batch)
+    ids = batch["src_idx"].reshape(-1)
+    T_ = ids.numel()
+    bounds = m.tap("glyph.bounds").view(torch.int32).cpu()
+    inv = m.tap("glyph.inv").view(torch.int32)[:T_].cpu().long()
+    counts = m.tap("glyph.counts").view(torch.float32)[:T_].cpu()
+    uids = m.tap("glyph.ids").view(torch.int64)[:T_].cpu()
+    uniq = torch.unique(ids)
+    U = int(bounds[0])
+    assert U == uniq.numel() and U < T_
+    assert [int(x) for x in bounds[1:6]] == [U * 256, U * 64, U * 16, U * 4, U]
+    assert torch.equal(uids[:U][inv], ids)                                   # inverse map reproduces every token id
+    assert torch.equal(counts[:U], torch.bincount(inv, minlength=U).float())  # multiplicities
+    assert float(counts[:U].sum()) == T_
+    first_pos = torch.tensor([int((ids == u).nonzero()[0]) for u in uids[:U]])
+    assert torch.all(first_pos[1:] > first_pos[:-1])                          # deterministic: order of first occurrence
