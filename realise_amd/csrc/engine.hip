@@ -66,10 +66,10 @@ template <typename T> struct Engine : EngineBase {
     int64_t mask_add, out_d, dlogits, count, loss_internal;
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
     int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
-    int64_t bn_sums;
+    int64_t bn_sums, bn_slots;
     int64_t gu_first, gu_flag, gu_ids, gu_counts, gu_inv, gu_bounds, seg_acc;   // glyph dedup
     // backward scratch
-    int64_t gA, gB, gC, gE, gD, gF, rowdot, X1, X2, X3, dz, tn_slab;
+    int64_t gA, gB, gC, gE, gD, gF, rowdot, X1, X2, X3, dz, tn_slab, ln_slots;
     int64_t gru_dh, gru_dgi, gru_dgh, gru_onehot, gru_dtable;
     int64_t r_dout, r_dc2, r_dcs, r_dh1, r_dc1, r_dx;
   } pl;
@@ -202,6 +202,7 @@ template <typename T> struct Engine : EngineBase {
     p.gA = b.take(Tk * H * e); p.gB = b.take(Tk * H * e); p.gC = b.take(Tk * H * e); p.gE = b.take(Tk * H * e);
     p.gD = b.take(Tk * I * e); p.gF = b.take(Tk * 3 * H * e); p.rowdot = b.take((int64_t)B * nh * S * 4);
     p.tn_slab = b.take(TN_SLAB_ELEMS * 4);
+    p.ln_slots = b.take(32 * 2 * 1024 * 4);
     tap("d_x0", p.gB, Tk * H);
     if (cfg.model_type == 1) {
       plan_stack(p.pho, cfg.pho_layers, "pho_model");
@@ -226,6 +227,7 @@ template <typename T> struct Engine : EngineBase {
         hin = a.Hout;
       }
       p.bn_sums = b.take(2 * 1024 * 4);
+      p.bn_slots = b.take(32 * 2 * 1024 * 4);
       p.gu_first = b.take((int64_t)V * 4); p.gu_flag = b.take(Tk * 4); p.gu_ids = b.take(Tk * 8); p.gu_counts = b.take(Tk * 4);
       p.gu_inv = b.take(Tk * 4); p.gu_bounds = b.take(64); p.seg_acc = b.take(Tk * H * 4);
       tap("glyph.bounds", p.gu_bounds, 64 / (int64_t)sizeof(T)); tap("glyph.inv", p.gu_inv, Tk * 4 / (int64_t)sizeof(T));
@@ -345,7 +347,7 @@ template <typename T> struct Engine : EngineBase {
       const DropParams d2 = site(sid * 1000 + l * 10 + 2, cfg.hidden_dropout);
       const DropParams d1 = site(sid * 1000 + l * 10 + 1, cfg.attn_dropout);
       {  // output LayerNorm: gA = d y2 -> gB = d s2 (residual part of d y1), gC = d(dense out) = d s2 * dropmask
-        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
+        LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
         ln.gamma = pp(o.out_ln_g); ln.dx = gB; ln.dx_drop = d3.thresh ? gC : nullptr; ln.out_drop = d3;
         ln.dgamma = gp(o.out_ln_g); ln.dbeta = gp(o.out_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
@@ -362,7 +364,7 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(gemm_nt<T>(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
       }
       {  // attention-output LayerNorm: gB = d y1 -> gA = d s1, gC = d(dense out)
-        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
+        LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
         ln.gamma = pp(o.ao_ln_g); ln.dx = gA; ln.dx_drop = d2.thresh ? gC : nullptr; ln.out_drop = d2;
         ln.dgamma = gp(o.ao_ln_g); ln.dbeta = gp(o.ao_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
@@ -390,7 +392,7 @@ template <typename T> struct Engine : EngineBase {
   // embeddings backward: gA = d(embedding output) -> dx (T*, d of the pre-LayerNorm sum) ; scatters table grads
   int emb_backward(hipStream_t st, int sid, const StackOff& so, StackAct& a, const int64_t* ids, int pos_zero, const T* gA, T* dx) {
     const int B = pl.B, S = pl.S, Tk = B * S;
-    LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gA; ln.in_drop = site(sid * 1000 + 900, cfg.hidden_dropout);
+    LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.in_drop = site(sid * 1000 + 900, cfg.hidden_dropout);
     ln.xhat = wp<T>(a.emb_xhat); ln.rstd = wp<float>(a.emb_rstd); ln.gamma = pp(so.ln_g); ln.dx = dx;
     ln.dgamma = gp(so.ln_g); ln.dbeta = gp(so.ln_b);
     RL_TRY(ln_bwd<T>(st, ln));
@@ -413,6 +415,7 @@ template <typename T> struct Engine : EngineBase {
     rb.rows_dev = wp<int>(pl.gu_bounds) + 1 + k;
     rb.counts = wp<float>(pl.gu_counts);
     rb.hw = pl.blk[k].Hout * pl.blk[k].Hout;
+    rb.slots = wp<float>(pl.bn_slots);
     return rb;
   }
   // Pn = B*S*Hout^2 is the TRUE sample count of the statistics (every token counts, PADs included, as in the
@@ -677,7 +680,7 @@ template <typename T> struct Engine : EngineBase {
         g.dfused = wp<T>(pl.gB); g.dbert = wp<T>(pl.X1); g.dpho = wp<T>(pl.X2); g.dres = wp<T>(pl.X3); g.dz = wp<float>(pl.dz);
         g.dW = gp(L.gate_w); g.dbias = gp(L.gate_b);
         RL_TRY(gate_bwd<T>(st, g));
-        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = wp<T>(pl.X3); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
+        LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = wp<T>(pl.X3); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
         ln.gamma = pp(L.res_ln_g); ln.dx = wp<T>(pl.gE); ln.dgamma = gp(L.res_ln_g); ln.dbeta = gp(L.res_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
         // per-token gradient -> per-distinct-glyph gradient (sum over the tokens that share the glyph)

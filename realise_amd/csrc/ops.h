@@ -13,6 +13,7 @@ struct RowBound {
   const int* rows_dev = nullptr;
   const float* counts = nullptr;
   int hw = 1;
+  float* slots = nullptr;          // optional scratch, 32 x 2C floats: replicated accumulators for the column reductions
 };
 __device__ __forceinline__ int rb_rows(const RowBound& b, int P) { return b.rows_dev ? min(P, *b.rows_dev) : P; }
 __device__ __forceinline__ float rb_weight(const RowBound& b, int row) { return b.counts ? b.counts[row / b.hw] : 1.0f; }
@@ -50,8 +51,9 @@ template <typename T> struct LnBwdArgs {
   T* dx = nullptr;
   T* dx_drop = nullptr;            // optional second output: dx * mask(out_drop) (dense dropout before the LN)
   DropParams out_drop;
-  float* dgamma = nullptr;         // atomically accumulated
+  float* dgamma = nullptr;         // accumulated
   float* dbeta = nullptr;
+  float* slots = nullptr;          // optional scratch 32 x 2H floats: replicated accumulators (cuts atomic contention)
 };
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a);
 

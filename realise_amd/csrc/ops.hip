@@ -7,6 +7,7 @@
 namespace rl {
 
 #define RL_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH)
+__global__ void col_fold_kernel(const float* __restrict__ slots, int slot_stride, int n, float* out0, float* out1, int C);
 static constexpr int LN_MAXV = 4;   // up to 4 x (64 lanes x 4 elems) = 1024 columns per row
 
 __global__ void mask_to_additive_kernel(const int64_t* __restrict__ m, float* __restrict__ out, int n) {
@@ -151,11 +152,14 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
     for (int j = 0; j < 4; ++j) { red[0][wave][c + j] = dg[i][j]; red[1][wave][c + j] = db[i][j]; }
   }
   __syncthreads();
+  float* og = a.dgamma;
+  float* ob = a.dbeta;
+  if (a.slots != nullptr) { og = a.slots + (int64_t)(blockIdx.x & 31) * 2 * H; ob = og + H; }
   for (int c = threadIdx.x; c < H; c += 256) {
     const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
     const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    if (a.dgamma != nullptr) atomicAdd(a.dgamma + c, g);
-    if (a.dbeta != nullptr) atomicAdd(a.dbeta + c, b);
+    if (og != nullptr) atomicAdd(og + c, g);
+    if (ob != nullptr) atomicAdd(ob + c, b);
   }
 }
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
@@ -163,7 +167,12 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
   if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
   int blocks = (a.rows + 3) / 4;
   if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, a);
+  LnBwdArgs<T> b = a;
+  if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr;
+  if (b.slots != nullptr) (void)hipMemsetAsync(b.slots, 0, (size_t)32 * 2 * a.H * sizeof(float), st);
+  hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, b);
+  if (b.slots != nullptr)
+    hipLaunchKernelGGL(col_fold_kernel, dim3((2 * a.H + 255) / 256), dim3(256), 0, st, b.slots, 2 * a.H, 2 * a.H, a.dgamma, a.dbeta, a.H);
   return RL_LAUNCH_CHECK();
 }
 template int ln_bwd<bf16_t>(hipStream_t, const LnBwdArgs<bf16_t>&);
@@ -212,41 +221,67 @@ template int embed_bwd<float>(hipStream_t, const float*, const int64_t*, int, in
 // Column reductions over a row-major [rows][C] matrix: 32 threads x 4 columns wide, 8 row lanes.
 // ---------------------------------------------------------------------------------------------
 template <typename F>
-__global__ void __launch_bounds__(256) col_reduce_kernel(F f, int rows_max, int C, int rows_per_block, float* out0, float* out1,
-                                                          RowBound rb) {
-  __shared__ floatx4 red[2][8][32];
-  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int col = (blockIdx.x * 32 + cx) * 4;
+__global__ void __launch_bounds__(256) col_reduce_kernel(F f, int rows_max, int C, int tpr_shift, float* out0, float* out1, RowBound rb,
+                                                          int slot_stride) {
+  // tpr = threads per row (each owns 4 consecutive columns); 256 / tpr rows are read per pass, so a wave always touches
+  // whole contiguous rows (C = 64: 16 threads x 4 cols = one 128-byte bf16 row, 4 rows per wave-instruction).
+  __shared__ floatx4 red[2][256];
+  const int tpr = 1 << tpr_shift, rpp = 256 >> tpr_shift;
+  const int cx = threadIdx.x & (tpr - 1), ry = threadIdx.x >> tpr_shift;
+  const int col = (blockIdx.x * tpr + cx) * 4;
   const int rows = rb_rows(rb, rows_max);
-  const int r0 = blockIdx.y * rows_per_block;
-  const int r1 = min(rows, r0 + rows_per_block);
+  const int chunk = (rows + gridDim.y - 1) / gridDim.y;          // live rows are re-split evenly over the grid
+  const int r0 = blockIdx.y * chunk;
+  const int r1 = min(rows, r0 + chunk);
   floatx4 a0 = floatx4{0.f, 0.f, 0.f, 0.f}, a1 = floatx4{0.f, 0.f, 0.f, 0.f};
   if (col < C)
-    for (int r = r0 + ry; r < r1; r += 8) f(r, col, a0, a1);
-  red[0][ry][cx] = a0;
-  red[1][ry][cx] = a1;
+    for (int r = r0 + ry; r < r1; r += rpp) f(r, col, a0, a1);
+  red[0][threadIdx.x] = a0;
+  red[1][threadIdx.x] = a1;
   __syncthreads();
   if (ry == 0 && col < C) {
-#pragma unroll
-    for (int k = 1; k < 8; ++k) { a0 += red[0][k][cx]; a1 += red[1][k][cx]; }
+    for (int k = 1; k < rpp; ++k) { a0 += red[0][k * tpr + cx]; a1 += red[1][k * tpr + cx]; }
+    // slot_stride > 0: 32 replicated accumulators (folded by col_fold_kernel) cut the same-address atomic contention
+    const int64_t so = slot_stride ? (int64_t)(blockIdx.y & 31) * slot_stride : 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      atomicAdd(out0 + col + j, a0[j]);
-      if (out1 != nullptr) atomicAdd(out1 + col + j, a1[j]);
+      atomicAdd(out0 + so + col + j, a0[j]);
+      if (out1 != nullptr) atomicAdd(out1 + so + col + j, a1[j]);
     }
   }
 }
+__global__ void col_fold_kernel(const float* __restrict__ slots, int slot_stride, int n, float* out0, float* out1, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;     // i in [0, n): n = C or 2C laid out [C | C]
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < 32; ++k) s += slots[(int64_t)k * slot_stride + i];
+  if (i < C) out0[i] += s; else out1[i - C] += s;
+}
 template <typename F>
-static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float* out0, float* out1, RowBound rb = RowBound()) {
+static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float* out0, float* out1, RowBound rb = RowBound(),
+                             float* slots = nullptr) {
   if (rows <= 0 || C <= 0) return RL_OK;
   if (C & 3) return RL_ERR_ARG;
-  const int gx = (C + 127) / 128;
+  int tpr_shift = 5;
+  while (tpr_shift > 2 && (1 << tpr_shift) * 4 > C) --tpr_shift;        // 32 threads x 4 columns unless the row is narrower
+  const int tpr = 1 << tpr_shift;
+  const int gx = (C + tpr * 4 - 1) / (tpr * 4);
   int gy = 1024 / gx;
   if (gy < 1) gy = 1;
-  int rpb = (rows + gy - 1) / gy;
-  if (rpb < 64) rpb = 64;
-  gy = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, rpb, out0, out1, rb);
+  const int rpp = 256 / tpr;
+  const int max_gy = (rows + 4 * rpp - 1) / (4 * rpp);                  // at least 4 passes per workgroup
+  if (gy > max_gy) gy = max_gy;
+  if (gy < 1) gy = 1;
+  if (slots != nullptr && gy > 96) {       // many row chunks hammering C addresses: go through 32 slots of [C | C]
+    const int stride = 2 * C;
+    (void)hipMemsetAsync(slots, 0, (size_t)32 * stride * sizeof(float), st);
+    hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, tpr_shift, slots, out1 ? slots + C : nullptr,
+                       rb, stride);
+    const int n = out1 ? 2 * C : C;
+    hipLaunchKernelGGL(col_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, slots, stride, n, out0, out1, C);
+  } else {
+    hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, tpr_shift, out0, out1, rb, 0);
+  }
   return RL_LAUNCH_CHECK();
 }
 
@@ -270,7 +305,7 @@ template <typename T> struct WSumF {
 };
 template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out, RowBound rb) {
   WSumF<T> f{x, (int64_t)C, rb};
-  return launch_col_reduce(st, f, P, C, out, nullptr, rb);
+  return launch_col_reduce(st, f, P, C, out, nullptr, rb, rb.slots);
 }
 template int col_sum<bf16_t>(hipStream_t, const bf16_t*, int, int, float*, RowBound);
 template int col_sum<float>(hipStream_t, const float*, int, int, float*, RowBound);
@@ -284,7 +319,7 @@ template <typename T> struct SumSqCF {
 };
 template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out, RowBound rb) {
   SumSqCF<T> f{x, (int64_t)C, mean, rb};
-  return launch_col_reduce(st, f, P, C, out, nullptr, rb);
+  return launch_col_reduce(st, f, P, C, out, nullptr, rb, rb.slots);
 }
 template int col_sumsq_centered<bf16_t>(hipStream_t, const bf16_t*, int, int, const float*, float*, RowBound);
 template int col_sumsq_centered<float>(hipStream_t, const float*, int, int, const float*, float*, RowBound);
@@ -307,7 +342,7 @@ template <typename T>
 int bn_bwd_reduce(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd, int P, int C,
                   float* sums, RowBound rb) {
   BnBwdF<T> f{dy, relu_src, x, mean, rstd, (int64_t)C};
-  return launch_col_reduce(st, f, P, C, sums, sums + C, rb);
+  return launch_col_reduce(st, f, P, C, sums, sums + C, rb, rb.slots);
 }
 template int bn_bwd_reduce<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, int, int, float*, RowBound);
 template int bn_bwd_reduce<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, int, int, float*, RowBound);
