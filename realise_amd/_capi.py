@@ -93,6 +93,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64; it must be in the process BEFORE this library is loaded so both
+    # resolve to ONE HIP runtime (loading /opt/rocm's copy first and torch's second gives two runtimes whose
+    # streams / kernels do not mix: every launch on a torch stream then fails).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RealiseHipError(
             "librealise_hip.so is missing (%s). Build it with `python -m realise_amd.build` "
