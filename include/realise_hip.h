@@ -71,6 +71,9 @@ int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const r
 void realise_set_tn_transpose_read(int enable);
 /* A/B knob: allow the 128x96 NT tile chosen by the chip-balance heuristic (default 1) */
 void realise_set_nt_allow_n96(int on);
+/* A/B knob: 1 (default) run the glyph ResNet once per distinct token id with multiplicity-weighted BatchNorm;
+ * 0 run it densely over all B*S tokens like the reference (identical results) */
+void realise_set_glyph_dedup(int on);
 
 /* BertSelfAttention core (modeling_bert.py:239-260): softmax(QK^T/8 + mask_add) -> dropout -> .V
  * q/k/v: [B*S][ldq] token-major, head h at columns 64h..64h+63; ctx [B*S][ldc]; lse [B][nh][S]. */

@@ -184,11 +184,13 @@ def batch_norm(sd, p, x, training, new_buffers=None):
     return xh * w.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
 
 
-def basic_block(sd, p, x, training, new_buffers=None):
+def basic_block(sd, p, x, training, new_buffers=None, taps=None, tap_name=None):
     """BasicBlock.forward, char_cnn.py:9-32 (always stride 2 with a 1x1
     shortcut conv in CharResNet)."""
     r = F.conv2d(x, sd[p + "residual_function.0.weight"], None, stride=2, padding=1)
     r = torch.relu(batch_norm(sd, p + "residual_function.1.", r, training, new_buffers))
+    if taps is not None:
+        taps[tap_name + ".h1"] = r
     r = F.conv2d(r, sd[p + "residual_function.3.weight"], None, stride=1, padding=1)
     r = batch_norm(sd, p + "residual_function.4.", r, training, new_buffers)
     s = F.conv2d(x, sd[p + "shortcut.0.weight"], None, stride=2, padding=0)
@@ -200,7 +202,7 @@ def char_resnet(sd, images, training, new_buffers=None, taps=None):
     """CharResNet.forward, char_cnn.py:46-55: [N,F,32,32] -> [N,768]."""
     h = images
     for i in range(1, 6):
-        h = basic_block(sd, "resnet.res_block%d." % i, h, training, new_buffers)
+        h = basic_block(sd, "resnet.res_block%d." % i, h, training, new_buffers, taps, "resnet.block%d" % i)
         if taps is not None:
             taps["resnet.block%d" % i] = h
     return h.squeeze(-1).squeeze(-1)

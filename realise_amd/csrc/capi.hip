@@ -72,6 +72,7 @@ int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const r
 }
 void realise_set_tn_transpose_read(int enable) { set_tn_transpose_read(enable); }
 void realise_set_nt_allow_n96(int on) { set_nt_allow_n96(on); }
+void realise_set_glyph_dedup(int on) { set_glyph_dedup(on); }
 
 int realise_attention_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ldq, const float* mask_add,
                           void* ctx, int64_t ldc, float* lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh,

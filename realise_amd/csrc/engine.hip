@@ -224,10 +224,11 @@ template <typename T> struct Engine : EngineBase {
           q->mean = b.take(C * 4); q->rstd = b.take(C * 4); q->scale = b.take(C * 4); q->shift = b.take(C * 4);
         }
         tap("resnet.block" + std::to_string(k + 1), a.out, (int64_t)a.Pout * C);
+        tap("resnet.block" + std::to_string(k + 1) + ".h1", a.h1, (int64_t)a.Pout * C);
         hin = a.Hout;
       }
       p.bn_sums = b.take(2 * 1024 * 4);
-      p.bn_slots = b.take(32 * 2 * 1024 * 4);
+      p.bn_slots = b.take((int64_t)COL_SLOT_FLOATS * 4);
       p.gu_first = b.take((int64_t)V * 4); p.gu_flag = b.take(Tk * 4); p.gu_ids = b.take(Tk * 8); p.gu_counts = b.take(Tk * 4);
       p.gu_inv = b.take(Tk * 4); p.gu_bounds = b.take(64); p.seg_acc = b.take(Tk * H * 4);
       tap("glyph.bounds", p.gu_bounds, 64 / (int64_t)sizeof(T)); tap("glyph.inv", p.gu_inv, Tk * 4 / (int64_t)sizeof(T));
@@ -242,6 +243,20 @@ template <typename T> struct Engine : EngineBase {
       const int64_t big = (int64_t)p.blk[0].Pout * 64 * e;     // block 1 is the largest activation
       p.r_dout = b.take(big); p.r_dc2 = b.take(big); p.r_dcs = b.take(big); p.r_dh1 = b.take(big); p.r_dc1 = b.take(big);
       p.r_dx = b.take(big);
+    }
+    {   // named views of the scratch regions (diagnostics: tools/diag_stale.py zeroes them one at a time)
+      const int64_t e1 = (int64_t)sizeof(T);
+      auto stap = [&](const char* n, int64_t off, int64_t bytes) { tap(std::string("scratch.") + n, off, bytes / e1); };
+      stap("tn_slab", p.tn_slab, TN_SLAB_ELEMS * 4); stap("ln_slots", p.ln_slots, 32 * 2 * 1024 * 4);
+      stap("gA", p.gA, Tk * H * e); stap("gB", p.gB, Tk * H * e); stap("gC", p.gC, Tk * H * e); stap("gE", p.gE, Tk * H * e);
+      stap("gD", p.gD, Tk * I * e); stap("gF", p.gF, Tk * 3 * H * e);
+      if (cfg.model_type == 1) {
+        const int64_t big = (int64_t)p.blk[0].Pout * 64 * e;
+        stap("r_dout", p.r_dout, big); stap("r_dc2", p.r_dc2, big); stap("r_dcs", p.r_dcs, big); stap("r_dh1", p.r_dh1, big);
+        stap("r_dc1", p.r_dc1, big); stap("r_dx", p.r_dx, big); stap("bn_sums", p.bn_sums, 2 * 1024 * 4);
+        stap("bn_slots", p.bn_slots, (int64_t)COL_SLOT_FLOATS * 4); stap("seg_acc", p.seg_acc, Tk * H * 4);
+        stap("X1", p.X1, Tk * H * e); stap("X2", p.X2, Tk * H * e); stap("X3", p.X3, Tk * H * e);
+      }
     }
     p.total = b.off;
     return p;

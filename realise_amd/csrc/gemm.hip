@@ -333,7 +333,7 @@ __device__ __forceinline__ void tn_epilogue4(const TnEpi& ep, int how, int split
 template <typename T, typename BLoader, bool TR, int WI, int WJ>
 __global__ void __launch_bounds__(256, 2)
 gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, int J, int tiles_j, int ntiles,
-               int pchunk, int how, TnEpi ep) {
+               int nsplit, int pchunk, int how, TnEpi ep) {
   typedef typename MmaOf<T>::type Mma;
   typedef TnGeo<T> G;
   constexpr int BI = 64 * WI, BJ = 64 * WJ;
@@ -344,13 +344,16 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave / WJ, wj = wave - wi * WJ;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
+  // 1-D grid of (split, tile) pairs: the XCD remap hands each XCD a contiguous run of them, so the tiles of one
+  // reduction split (which share A / B row panels) sit behind one L2.
+  const int logical = xcd_remap(blockIdx.x, ntiles * nsplit);
+  const int split = logical / ntiles, tile = logical - split * ntiles;
   const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
   const int i0 = ti * BI, j0 = tj * BJ;
   lb.clamp_rows();
   const int Pe = min(P, lb.rows);                      // device-side row bound (glyph dedup): re-split the live rows evenly
-  if (Pe < P) pchunk = (((Pe + (int)gridDim.y - 1) / (int)gridDim.y + G::BP - 1) / G::BP) * G::BP;
-  const int p_begin = blockIdx.y * pchunk;
+  if (Pe < P) pchunk = (((Pe + nsplit - 1) / nsplit + G::BP - 1) / G::BP) * G::BP;
+  const int p_begin = split * pchunk;
   const int p_end = max(p_begin, min(Pe, p_begin + pchunk));
   const void* zero = (const void*)g_zero16;
 
@@ -483,7 +486,7 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      tn_epilogue4(ep, how, blockIdx.y, I, J, i0 + wi * 64 + i * 16 + l15, j0 + wj * 64 + j * 16 + 4 * g, acc[i][j]);
+      tn_epilogue4(ep, how, split, I, J, i0 + wi * 64 + i * 16 + l15, j0 + wj * 64 + j * 16 + 4 * g, acc[i][j]);
   if (do_colsum && g == 0) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -536,17 +539,17 @@ static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader
   nsplit = (P + pchunk - 1) / pchunk;
   const int how = nsplit == 1 ? TN_OUT_DIRECT : (ep.slab != nullptr ? TN_OUT_SLAB : TN_OUT_ATOMIC);
   const size_t lds = 2 * (size_t)G::BP * (BI + BJ) * sizeof(T);
-  dim3 grid(ntiles, nsplit);
+  dim3 grid(ntiles * nsplit);
   {
     ProfScope ps(st, sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos) ? PK_GEMM_TN : PK_CONV_TN, 2.0 * P * I * J);
     if (sizeof(T) == 2 && g_tn_tr) {
       static bool a1 = false;
       if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, true, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
-      hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, true, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, pchunk, how, ep);
+      hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, true, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
     } else {
       static bool a2 = false;
       if (!a2) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, false, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
-      hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, false, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, pchunk, how, ep);
+      hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, false, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
     }
     if (how == TN_OUT_SLAB) {
       const int64_t n4 = (int64_t)I * J / 4;

@@ -9,11 +9,13 @@ struct DropParams { uint32_t seed = 0, thresh = 0; float scale = 1.0f; };
 
 // Device-side row bound + per-image multiplicity for the glyph branch, which runs once per DISTINCT token id of the
 // batch: effective rows = min(P, *rows_dev); weight(row) = counts[row / hw] (the number of tokens sharing that glyph).
+constexpr int COL_SLOT_FLOATS = 262144;   // >= (row chunks) x 2C for every launch shape of the column reductions
 struct RowBound {
   const int* rows_dev = nullptr;
   const float* counts = nullptr;
   int hw = 1;
-  float* slots = nullptr;          // optional scratch, 32 x 2C floats: replicated accumulators for the column reductions
+  float* slots = nullptr;          // optional scratch of COL_SLOT_FLOATS floats: per-row-chunk partial sums, folded in a fixed order
+                                   // (bitwise reproducible BatchNorm statistics; without it the reductions use float atomics)
 };
 __device__ __forceinline__ int rb_rows(const RowBound& b, int P) { return b.rows_dev ? min(P, *b.rows_dev) : P; }
 __device__ __forceinline__ float rb_weight(const RowBound& b, int row) { return b.counts ? b.counts[row / b.hw] : 1.0f; }
@@ -147,6 +149,8 @@ template <typename T> int relu_bwd(hipStream_t st, const T* dy, const T* relu_sr
 // ids[T] -> uniq_ids[<=T] (order of first occurrence), counts[slot], inv[t] = slot of token t, and bounds[0] = U,
 // bounds[1+k] = U * hw[k] for k < nhw.  first_scratch: V ints, flag_scratch: T ints.
 struct HwList { int n = 0; int v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; };
+// dedup == 0: identity bookkeeping (every token its own slot) - the dense reference pass, for A/B runs
+void set_glyph_dedup(int on);
 int glyph_unique(hipStream_t st, const int64_t* ids, int T_, int V, int* first_scratch, int* flag_scratch, int64_t* uniq_ids,
                  float* counts, int* inv, int* bounds, HwList hw);
 // out[u][c] = sum over tokens t with inv[t] == u of x[t][c]   (fp32 scratch `acc` of T*C floats, out rows >= U untouched)

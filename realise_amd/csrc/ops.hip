@@ -7,7 +7,7 @@
 namespace rl {
 
 #define RL_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH)
-__global__ void col_fold_kernel(const float* __restrict__ slots, int slot_stride, int n, float* out0, float* out1, int C);
+__global__ void col_fold_kernel(const float* __restrict__ slots, int slot_stride, int nrec, int n, float* out0, float* out1, int C);
 static constexpr int LN_MAXV = 4;   // up to 4 x (64 lanes x 4 elems) = 1024 columns per row
 
 __global__ void mask_to_additive_kernel(const int64_t* __restrict__ m, float* __restrict__ out, int n) {
@@ -172,7 +172,7 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
   if (b.slots != nullptr) (void)hipMemsetAsync(b.slots, 0, (size_t)32 * 2 * a.H * sizeof(float), st);
   hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, b);
   if (b.slots != nullptr)
-    hipLaunchKernelGGL(col_fold_kernel, dim3((2 * a.H + 255) / 256), dim3(256), 0, st, b.slots, 2 * a.H, 2 * a.H, a.dgamma, a.dbeta, a.H);
+    hipLaunchKernelGGL(col_fold_kernel, dim3((2 * a.H + 31) / 32), dim3(256), 0, st, b.slots, 2 * a.H, 32, 2 * a.H, a.dgamma, a.dbeta, a.H);
   return RL_LAUNCH_CHECK();
 }
 template int ln_bwd<bf16_t>(hipStream_t, const LnBwdArgs<bf16_t>&);
@@ -241,21 +241,34 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(F f, int rows_max, int 
   __syncthreads();
   if (ry == 0 && col < C) {
     for (int k = 1; k < rpp; ++k) { a0 += red[0][k * tpr + cx]; a1 += red[1][k * tpr + cx]; }
-    // slot_stride > 0: 32 replicated accumulators (folded by col_fold_kernel) cut the same-address atomic contention
-    const int64_t so = slot_stride ? (int64_t)(blockIdx.y & 31) * slot_stride : 0;
+    if (slot_stride) {     // deterministic path: this row chunk's partial sums go to their own [C | C] record (col_fold_kernel adds them up)
+      float* rec = out0 + (int64_t)blockIdx.y * slot_stride;
+      *(floatx4*)(rec + col) = a0;
+      if (out1 != nullptr) *(floatx4*)(rec + C + col) = a1;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      atomicAdd(out0 + so + col + j, a0[j]);
-      if (out1 != nullptr) atomicAdd(out1 + so + col + j, a1[j]);
+      atomicAdd(out0 + col + j, a0[j]);
+      if (out1 != nullptr) atomicAdd(out1 + col + j, a1[j]);
     }
   }
 }
-__global__ void col_fold_kernel(const float* __restrict__ slots, int slot_stride, int n, float* out0, float* out1, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;     // i in [0, n): n = C or 2C laid out [C | C]
-  if (i >= n) return;
+// out[i] += sum over the nrec partial records, in a fixed order (8 strided lanes per column, then a fixed tree)
+__global__ void __launch_bounds__(256) col_fold_kernel(const float* __restrict__ slots, int slot_stride, int nrec, int n, float* out0,
+                                                        float* out1, int C) {
+  __shared__ float red[8][32];
+  const int ci = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + ci;                      // i in [0, n): n = C or 2C laid out [C | C]
   float s = 0.f;
-  for (int k = 0; k < 32; ++k) s += slots[(int64_t)k * slot_stride + i];
-  if (i < C) out0[i] += s; else out1[i - C] += s;
+  if (i < n)
+    for (int k = kl; k < nrec; k += 8) s += slots[(int64_t)k * slot_stride + i];
+  red[kl][ci] = s;
+  __syncthreads();
+  if (kl == 0 && i < n) {
+    s = ((red[0][ci] + red[1][ci]) + (red[2][ci] + red[3][ci])) + ((red[4][ci] + red[5][ci]) + (red[6][ci] + red[7][ci]));
+    if (i < C) out0[i] += s; else out1[i - C] += s;
+  }
 }
 template <typename F>
 static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float* out0, float* out1, RowBound rb = RowBound(),
@@ -272,13 +285,14 @@ static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float*
   const int max_gy = (rows + 4 * rpp - 1) / (4 * rpp);                  // at least 4 passes per workgroup
   if (gy > max_gy) gy = max_gy;
   if (gy < 1) gy = 1;
-  if (slots != nullptr && gy > 96) {       // many row chunks hammering C addresses: go through 32 slots of [C | C]
+  if (slots != nullptr) {      // per-chunk partial records + ordered fold: bitwise reproducible (gy * 2C <= COL_SLOT_FLOATS)
     const int stride = 2 * C;
-    (void)hipMemsetAsync(slots, 0, (size_t)32 * stride * sizeof(float), st);
+    if ((int64_t)gy * stride > COL_SLOT_FLOATS) gy = COL_SLOT_FLOATS / stride;
+    if (gy < 1) return RL_ERR_ARG;
     hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, tpr_shift, slots, out1 ? slots + C : nullptr,
                        rb, stride);
     const int n = out1 ? 2 * C : C;
-    hipLaunchKernelGGL(col_fold_kernel, dim3((n + 255) / 256), dim3(256), 0, st, slots, stride, n, out0, out1, C);
+    hipLaunchKernelGGL(col_fold_kernel, dim3((n + 31) / 32), dim3(256), 0, st, slots, stride, gy, n, out0, out1, C);
   } else {
     hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, tpr_shift, out0, out1, rb, 0);
   }
@@ -660,8 +674,19 @@ __global__ void gu_final_kernel(const int64_t* __restrict__ ids, int T_, const i
   inv[t] = s;
   atomicAdd(counts + s, 1.0f);
 }
+static int g_glyph_dedup = 1;
+void set_glyph_dedup(int on) { g_glyph_dedup = on; }
+__global__ void gu_identity_kernel(const int64_t* __restrict__ ids, int T_, int64_t* uniq_ids, float* counts, int* inv, int* bounds, HwList hw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < T_) { uniq_ids[t] = ids[t]; counts[t] = 1.0f; inv[t] = t; }
+  if (t == 0) { bounds[0] = T_; for (int k = 0; k < hw.n; ++k) bounds[1 + k] = T_ * hw.v[k]; }
+}
 int glyph_unique(hipStream_t st, const int64_t* ids, int T_, int V, int* first_scratch, int* flag_scratch, int64_t* uniq_ids,
                  float* counts, int* inv, int* bounds, HwList hw) {
+  if (!g_glyph_dedup) {
+    hipLaunchKernelGGL(gu_identity_kernel, dim3((T_ + 255) / 256), dim3(256), 0, st, ids, T_, uniq_ids, counts, inv, bounds, hw);
+    return RL_LAUNCH_CHECK();
+  }
   const int n = V > T_ ? V : T_;
   hipLaunchKernelGGL(gu_clear_kernel, dim3((n + 255) / 256), dim3(256), 0, st, first_scratch, V, counts, T_);
   hipLaunchKernelGGL(gu_first_kernel, dim3((T_ + 255) / 256), dim3(256), 0, st, ids, T_, first_scratch);

@@ -72,15 +72,57 @@ def test_eval_forward_bf16_within_band(golden_dir, name, model_type):
     assert agree > 0.85, agree
 
 
-def _oracle_train(model_type, cfg, sd_np, batch):
+def _oracle_train(model_type, cfg, sd_np, batch, taps=None):
     sd = oracle_state_dict(sd_np, requires_grad=True)
     nb = {}
     if model_type == "arch3":
-        loss, logits = R.arch3_forward(sd, cfg, batch, training=True, new_buffers=nb)
+        loss, logits = R.arch3_forward(sd, cfg, batch, training=True, new_buffers=nb, taps=taps)
     else:
         loss, logits = R.spellbert_forward(sd, cfg, batch, training=True)
     loss.backward()
     return sd, nb, loss, logits
+
+
+def _relu_boundary_flips(m, taps):
+    """The glyph ResNet has 10 ReLUs over ~10^7 activations per batch; one whose pre-activation is within rounding
+    (~1e-6) of zero can land on the other side than in the oracle, which legitimately selects a different subgradient
+    for everything upstream of it (tools/diag_relu_flip.py shows such a case).  Returns the deepest block (1..5) with a
+    mask disagreement (0 = masks identical) after checking that every disagreement IS such a boundary case."""
+    deepest = 0
+    T_ = taps["resnet.block1"].shape[0]
+    inv = m.tap("glyph.inv").view(torch.int32)[:T_].cpu().long()          # token -> slot of its distinct glyph
+    for k in range(1, 6):
+        for site in ("resnet.block%d" % k, "resnet.block%d.h1" % k):
+            o = taps[site].detach()
+            N, C, h, w = o.shape
+            ours = m.tap(site).float().cpu().reshape(N, h, w, C)[inv].permute(0, 3, 1, 2)
+            assert (ours - o).abs().max().item() < 5e-3, site          # tiny batches make BatchNorm ill-conditioned
+            flip = (ours > 0) != (o > 0)
+            if flip.any():
+                assert flip.sum().item() <= 4 and max(ours[flip].abs().max().item(), o[flip].abs().max().item()) < 2e-5, site
+                deepest = k
+    return deepest
+
+
+def _assert_grads_match_oracle(m, sd, flip_block, rtol, tag=""):
+    bad = []
+    for pname, p in m.named_parameters():
+        og = sd[pname].grad
+        if og is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, pname
+            continue
+        assert p.grad is not None, pname
+        mine = p.grad.cpu()
+        scale = og.abs().max().item()
+        if pname.startswith("resnet.res_block") and int(pname[len("resnet.res_block")]) <= flip_block:
+            # upstream of a boundary flip: only a few rows/channels may differ, bounded in the L2 sense
+            assert (mine - og).norm().item() <= 0.25 * og.norm().item() + 1e-6, (tag, pname)
+            continue
+        d = (mine - og).abs().max().item()
+        if d > 1e-6 + rtol * scale:
+            bad.append((d / (scale + 1e-9), d, scale, pname))
+    bad.sort(reverse=True)
+    assert not bad, "gradient mismatch vs oracle %s: %s" % (tag, bad[:8])
 
 
 @pytest.mark.parametrize("name,model_type", [("spellbert_b2s16_train", "bert"), ("arch3_b2s16_train", "arch3"),
@@ -94,23 +136,14 @@ def test_train_step_fp32_grads_match_oracle_and_golden(golden_dir, name, model_t
     torch.cuda.synchronize()
     assert abs(loss.item() - float(g["loss"])) < 1e-4
     check_summary(g, "logits", logits.float(), FP32_LOGIT_TOL)
-    sd, nb, oloss, _ = _oracle_train(model_type, cfg, sd_np, batch)
-    worst = []
+    taps = {}
+    sd, nb, oloss, _ = _oracle_train(model_type, cfg, sd_np, batch, taps)
+    flip_block = _relu_boundary_flips(m, taps) if model_type == "arch3" else 0
+    _assert_grads_match_oracle(m, sd, flip_block, 2e-3, name)
     for pname, p in m.named_parameters():
-        og = sd[pname].grad
-        if og is None:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, pname
-            continue
-        assert p.grad is not None, pname
-        d = (p.grad.cpu() - og).abs().max().item()
-        scale = og.abs().max().item()
-        worst.append((d / (scale + 1e-9), d, scale, pname))
         gk = "grad/" + pname
-        if gk + "/n" in g:
+        if gk + "/n" in g and not (pname.startswith("resnet.res_block") and int(pname[len("resnet.res_block")]) <= flip_block):
             check_summary(g, gk, p.grad, atol=2e-6 + 5e-3 * float(g[gk + "/abssum"]) / int(g[gk + "/n"]), what="grad(golden)")
-    worst.sort(reverse=True)
-    bad = [w for w in worst if w[1] > 1e-6 + 2e-3 * w[2]]
-    assert not bad, "gradient mismatch vs oracle: %s" % (bad[:8],)
     if model_type == "arch3":
         for k, v in nb.items():
             mine = m.state_dict()[k].cpu().double()
@@ -168,9 +201,8 @@ def test_dropout_training_mode_is_seeded_and_unbiased():
     l2 = m(batch)[0]
     l2.backward()
     assert l1.item() == l2.item() or abs(l1.item() - l2.item()) < 1e-5   # same seed -> same masks (atomics reorder sums)
-    # identical masks => identical gradients, up to the summation order of fp32 atomics.  Everything outside the
-    # glyph ResNet is bit-reproducible apart from that; BatchNorm statistics (atomic column sums) add ~1e-5 noise to
-    # the glyph branch that the heavily-cancelling conv weight gradients amplify (tools/diag_determinism.py).
+    # identical masks => identical gradients, up to the summation order of the fp32 atomics left in the backward
+    # (LayerNorm / embedding / segment sums); the forward, BatchNorm statistics included, is bitwise reproducible.
     g2 = m.flat_gradients()
     for name, (arena, off, shape, p) in m._views.items():
         if arena != 0 or p is None or "key.bias" in name:
@@ -178,7 +210,7 @@ def test_dropout_training_mode_is_seeded_and_unbiased():
         n = p.numel()
         a, b = g1[off:off + n], g2[off:off + n]
         rel = ((a - b).norm() / (a.norm() + 1e-12)).item()
-        assert rel < (2e-2 if name.startswith("resnet") else 1e-4), (name, rel)
+        assert rel < (1e-3 if name.startswith("resnet") else 1e-4), (name, rel)
     l3 = m(batch)[0]
     assert l3.item() != l1.item()                                         # next step -> new masks
     m.eval()
@@ -224,3 +256,78 @@ def test_glyph_dedup_bookkeeping():
     assert float(counts[:U].sum()) == T_
     first_pos = torch.tensor([int((ids == u).nonzero()[0]) for u in uids[:U]])
     assert torch.all(first_pos[1:] > first_pos[:-1])                          # deterministic: order of first occurrence
+
+
+def _edge_batch(kind):
+    """hand-built ragged / extreme batches (the reference pads every sentence to max_seq_length, run.py:68-101)"""
+    from realise_amd.data import synthetic_batch
+    if kind == "single_short":          # B=1, one real character
+        b = synthetic_batch(1, 8, seed=31)
+        b["src_idx"][0] = torch.tensor([101, 21127, 102, 0, 0, 0, 0, 0])
+        b["tgt_idx"][0] = torch.tensor([101, 670, 102, 0, 0, 0, 0, 0])
+        b["masks"][0] = torch.tensor([1, 1, 1, 0, 0, 0, 0, 0])
+        b["loss_masks"][0] = torch.tensor([0, 1, 0, 0, 0, 0, 0, 0])
+        b["pho_idx"] = torch.zeros((8, 7), dtype=torch.long)
+        b["pho_idx"][:, 0] = 32
+        b["pho_idx"][1] = torch.tensor([5, 6, 31, 17, 9, 22, 13])          # longest pinyin (7 letters)
+        b["pho_lens"] = [1, 7, 1, 1, 1, 1, 1, 1]
+        return b
+    if kind == "full_length":           # maximum size: S = 128, no padding at all
+        return synthetic_batch(2, 128, seed=32, full_length=True)
+    if kind == "ragged":                # very different lengths, S not a multiple of 16
+        b = synthetic_batch(5, 37, seed=33)
+        return b
+    if kind == "all_len1_pinyin":       # every token maps to 'U' (length 1): the GRU runs a single step
+        b = synthetic_batch(2, 16, seed=34)
+        n = 2 * 16
+        b["pho_idx"] = torch.full((n, 1), 32, dtype=torch.long)
+        b["pho_lens"] = [1] * n
+        return b
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["single_short", "full_length", "ragged", "all_len1_pinyin"])
+def test_edge_case_batches_fp32_match_oracle(kind):
+    from realise_amd.init import init_state_dict_numpy
+    cfg = RealiseConfig(num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = init_state_dict_numpy(cfg, "arch3", seed=41, scheme="perturbed")
+    batch = _edge_batch(kind)
+    m = build("arch3", cfg, sd_np, "fp32", train=True)
+    loss, logits = m(batch)
+    loss.backward()
+    torch.cuda.synchronize()
+    taps = {}
+    sd, nb, oloss, ologits = _oracle_train("arch3", cfg, sd_np, batch, taps)
+    assert abs(loss.item() - oloss.item()) < 1e-4
+    assert (logits.float().cpu() - ologits).abs().max().item() < FP32_LOGIT_TOL
+    assert torch.equal(logits.argmax(-1).cpu(), ologits.argmax(-1))
+    _assert_grads_match_oracle(m, sd, _relu_boundary_flips(m, taps), 3e-3, kind)
+
+
+def test_glyph_branch_is_bitwise_reproducible():
+    """BatchNorm statistics are folded in a fixed order (no float atomics), so two passes over the same batch give
+    identical activations and therefore identical ReLU masks (before this, a boundary activation could flip between runs)."""
+    from realise_amd.init import init_state_dict_numpy
+    cfg = RealiseConfig(num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = init_state_dict_numpy(cfg, "arch3", seed=41, scheme="perturbed")
+    batch = _edge_batch("ragged")
+    m = build("arch3", cfg, sd_np, "fp32", train=True)
+    runs = []
+    for _ in range(3):
+        m.zero_grad()
+        loss, logits = m(batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append([m.tap("resnet.block%d" % k).clone() for k in range(1, 6)] + [logits.detach().clone()])
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
+
+
+def test_rejects_sequences_longer_than_the_kernels_support():
+    from realise_amd import _capi
+    from realise_amd.data import synthetic_batch
+    cfg = RealiseConfig(num_hidden_layers=1)
+    m = SpellBert(cfg, compute_dtype="bf16").to("cuda").eval()
+    with pytest.raises(_capi.RealiseHipError):
+        m(synthetic_batch(1, 160, with_pho=False))          # the reference caps max_seq_length at 128 (run.py:304)
