@@ -71,6 +71,18 @@ int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const r
 void realise_set_tn_transpose_read(int enable);
 /* A/B knob: allow the 128x96 NT tile chosen by the chip-balance heuristic (default 1) */
 void realise_set_nt_allow_n96(int on);
+/* Diagnostics only (tools/nt_probe.cpp; results are WRONG when != 0): 1 every tile fetches tile 0's operands (cache-hot),
+ * 2 no operand fetches, 3 no MFMA work - separates the memory, issue and compute shares of the NT kernel's time. */
+void realise_set_nt_probe(int mode);
+/* Diagnostics: force an experimental NT tile shape for dense bf16 GEMMs (0 = production heuristic). */
+void realise_set_nt_variant(int v);
+/* Diagnostics for the TN kernel: 2 no operand fetches, 3 no MFMA work, 4 skip the slab fold pass. */
+void realise_set_tn_probe(int mode);
+/* Diagnostics: force the number of reduction splits of the TN kernel (0 = heuristic). */
+void realise_set_tn_split(int n);
+/* A/B knob: 1 (default) the NT epilogue goes through a per-wave LDS transpose so every global access is 16 B per lane over
+ * whole 128-byte row segments; 0 stores the MFMA fragments directly (8 B per lane). Identical results. */
+void realise_set_nt_wide_epilogue(int on);
 /* A/B knob: 1 (default) run the glyph ResNet once per distinct token id with multiplicity-weighted BatchNorm;
  * 0 run it densely over all B*S tokens like the reference (identical results) */
 void realise_set_glyph_dedup(int on);

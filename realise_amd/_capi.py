@@ -51,6 +51,11 @@ SYMBOLS = {
     "realise_conv_tn": (_I, [_P, _I, _P, _L, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _L]),
     "realise_set_tn_transpose_read": (None, [_I]),
     "realise_set_nt_allow_n96": (None, [_I]),
+    "realise_set_nt_probe": (None, [_I]),
+    "realise_set_nt_variant": (None, [_I]),
+    "realise_set_tn_probe": (None, [_I]),
+    "realise_set_tn_split": (None, [_I]),
+    "realise_set_nt_wide_epilogue": (None, [_I]),
     "realise_set_glyph_dedup": (None, [_I]),
     "realise_attention_fwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _U, _U, _F]),
     "realise_attention_bwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _U, _U, _F]),

@@ -72,6 +72,11 @@ int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const r
 }
 void realise_set_tn_transpose_read(int enable) { set_tn_transpose_read(enable); }
 void realise_set_nt_allow_n96(int on) { set_nt_allow_n96(on); }
+void realise_set_nt_probe(int mode) { set_nt_probe(mode); }
+void realise_set_nt_variant(int v) { set_nt_variant(v); }
+void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
+void realise_set_tn_split(int n) { set_tn_split(n); }
+void realise_set_nt_wide_epilogue(int on) { set_nt_wide_epilogue(on); }
 void realise_set_glyph_dedup(int on) { set_glyph_dedup(on); }
 
 int realise_attention_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ldq, const float* mask_add,

@@ -46,6 +46,27 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, floatx4 v)
   *(uint2*)p = u;
 }
 
+// ---- 8-wide load / store (16 B for bf16: one dwordx4 per lane; 32 B for f32) ---------------
+template <typename T> __device__ __forceinline__ void load8(const T* p, floatx4& a, floatx4& b);
+template <> __device__ __forceinline__ void load8<float>(const float* p, floatx4& a, floatx4& b) { a = *(const floatx4*)p; b = *(const floatx4*)(p + 4); }
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, floatx4& a, floatx4& b) {
+  const uint4 u = *(const uint4*)p;
+  a[0] = __uint_as_float(u.x << 16); a[1] = __uint_as_float(u.x & 0xffff0000u);
+  a[2] = __uint_as_float(u.y << 16); a[3] = __uint_as_float(u.y & 0xffff0000u);
+  b[0] = __uint_as_float(u.z << 16); b[1] = __uint_as_float(u.z & 0xffff0000u);
+  b[2] = __uint_as_float(u.w << 16); b[3] = __uint_as_float(u.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, floatx4 a, floatx4 b);
+template <> __device__ __forceinline__ void store8<float>(float* p, floatx4 a, floatx4 b) { *(floatx4*)p = a; *(floatx4*)(p + 4) = b; }
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, floatx4 a, floatx4 b) {
+  uint4 u;
+  u.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
+  u.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
+  u.z = (uint32_t)f2bf(b[0]) | ((uint32_t)f2bf(b[1]) << 16);
+  u.w = (uint32_t)f2bf(b[2]) | ((uint32_t)f2bf(b[3]) << 16);
+  *(uint4*)p = u;
+}
+
 // ---- MMA atoms -----------------------------------------------------------------------------
 // Both atoms compute a 16x16 fp32 tile.  Operand register layout is symmetric for the
 // two inputs: lane l supplies, for row/col index (l & 15), the K-slots owned by group
@@ -126,6 +147,26 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+// Speed-mode GELU: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below bf16 resolution) - one v_exp_f32, one
+// v_rcp_f32 and 6 FMAs instead of the ~45-instruction erff; the same exponential serves the density term of the gradient.
+// T = float (parity mode) keeps erff / expf.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& two_phi, float& e) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  e = __expf(-z * z);                                        // exp(-x^2 / 2)
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+  const float q = p * t * e;                                 // erfc(|x| / sqrt 2)
+  two_phi = x < 0.f ? q : 2.0f - q;                          // 2 * Phi(x), no cancellation in the negative tail
+}
+template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
+  if constexpr (sizeof(T) == 4) return gelu_erf(x);
+  else { float tp, e; gelu_parts_fast(x, tp, e); return 0.5f * x * tp; }
+}
+template <typename T> __device__ __forceinline__ float gelu_bwd(float x) {
+  if constexpr (sizeof(T) == 4) return gelu_erf_grad(x);
+  else { float tp, e; gelu_parts_fast(x, tp, e); return fmaf(x * 0.39894228040143267794f, e, 0.5f * tp); }
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 

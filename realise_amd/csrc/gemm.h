@@ -27,6 +27,8 @@ template <typename T> struct EpiParams {
   float drop_scale = 1.0f;
   int S = 1, nh = 1;            // EPI_QKV: tokens per sentence, heads
   int64_t qkv_plane = 0;        // EPI_QKV: elements per Q/K/V plane
+  int wide = 0;                 // set by the launcher: rows are 8-element aligned -> LDS-staged epilogue, 16 B per lane
+  int probe = 0;                // diagnostics (tools/nt_probe.cpp): 1 all tiles fetch tile 0, 2 no fetches, 3 no MFMA
 };
 
 // ---- operand loaders ---------------------------------------------------------------------------
@@ -136,6 +138,7 @@ struct TnEpi {
   // optional fused column sums of the A operand: colsum[i] += alpha * sum_p A[p,i]  (the bias gradient that goes
   // with a Linear weight gradient), computed by one extra ones-vector MFMA per A fragment in the j-tile-0 workgroups
   float* colsum = nullptr;
+  int probe = 0;            // diagnostics (tools/nt_probe.cpp): 2 no fetches, 3 no MFMA, 4 no fold pass
 };
 
 // C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)
@@ -152,6 +155,11 @@ template <typename T>
 int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& lb, int P, int I, int J, const TnEpi& ep);
 
 void set_tn_transpose_read(int use_tr);
+void set_nt_wide_epilogue(int on);        // A/B knob: LDS-staged 16-B-per-lane epilogue (default on)
+void set_tn_probe(int mode);
+void set_tn_split(int n);                 // force the reduction split of the TN kernel (0 = heuristic)
+void set_nt_variant(int v);               // experimental NT tile shapes, 0 = production heuristic
+void set_nt_probe(int mode);              // bottleneck probe of the NT kernel, 0 = off (results are wrong when on)
 void set_nt_allow_n96(int on);            // allow the 128x96 NT tile (chip-balance heuristic), default on
 
 }  // namespace rl

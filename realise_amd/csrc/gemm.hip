@@ -43,7 +43,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, 
     case EPI_GELU: {
       if (ep.out2 != nullptr) store4<T>(ep.out2 + (int64_t)row * ep.ldo + col, v);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+      for (int j = 0; j < 4; ++j) v[j] = gelu_fwd<T>(v[j]);
       store4<T>(ep.out + (int64_t)row * ep.ldo + col, v);
     } break;
     case EPI_DROP_RESID: {
@@ -56,10 +56,52 @@ __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, 
     case EPI_GELU_BWD: {
       const floatx4 x = load4<T>(ep.aux + (int64_t)row * ep.ldaux + col);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_grad(x[j]);
+      for (int j = 0; j < 4; ++j) v[j] *= gelu_bwd<T>(x[j]);
       T* o = ep.out + (int64_t)row * ep.ldo + col;
       if (ep.accumulate) v += load4<T>(o);
       store4<T>(o, v);
+    } break;
+    default: break;
+  }
+}
+
+// Same epilogues over 8 consecutive columns of one row (col % 8 == 0, N % 8 == 0): every global access is one
+// dwordx4 per lane (bf16) and a wave-instruction covers whole 128-byte row segments.
+template <typename T>
+__device__ __forceinline__ void epilogue8(const EpiParams<T>& ep, int M, int N, int row, int col, floatx4 a, floatx4 b) {
+  if (row >= M || col >= N) return;
+  if (ep.alpha != 1.0f) { a *= ep.alpha; b *= ep.alpha; }
+  if (ep.bias != nullptr) { a += *(const floatx4*)(ep.bias + col); b += *(const floatx4*)(ep.bias + col + 4); }
+  T* o = ep.out + (int64_t)row * ep.ldo + col;
+  switch (ep.mode) {
+    case EPI_STORE: {
+      if (ep.accumulate) { floatx4 pa, pb; load8<T>(o, pa, pb); a += pa; b += pb; }
+      store8<T>(o, a, b);
+    } break;
+    case EPI_GELU: {
+      if (ep.out2 != nullptr) store8<T>(ep.out2 + (int64_t)row * ep.ldo + col, a, b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = gelu_fwd<T>(a[j]); b[j] = gelu_fwd<T>(b[j]); }
+      store8<T>(o, a, b);
+    } break;
+    case EPI_DROP_RESID: {
+      const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)col;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] *= drop_mult(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + j);
+        b[j] *= drop_mult(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + 4 + j);
+      }
+      floatx4 ra, rb;
+      load8<T>(ep.aux + (int64_t)row * ep.ldaux + col, ra, rb);
+      store8<T>(o, a + ra, b + rb);
+    } break;
+    case EPI_GELU_BWD: {
+      floatx4 xa, xb;
+      load8<T>(ep.aux + (int64_t)row * ep.ldaux + col, xa, xb);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] *= gelu_bwd<T>(xa[j]); b[j] *= gelu_bwd<T>(xb[j]); }
+      if (ep.accumulate) { floatx4 pa, pb; load8<T>(o, pa, pb); a += pa; b += pb; }
+      store8<T>(o, a, b);
     } break;
     default: break;
   }
@@ -70,7 +112,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, 
 // K-tile = one 128-byte LDS row per operand row (64 bf16 / 32 f32), chunk c of row r stored at chunk
 // (c ^ (r & 7)) (KTile): conflict-free ds_read_b128 operand reads.
 // =================================================================================================
-template <typename T, typename ALoader, int WM, int WN, int NSTAGE, int NF>
+template <typename T, typename ALoader, int WM, int WN, int NSTAGE, int NF, bool SPREAD>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE == 2) ? 2 : 1)
 gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, int ntiles, EpiParams<T> ep) {
   typedef typename MmaOf<T>::type Mma;
@@ -97,10 +139,11 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
 
   typename ALoader::Ctx actx[NA];
   typename DenseLoader<T>::Ctx bctx[NB];
+  const int m0f = ep.probe == 1 ? 0 : m0, n0f = ep.probe == 1 ? 0 : n0;
 #pragma unroll
-  for (int j = 0; j < NA; ++j) actx[j] = la.prepare(m0 + (wave * NA + j) * 8 + lrow);
+  for (int j = 0; j < NA; ++j) actx[j] = la.prepare(m0f + (wave * NA + j) * 8 + lrow);
 #pragma unroll
-  for (int j = 0; j < NB; ++j) bctx[j] = lb.prepare(n0 + (wave * NB + j) * 8 + lrow);
+  for (int j = 0; j < NB; ++j) bctx[j] = lb.prepare(n0f + (wave * NB + j) * 8 + lrow);
   typename ALoader::KPos aq = la.kpos(kchunk);
   typename DenseLoader<T>::KPos bq = lb.kpos(kchunk);
   const int nk = (K + G::BK - 1) / G::BK;
@@ -133,6 +176,7 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
     for (int j = 0; j < NF; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   auto issue = [&](int stage) {                      // fetch the next K-tile, then advance the positions
+    if (ep.probe == 2) return;
     char* base = smem + stage * STAGE;
     if (kDenseA && fast) {
 #pragma unroll
@@ -152,6 +196,20 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
     }
   };
 
+  // One 1-KiB piece of the next K-tile (fast addressing only): lets the main loop spread the NA + NB fetch instructions
+  // between its MFMA groups instead of queueing them back to back behind the barrier.
+  auto issue_piece = [&](int stage, int j) {
+    char* base = smem + stage * STAGE;
+    if constexpr (kDenseA) {
+#pragma unroll
+      for (int q = 0; q < NA; ++q)
+        if (q == j) { glds16(pa[q], base + (wave * NA + q) * 1024); pa[q] += inca[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      if (NA + q == j) { glds16(pb[q], base + A_BYTES + (wave * NB + q) * 1024); pb[q] += incb[q]; }
+  };
+
   // NSTAGE-deep ring: tiles kt .. kt+NSTAGE-2 are in flight while tile kt is awaited.  LDS-DMA completion is
   // tracked by vmcnt, so the wait is a COUNTED vmcnt (leave the younger tiles outstanding) followed by a raw
   // s_barrier (a __syncthreads() here would drain vmcnt to 0 and serialise the pipeline).
@@ -162,19 +220,20 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
     if (NSTAGE == 2 || kt + 1 >= nk) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (NSTAGE == 3 || kt + 2 >= nk) {
-      if constexpr (NA + NB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if constexpr (NA + NB == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if constexpr (NA + NB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");          // one younger tile stays in flight
     } else {
-      if constexpr (NA + NB == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory");    // two younger tiles stay in flight
     }
     __builtin_amdgcn_s_barrier();                     // tile kt landed for every wave; stage (kt-1) % NSTAGE is free
     asm volatile("" ::: "memory");
-    if (kt + NSTAGE - 1 < nk) issue((kt + NSTAGE - 1) % NSTAGE);
+    const bool more = kt + NSTAGE - 1 < nk;
+    const int nstage = (kt + NSTAGE - 1) % NSTAGE;
+    constexpr bool kSpread = SPREAD && kDenseA && sizeof(T) == 2;
+    const bool spread = kSpread && fast && ep.probe == 0;
+    if (more && !spread) issue(nstage);
     const char* As = smem + (kt % NSTAGE) * STAGE;
     const char* Bs = As + A_BYTES;
+    if (ep.probe == 3) continue;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       typename Mma::Frag a[4], b[NF];
@@ -183,10 +242,37 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
 #pragma unroll
       for (int j = 0; j < NF; ++j) b[j] = ktile_frag<T, G::BK>(Bs, wn * 16 * NF + j * 16 + l15, ks, g);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = Mma::mma(b[j], a[i], acc[i][j]);
+        if constexpr (kSpread) {
+          if (spread && more) {
+            constexpr int SLOTS = 4 * G::KSTEPS, PER = (NA + NB + SLOTS - 1) / SLOTS;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) issue_piece(nstage, (ks * 4 + i) * PER + u);
+            __builtin_amdgcn_sched_barrier(0);          // keep the piece between this MFMA group and the next
+          }
+        }
+      }
     }
+  }
+  if (ep.wide) {
+    // Each wave transposes its 64 x 16NF result through a private, padded fp32 LDS tile (row stride 16NF + 4 floats:
+    // the 8-lane groups of ds_write_b128 land on 8 distinct 4-bank sets) and leaves with 8 consecutive columns per lane.
+    constexpr int RS = 16 * NF + 4, ITEMS = 2 * NF;            // floats per row ; 8-column items per row
+    __syncthreads();                                           // every wave is done reading the last K-tile
+    float* et = (float*)smem + wave * (64 * RS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) *(floatx4*)(et + (i * 16 + l15) * RS + j * 16 + 4 * g) = acc[i][j];
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+      const int e = lane + 64 * t, r = e / ITEMS, c8 = e - r * ITEMS;
+      const floatx4 v0 = *(const floatx4*)(et + r * RS + c8 * 8), v1 = *(const floatx4*)(et + r * RS + c8 * 8 + 4);
+      epilogue8<T>(ep, M, N, m0 + wm * 64 + r, n0 + wn * 16 * NF + c8 * 8, v0, v1);
+    }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -197,20 +283,31 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
 
 static int g_nt_n96 = 1;             // allow 128x96 tiles (tuning / A-B knob)
 void set_nt_allow_n96(int on) { g_nt_n96 = on; }
+static int g_nt_probe = 0, g_nt_wide = 1, g_nt_variant = 0;
+void set_nt_variant(int v) { g_nt_variant = v; }
+static int g_tn_probe = 0, g_tn_split = 0;
+void set_tn_split(int n) { g_tn_split = n; }
+void set_tn_probe(int mode) { g_tn_probe = mode; }
+void set_nt_wide_epilogue(int on) { g_nt_wide = on; }
+void set_nt_probe(int mode) { g_nt_probe = mode; }
 
-template <typename T, typename ALoader, int WM, int WN, int NSTAGE = 2, int NF = 4>
+template <typename T, typename ALoader, int WM, int WN, int NSTAGE = 2, int NF = 4, bool SPREAD = false>
 static int launch_nt_tile(hipStream_t st, const ALoader& la, const DenseLoader<T>& lb, int M, int N, int K, const EpiParams<T>& ep) {
   constexpr int BM_ = 64 * WM, BN_ = 16 * NF * WN;
   const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_;
   const int ntiles = tiles_m * tiles_n;
-  const size_t lds = NSTAGE * (size_t)(BM_ + BN_) * 128;
+  const size_t ring = NSTAGE * (size_t)(BM_ + BN_) * 128, etile = (size_t)WM * WN * 64 * (16 * NF + 4) * 4;
+  const size_t lds = ring > etile ? ring : etile;        // the epilogue re-uses the ring as per-wave transpose tiles
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   ProfScope ps(st, sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos) ? PK_GEMM_NT : PK_CONV_NT, 2.0 * M * N * K);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF>), dim3(ntiles), dim3(64 * WM * WN), lds, st, la, lb, M, N, K, tiles_n, ntiles, ep);
+  EpiParams<T> epp = ep;
+  epp.probe = g_nt_probe;
+  epp.wide = g_nt_wide && (N % 8 == 0) && (ep.ldo % 8 == 0) && (ep.aux == nullptr || ep.ldaux % 8 == 0);
+  hipLaunchKernelGGL((gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF, SPREAD>), dim3(ntiles), dim3(64 * WM * WN), lds, st, la, lb, M, N, K, tiles_n, ntiles, epp);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -229,6 +326,24 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
     const long tpc = (tiles + 255) / 256;
     return bn * (tpc == 1 ? 1.0 : 0.75 * (double)tpc);
   };
+  if constexpr (sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos) && sizeof(T) == 2) {
+    switch (g_nt_variant) {       // experimental tile shapes (tools/nt_probe.cpp)
+      case 1: return launch_nt_tile<T, ALoader, 2, 4, 2, 3>(st, la, lb, M, N, K, ep);     // 128 x 192, 8 waves, 2 stages
+      case 2: return launch_nt_tile<T, ALoader, 2, 4, 3, 3>(st, la, lb, M, N, K, ep);     // 128 x 192, 3 stages
+      case 3: return launch_nt_tile<T, ALoader, 4, 2, 2, 4>(st, la, lb, M, N, K, ep);     // 256 x 128, 2 stages
+      case 4: return launch_nt_tile<T, ALoader, 4, 2, 3, 4>(st, la, lb, M, N, K, ep);     // 256 x 128, 3 stages
+      case 5: if (g_nt_n96 && cost(96) < cost(128)) return launch_nt_tile<T, ALoader, 2, 2, 2, 3, true>(st, la, lb, M, N, K, ep);
+              return launch_nt_tile<T, ALoader, 2, 2, 2, 4, true>(st, la, lb, M, N, K, ep);   // production tiles, spread fetch issue
+      case 6: return launch_nt_tile<T, ALoader, 4, 2, 3, 4, true>(st, la, lb, M, N, K, ep);     // 256 x 128, 3 stages, spread
+      case 7: return launch_nt_tile<T, ALoader, 2, 4, 3, 3, true>(st, la, lb, M, N, K, ep);     // 128 x 192, 3 stages, spread
+      default: break;
+    }
+    // very wide outputs (the 21128-column classifier: > 20 rounds of 128x128 tiles): 8-wave 256x128 tiles cut the
+    // operand traffic per flop by a third; three stages and the fetches spread between the MFMA groups keep the single
+    // resident workgroup fed (730 vs 644 TF, tools/nt_probe.cpp).  Below ~8 rounds the 4-wave tiles win.
+    if ((long)((M + 127) / 128) * ((N + 127) / 128) >= 4096 && (K % Geo<T>::BK) == 0)
+      return launch_nt_tile<T, ALoader, 4, 2, 3, 4, true>(st, la, lb, M, N, K, ep);
+  }
   if (g_nt_n96 && cost(96) < cost(128)) return launch_nt_tile<T, ALoader, 2, 2, 2, 3>(st, la, lb, M, N, K, ep);
   return launch_nt_tile<T, ALoader, 2, 2>(st, la, lb, M, N, K, ep);
 }
@@ -421,6 +536,7 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
     }
   }
   auto issue = [&](int pt, int stage) {
+    if (ep.probe == 2) return;
     char* base = smem + stage * STAGE;
     const bool full = pt + G::BP <= p_end;
 #pragma unroll
@@ -456,6 +572,7 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
     if (pt + G::BP < p_end) issue(pt + G::BP, cur ^ 1);
     const char* At = smem + cur * STAGE;
     const char* Bt = At + A_BYTES;
+    if (ep.probe == 3) { cur ^= 1; continue; }
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       typename Mma::Frag a[4], b[4];
@@ -522,21 +639,33 @@ static int g_tn_tr = 1;   // ds_read_b64_tr_b16 verified on MI355X (tests/test_k
 void set_tn_transpose_read(int use_tr) { g_tn_tr = use_tr; }
 
 template <typename T, typename BLoader, int WI, int WJ>
-static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader& lb, int P, int I, int J, const TnEpi& ep) {
+static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader& lb, int P, int I, int J, const TnEpi& ep_) {
   typedef TnGeo<T> G;
+  TnEpi ep = ep_;
+  ep.probe = g_tn_probe;
   constexpr int BI = 64 * WI, BJ = 64 * WJ;
   const int tiles_i = (I + BI - 1) / BI, tiles_j = (J + BJ - 1) / BJ, ntiles = tiles_i * tiles_j;
-  int nsplit = (512 + ntiles - 1) / ntiles;                 // ~2 workgroups per CU
+  // Reduction split: the chip holds 512 workgroups (256 CUs x 2).  Pick the split count that minimises
+  //   rounds(split) x rows per workgroup + split x (slab write + fold read, in row-times)
+  // - a split that spills a few workgroups into a second round costs a whole extra pass (e.g. 144 tiles: 3 splits =
+  // 432 workgroups beat 4 splits = 576 by 25 %, tools/nt_probe.cpp sweep).
   const int max_split = (P + 4 * G::BP - 1) / (4 * G::BP);
-  if (nsplit > max_split) nsplit = max_split;
-  if (ep.slab != nullptr) {
-    const int64_t cap = ep.slab_elems / ((int64_t)I * J);
-    if (nsplit > cap) nsplit = (int)cap;
+  int64_t cap = max_split;
+  if (ep.slab != nullptr && ep.slab_elems / ((int64_t)I * J) < cap) cap = ep.slab_elems / ((int64_t)I * J);
+  if (cap < 1) cap = 1;
+  int nsplit = 1, pchunk = ((P + G::BP - 1) / G::BP) * G::BP;
+  {
+    double best = 1e30;
+    const double slab_rows = 1e-4 * (double)I * (double)J;
+    for (int ns = 1; ns <= (int)cap; ++ns) {
+      if (g_tn_split > 0 && ns != (g_tn_split < (int)cap ? g_tn_split : (int)cap)) continue;
+      const int pc = (((P + ns - 1) / ns + G::BP - 1) / G::BP) * G::BP;
+      const int ne = (P + pc - 1) / pc;
+      const double rounds = (double)(((int64_t)ntiles * ne + 511) / 512);
+      const double c = rounds * pc + (ne > 1 ? ne * slab_rows : 0.0);
+      if (c < best) { best = c; nsplit = ne; pchunk = pc; }
+    }
   }
-  if (nsplit < 1) nsplit = 1;
-  int pchunk = (P + nsplit - 1) / nsplit;
-  pchunk = ((pchunk + G::BP - 1) / G::BP) * G::BP;
-  nsplit = (P + pchunk - 1) / pchunk;
   const int how = nsplit == 1 ? TN_OUT_DIRECT : (ep.slab != nullptr ? TN_OUT_SLAB : TN_OUT_ATOMIC);
   const size_t lds = 2 * (size_t)G::BP * (BI + BJ) * sizeof(T);
   dim3 grid(ntiles * nsplit);
@@ -551,7 +680,7 @@ static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader
       if (!a2) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, false, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
       hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, false, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
     }
-    if (how == TN_OUT_SLAB) {
+    if (how == TN_OUT_SLAB && ep.probe != 4) {
       const int64_t n4 = (int64_t)I * J / 4;
       int blocks = (int)((n4 + 255) / 256);
       if (blocks > 2048) blocks = 2048;

@@ -1,0 +1,129 @@
+// Bottleneck probe of the NT GEMM kernel on the shapes of the BERT stacks (no torch: starts in seconds).
+//   hipcc --offload-arch=gfx950 -O2 tools/nt_probe.cpp -o gpurun_out/nt_probe -ldl && gpurun_out/nt_probe realise_amd/librealise_hip.so
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../include/realise_hip.h"
+
+typedef int (*gemm_nt_fn)(void*, int, const void*, int64_t, const void*, int64_t, int, int, int, const realise_epilogue*);
+typedef void (*seti_fn)(int);
+
+int main(int argc, char** argv) {
+  const char* path = argc > 1 ? argv[1] : "realise_amd/librealise_hip.so";
+  void* h = dlopen(path, RTLD_NOW);
+  if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+  gemm_nt_fn gemm = (gemm_nt_fn)dlsym(h, "realise_gemm_nt");
+  seti_fn probe = (seti_fn)dlsym(h, "realise_set_nt_probe");
+  seti_fn n96 = (seti_fn)dlsym(h, "realise_set_nt_allow_n96");
+  seti_fn variant = (seti_fn)dlsym(h, "realise_set_nt_variant");
+  if (!gemm || !probe) { fprintf(stderr, "missing symbols\n"); return 1; }
+  struct Shape { int M, N, K; const char* what; };
+  const Shape shapes[] = {{8192, 768, 768, "attn-out / dgrad"}, {8192, 2304, 768, "qkv"}, {8192, 3072, 768, "ffn1 / ffn2-dgrad"},
+                          {8192, 768, 3072, "ffn2 / ffn1-dgrad"}, {8192, 768, 2304, "qkv-dgrad"}, {8192, 21128, 768, "classifier"}};
+  size_t maxA = (size_t)8192 * 3072, maxB = (size_t)21128 * 768, maxC = (size_t)8192 * 21128;
+  uint16_t *A, *B, *C;
+  hipMalloc(&A, maxA * 2); hipMalloc(&B, maxB * 2); hipMalloc(&C, maxC * 2);
+  {   // uniform random bf16 in [-1, 1): zero operands would run at a higher clock
+    std::vector<uint16_t> hbuf(maxB > maxA ? maxB : maxA);
+    uint32_t s = 12345;
+    for (auto& v : hbuf) { s = s * 1664525u + 1013904223u; float f = ((s >> 8) / 8388608.0f) - 1.0f; uint32_t u; memcpy(&u, &f, 4); v = (uint16_t)(u >> 16); }
+    hipMemcpy(A, hbuf.data(), maxA * 2, hipMemcpyHostToDevice); hipMemcpy(B, hbuf.data(), maxB * 2, hipMemcpyHostToDevice);
+  }
+  hipStream_t st; hipStreamCreate(&st);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  seti_fn wide = (seti_fn)dlsym(h, "realise_set_nt_wide_epilogue");
+  uint16_t *C2, *AUX; float* bias;
+  hipMalloc(&C2, (size_t)8192 * 3072 * 2); hipMalloc(&AUX, (size_t)8192 * 3072 * 2); hipMalloc(&bias, 21128 * 4);
+  hipMemcpy(AUX, A, (size_t)8192 * 3072 * 2, hipMemcpyDeviceToDevice); hipMemset(bias, 0, 21128 * 4);
+  auto run = [&](const Shape& sh, int epi) {
+    realise_epilogue ep; memset(&ep, 0, sizeof(ep));
+    ep.mode = epi; ep.out = C; ep.ldo = sh.N; ep.alpha = 1.0f; ep.drop_scale = 1.0f;
+    if (epi != 0) ep.bias = bias;
+    if (epi == 1) ep.out2 = C2;
+    if (epi == 2) { ep.aux = AUX; ep.ldaux = sh.N; ep.drop_seed = 77; ep.drop_thresh = 429496730u; ep.drop_scale = 1.0f / 0.9f; }
+    if (epi == 4) { ep.aux = AUX; ep.ldaux = sh.N; ep.bias = nullptr; }
+    for (int i = 0; i < 3; ++i) gemm(st, 1, A, sh.K, B, sh.K, sh.M, sh.N, sh.K, &ep);
+    const int reps = 20;
+    hipEventRecord(e0, st);
+    for (int i = 0; i < reps; ++i) gemm(st, 1, A, sh.K, B, sh.K, sh.M, sh.N, sh.K, &ep);
+    hipEventRecord(e1, st); hipEventSynchronize(e1);
+    float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1000.0 / reps;
+  };
+  const int nvar = variant ? (argc > 2 ? atoi(argv[2]) : 1) : 1;
+  for (int v = 0; v < nvar; ++v) {
+    if (variant) variant(v);
+    for (const Shape& sh : shapes) {
+      printf("variant %d  %5d x %5d x %4d %-18s", v, sh.M, sh.N, sh.K, sh.what);
+      for (int mode = 0; mode <= 3; ++mode) {
+        probe(mode);
+        const double us = run(sh, 0);
+        printf(" | m%d %6.1f us %5.0f TF", mode, us, 2.0 * sh.M * sh.N * sh.K / us * 1e-6);
+      }
+      probe(0);
+      printf("\n     epilogues (direct -> wide, us):");
+      const int epis[4] = {0, 1, 2, 4};
+      const char* names[4] = {"store", "gelu+pre", "drop+resid", "gelu_bwd"};
+      for (int k = 0; k < 4; ++k) {
+        if (sh.N > 3072 && k > 0) break;
+        double t[2];
+        for (int w = 0; w < 2; ++w) { if (wide) wide(w); t[w] = run(sh, epis[k]); }
+        printf("  %s %.1f -> %.1f", names[k], t[0], t[1]);
+      }
+      if (wide) wide(1);
+      printf("\n");
+    }
+  }
+  probe(0);
+  {   // weight-gradient shapes: out[I,J] += sum_p A[p,i] B[p,j], P = 8192 (kernel + fold)
+    typedef int (*gemm_tn_fn)(void*, int, const void*, int64_t, const void*, int64_t, int, int, int, float*, int64_t, float*, int64_t, float*);
+    gemm_tn_fn tn = (gemm_tn_fn)dlsym(h, "realise_gemm_tn");
+    seti_fn tnprobe = (seti_fn)dlsym(h, "realise_set_tn_probe");
+    float *out, *slab, *colsum;
+    const int64_t slab_elems = 16 * 1024 * 1024;
+    hipMalloc(&out, (size_t)3072 * 3072 * 4); hipMalloc(&slab, slab_elems * 4); hipMalloc(&colsum, 21128 * 4);
+    hipMemset(out, 0, (size_t)3072 * 3072 * 4); hipMemset(colsum, 0, 21128 * 4);
+    const Shape tshapes[] = {{8192, 768, 768, "attn-out wgrad"}, {8192, 2304, 768, "qkv wgrad"}, {8192, 3072, 768, "ffn1 wgrad"},
+                             {8192, 768, 3072, "ffn2 wgrad"}};
+    for (const Shape& sh : tshapes) {
+      printf("TN  P %5d  I %5d  J %5d %-16s", sh.M, sh.N, sh.K, sh.what);
+      for (int mode = 0; mode <= (tnprobe ? 4 : 0); ++mode) {
+        if (mode == 1) continue;
+        if (tnprobe) tnprobe(mode);
+        for (int i = 0; i < 3; ++i) tn(st, 1, A, sh.N, AUX, sh.K, sh.M, sh.N, sh.K, out, sh.K, slab, slab_elems, colsum);
+        const int reps = 20;
+        hipEventRecord(e0, st);
+        for (int i = 0; i < reps; ++i) tn(st, 1, A, sh.N, AUX, sh.K, sh.M, sh.N, sh.K, out, sh.K, slab, slab_elems, colsum);
+        hipEventRecord(e1, st); hipEventSynchronize(e1);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+        const double us = ms * 1000.0 / reps;
+        printf(" | m%d %6.1f us %5.0f TF", mode, us, 2.0 * sh.M * sh.N * sh.K / us * 1e-6);
+      }
+      printf("\n");
+    }
+    if (tnprobe) tnprobe(0);
+    seti_fn tnsplit = (seti_fn)dlsym(h, "realise_set_tn_split");
+    if (tnsplit) {
+      for (const Shape& sh : tshapes) {
+        printf("TN split sweep I %5d J %5d:", sh.N, sh.K);
+        for (int ns = 1; ns <= 16; ++ns) {
+          if (ns > 8 && (ns & 1) && ns != 13 && ns != 15) continue;
+          tnsplit(ns);
+          for (int i = 0; i < 2; ++i) tn(st, 1, A, sh.N, AUX, sh.K, sh.M, sh.N, sh.K, out, sh.K, slab, slab_elems, colsum);
+          const int reps = 10;
+          hipEventRecord(e0, st);
+          for (int i = 0; i < reps; ++i) tn(st, 1, A, sh.N, AUX, sh.K, sh.M, sh.N, sh.K, out, sh.K, slab, slab_elems, colsum);
+          hipEventRecord(e1, st); hipEventSynchronize(e1);
+          float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+          printf(" %d:%.1f", ns, ms * 1000.0 / reps);
+        }
+        printf("\n");
+      }
+      tnsplit(0);
+    }
+  }
+  return 0;
+}
