@@ -51,7 +51,10 @@ template <typename T> struct Engine : EngineBase {
   BlockSh sh_blk[5];
   int64_t sh_cls_w = 0, sh_cls_wT = 0, sh_gru_hh = 0, sh_gru_hhT = 0, sh_glyph = 0;
   int64_t shadow_total = 0;
-  bool glyph_built = false;
+  bool glyph_built = false, descs_built = false;
+  int64_t sh_descs = 0;
+  int n_descs = 0, desc_tiles = 0;
+  std::vector<CastDesc> desc_host;
 
   // ---------------------------------------------------------------- workspace plan (byte offsets)
   struct LayerAct { int64_t qkv, lse, ctx, s1, rstd1, y1, pre, post, s2, rstd2, y2; };
@@ -127,6 +130,7 @@ template <typename T> struct Engine : EngineBase {
       const int gs = cfg.glyph_size;
       sh_glyph = b.take((int64_t)V * gs * gs * 8 * e);
     }
+    sh_descs = b.take(256 * (int64_t)sizeof(CastDesc));      // device table for the one-launch refresh of the Linear weights
     shadow_total = b.off;
   }
 
@@ -134,22 +138,39 @@ template <typename T> struct Engine : EngineBase {
 
   int refresh_shadows(hipStream_t st) override {
     if (!sh) return RL_ERR_ARG;
-    auto do_stack = [&](const StackOff& so, const std::vector<LayerSh>& v) -> int {
-      for (size_t l = 0; l < v.size(); ++l) {
-        const LayerOff& o = so.layers[l];
-        RL_TRY(cast_transpose<T>(st, pp(o.qkv_w), 3 * H, H, sp<T>(v[l].qkv_w), sp<T>(v[l].qkv_wT)));
-        RL_TRY(cast_transpose<T>(st, pp(o.ao_w), H, H, sp<T>(v[l].ao_w), sp<T>(v[l].ao_wT)));
-        RL_TRY(cast_transpose<T>(st, pp(o.in_w), I, H, sp<T>(v[l].in_w), sp<T>(v[l].in_wT)));
-        RL_TRY(cast_transpose<T>(st, pp(o.out_w), H, I, sp<T>(v[l].out_w), sp<T>(v[l].out_wT)));
+    if (!descs_built) {          // every Linear weight -> (W, W^T) operand copies, one launch per refresh
+      std::vector<CastDesc>& d = desc_host;       // member: stays alive while the async upload is in flight
+      d.clear();
+      int tiles = 0;
+      auto add = [&](int64_t src, int R, int C, int64_t dst, int64_t dstT) {
+        CastDesc x;
+        x.src = pp(src); x.dst = sp<T>(dst); x.dstT = sp<T>(dstT); x.R = R; x.C = C;
+        x.tile_begin = tiles; x.tiles_c = (C + 63) / 64;
+        tiles += x.tiles_c * ((R + 63) / 64);
+        d.push_back(x);
+      };
+      auto add_stack = [&](const StackOff& so, const std::vector<LayerSh>& v) {
+        for (size_t l = 0; l < v.size(); ++l) {
+          const LayerOff& o = so.layers[l];
+          add(o.qkv_w, 3 * H, H, v[l].qkv_w, v[l].qkv_wT);
+          add(o.ao_w, H, H, v[l].ao_w, v[l].ao_wT);
+          add(o.in_w, I, H, v[l].in_w, v[l].in_wT);
+          add(o.out_w, H, I, v[l].out_w, v[l].out_wT);
+        }
+      };
+      add_stack(L.bert, sh_bert);
+      add(L.cls_w, V, H, sh_cls_w, sh_cls_wT);
+      if (cfg.model_type == 1) {
+        add_stack(L.pho, sh_pho);
+        add_stack(L.outb, sh_out);
+        add(L.gru_w_hh, 3 * H, H, sh_gru_hh, sh_gru_hhT);
       }
-      return RL_OK;
-    };
-    RL_TRY(do_stack(L.bert, sh_bert));
-    RL_TRY(cast_transpose<T>(st, pp(L.cls_w), V, H, sp<T>(sh_cls_w), sp<T>(sh_cls_wT)));
+      if (d.size() > 256) return RL_ERR_ARG;
+      if (hipMemcpyAsync(sh + sh_descs, d.data(), d.size() * sizeof(CastDesc), hipMemcpyHostToDevice, st) != hipSuccess) return RL_ERR_LAUNCH;
+      n_descs = (int)d.size(); desc_tiles = tiles; descs_built = true;
+    }
+    RL_TRY(cast_transpose_multi<T>(st, (const CastDesc*)(sh + sh_descs), n_descs, desc_tiles));
     if (cfg.model_type == 1) {
-      RL_TRY(do_stack(L.pho, sh_pho));
-      RL_TRY(do_stack(L.outb, sh_out));
-      RL_TRY(cast_transpose<T>(st, pp(L.gru_w_hh), 3 * H, H, sp<T>(sh_gru_hh), sp<T>(sh_gru_hhT)));
       for (int k = 0; k < 5; ++k) {
         const BlockOff& o = L.blocks[k];
         const BlockSh& s = sh_blk[k];
@@ -269,7 +290,7 @@ template <typename T> struct Engine : EngineBase {
     return p.total;
   }
   int bind(void* shadow, void* workspace, int64_t bytes) override {
-    if (shadow != (void*)sh) glyph_built = false;
+    if (shadow != (void*)sh) { glyph_built = false; descs_built = false; }
     sh = (char*)shadow; ws = (char*)workspace; ws_bytes = bytes; pl = Plan(); have_fwd = false;
     return RL_OK;
   }

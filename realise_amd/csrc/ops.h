@@ -160,6 +160,10 @@ template <typename T> int segment_sum(hipStream_t st, const T* x, const int* inv
 template <typename T> int cast_copy(hipStream_t st, const float* src, T* dst, int64_t n);
 // src fp32 [R][C] -> dst [R][C] (optional) and dstT [C][R] (optional)
 template <typename T> int cast_transpose(hipStream_t st, const float* src, int R, int C, T* dst, T* dstT);
+// many matrices in ONE launch (the per-step refresh of every Linear weight's W and W^T operand copies): `descs` is a
+// device array of n descriptors sorted by tile_begin, total_tiles 64x64 tiles overall
+struct CastDesc { const float* src; void* dst; void* dstT; int R, C; int tile_begin, tiles_c; };
+template <typename T> int cast_transpose_multi(hipStream_t st, const CastDesc* descs, int n, int total_tiles);
 // conv weight [Co][Ci][KH][KW] fp32 -> fwd [Co][KH*KW][Cpad] and dgrad [Ci_rows][KH*KW][Co] (rows >= Ci zero)
 template <typename T>
 int conv_weight_shadow(hipStream_t st, const float* w, int Co, int Ci, int KHW, int Cpad, int CiRows, T* fwd, T* dgrad);

@@ -254,20 +254,26 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(F f, int rows_max, int 
     }
   }
 }
-// out[i] += sum over the nrec partial records, in a fixed order (8 strided lanes per column, then a fixed tree)
+// out[i] += sum over the nrec partial records, in a fixed order: 32 record lanes per column quad (each adds records
+// k, k + 32, ... in order), then a fixed pairwise tree over the 32 lane sums.  One workgroup per 32 columns.
 __global__ void __launch_bounds__(256) col_fold_kernel(const float* __restrict__ slots, int slot_stride, int nrec, int n, float* out0,
                                                         float* out1, int C) {
-  __shared__ float red[8][32];
-  const int ci = threadIdx.x & 31, kl = threadIdx.x >> 5;
-  const int i = blockIdx.x * 32 + ci;                      // i in [0, n): n = C or 2C laid out [C | C]
-  float s = 0.f;
+  __shared__ floatx4 red[32][8];
+  const int cq = threadIdx.x & 7, kl = threadIdx.x >> 3;
+  const int i = (blockIdx.x * 8 + cq) * 4;                 // i in [0, n): n = C or 2C laid out [C | C], C % 4 == 0
+  floatx4 s = floatx4{0.f, 0.f, 0.f, 0.f};
   if (i < n)
-    for (int k = kl; k < nrec; k += 8) s += slots[(int64_t)k * slot_stride + i];
-  red[kl][ci] = s;
+    for (int k = kl; k < nrec; k += 32) s += *(const floatx4*)(slots + (int64_t)k * slot_stride + i);
+  red[kl][cq] = s;
   __syncthreads();
+#pragma unroll
+  for (int w = 16; w > 0; w >>= 1) {
+    if (kl < w) red[kl][cq] += red[kl + w][cq];
+    __syncthreads();
+  }
   if (kl == 0 && i < n) {
-    s = ((red[0][ci] + red[1][ci]) + (red[2][ci] + red[3][ci])) + ((red[4][ci] + red[5][ci]) + (red[6][ci] + red[7][ci]));
-    if (i < C) out0[i] += s; else out1[i - C] += s;
+    float* o = i < C ? out0 + i : out1 + (i - C);
+    *(floatx4*)o += red[0][cq];
   }
 }
 template <typename F>

@@ -334,6 +334,57 @@ template <typename T> int cast_transpose(hipStream_t st, const float* src, int R
   hipLaunchKernelGGL((cast_transpose_kernel<T>), dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, src, R, C, dst, dstT);
   return RL_LAUNCH_CHECK();
 }
+// 64 x 64 tiles, 16 B fp32 reads / 4-element writes; the transposed copy goes through a padded LDS tile so both outputs
+// are written in 128-byte (bf16) row segments.
+template <typename T>
+__global__ void __launch_bounds__(256) cast_transpose_multi_kernel(const CastDesc* __restrict__ descs, int n) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = n - 1;                               // last descriptor with tile_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = descs[lo];
+  const int t = blockIdx.x - d.tile_begin;
+  const int r0 = (t / d.tiles_c) * 64, c0 = (t % d.tiles_c) * 64;
+  const int q = threadIdx.x & 15, y = threadIdx.x >> 4;     // 16 quads x 16 rows per pass
+  T* dst = (T*)d.dst;
+  T* dstT = (T*)d.dstT;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + y + 16 * k, c = c0 + 4 * q;
+    floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (r < d.R && c < d.C) {                           // C % 4 == 0
+      v = *(const floatx4*)(d.src + (int64_t)r * d.C + c);
+      if (dst != nullptr) store4<T>(dst + (int64_t)r * d.C + c, v);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[y + 16 * k][4 * q + j] = v[j];
+  }
+  __syncthreads();
+  if (dstT == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + y + 16 * k, r = r0 + 4 * q;
+    if (c < d.C && r < d.R) {
+      if (r + 3 < d.R && (d.R & 3) == 0) {
+        floatx4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = tile[4 * q + j][y + 16 * k];
+        store4<T>(dstT + (int64_t)c * d.R + r, v);
+      } else {
+        for (int j = 0; j < 4 && r + j < d.R; ++j) dstT[(int64_t)c * d.R + r + j] = from_f<T>(tile[4 * q + j][y + 16 * k]);
+      }
+    }
+  }
+}
+template <typename T> int cast_transpose_multi(hipStream_t st, const CastDesc* descs, int n, int total_tiles) {
+  if (n <= 0 || total_tiles <= 0) return RL_OK;
+  hipLaunchKernelGGL((cast_transpose_multi_kernel<T>), dim3(total_tiles), dim3(256), 0, st, descs, n);
+  return RL_LAUNCH_CHECK();
+}
+template int cast_transpose_multi<bf16_t>(hipStream_t, const CastDesc*, int, int);
+template int cast_transpose_multi<float>(hipStream_t, const CastDesc*, int, int);
 template int cast_transpose<bf16_t>(hipStream_t, const float*, int, int, bf16_t*, bf16_t*);
 template int cast_transpose<float>(hipStream_t, const float*, int, int, float*, float*);
 

@@ -78,6 +78,24 @@ int main(int argc, char** argv) {
     }
   }
   probe(0);
+  if (variant) variant(0);
+  {   // sustained run: the four forward GEMMs of a layer, cycling through 19 different weight sets for ~0.3 s
+    uint16_t* W; const size_t wl = (size_t)(2304 + 768 + 3072 + 3072) * 768;
+    hipMalloc(&W, wl * 19 * 2); hipMemset(W, 0x3c, wl * 19 * 2);
+    const Shape ls[4] = {{8192, 2304, 768, "qkv"}, {8192, 768, 768, "attn-out"}, {8192, 3072, 768, "ffn1"}, {8192, 768, 3072, "ffn2"}};
+    const size_t woff[4] = {0, (size_t)2304 * 768, (size_t)(2304 + 768) * 768, (size_t)(2304 + 768 + 3072) * 768};
+    realise_epilogue ep; memset(&ep, 0, sizeof(ep)); ep.out = C; ep.alpha = 1.0f; ep.drop_scale = 1.0f;
+    for (int pass = 0; pass < 2; ++pass) {
+      const int layers = pass == 0 ? 19 : 19 * 100;
+      hipEventRecord(e0, st);
+      for (int l = 0; l < layers; ++l)
+        for (int k = 0; k < 4; ++k) { ep.ldo = ls[k].N; gemm(st, 1, A, ls[k].K, W + (size_t)(l % 19) * wl + woff[k], ls[k].K, ls[k].M, ls[k].N, ls[k].K, &ep); }
+      hipEventRecord(e1, st); hipEventSynchronize(e1);
+      float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+      printf("sustained: %d layers x 4 GEMMs, %.1f us per layer (isolated sum of the four: see m0 above), %.0f TF\n", layers, ms * 1000.0 / layers,
+             2.0 * 8192 * 768 * (2304 + 768 + 3072 + 3072) * layers / (ms * 1e-3) * 1e-12);
+    }
+  }
   {   // weight-gradient shapes: out[I,J] += sum_p A[p,i] B[p,j], P = 8192 (kernel + fold)
     typedef int (*gemm_tn_fn)(void*, int, const void*, int64_t, const void*, int64_t, int, int, int, float*, int64_t, float*, int64_t, float*);
     gemm_tn_fn tn = (gemm_tn_fn)dlsym(h, "realise_gemm_tn");
