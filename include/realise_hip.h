@@ -107,6 +107,10 @@ int realise_layernorm_bwd(void* stream, int dtype, const void* dy, const void* x
 int realise_masked_ce(void* stream, int dtype, const void* logits, int64_t ld, const int64_t* labels,
                       const int64_t* loss_mask, int rows, int V, float* loss_out, float* count_scratch, void* dlogits);
 
+/* Eval decode: ids[row] = argmax over the V logits of the row, first maximum wins - replaces
+ * `logits.detach().cpu().numpy()` + `np.argmax(preds, axis=-1)` (src/run.py:262-263): only the ids cross PCIe. */
+int realise_argmax(void* stream, int dtype, const void* logits, int64_t ld, int rows, int V, int64_t* ids);
+
 /* ------------------------------------------------------------------------------------------
  * Whole-model engine: SpellBert.forward (models.py:50-73) / SpellBertPho2ResArch3.forward
  * (models.py:806-870) and their autograd (`loss.backward()`, run.py:200), one C call each.

@@ -63,6 +63,7 @@ SYMBOLS = {
     "realise_layernorm_fwd": (_I, [_P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I]),
     "realise_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I]),
     "realise_masked_ce": (_I, [_P, _I, _P, _L, _P, _P, _I, _I, _P, _P, _P]),
+    "realise_argmax": (_I, [_P, _I, _P, _L, _I, _I, _P]),
     "realise_layout_count": (_I, [C.POINTER(Config)]),
     "realise_layout_entry": (_I, [C.POINTER(Config), _I, C.c_char_p, _I, C.POINTER(C.c_int32), C.POINTER(_L),
                                   C.POINTER(C.c_int32), C.POINTER(_L)]),

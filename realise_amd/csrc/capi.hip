@@ -139,6 +139,12 @@ int realise_layernorm_bwd(void* stream, int dtype, const void* dy, const void* x
   }
   return RL_ERR_ARG;
 }
+int realise_argmax(void* stream, int dtype, const void* logits, int64_t ld, int rows, int V, int64_t* ids) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1) return argmax_rows<bf16_t>(st, (const bf16_t*)logits, ld, rows, V, ids);
+  if (dtype == 0) return argmax_rows<float>(st, (const float*)logits, ld, rows, V, ids);
+  return RL_ERR_ARG;
+}
 int realise_masked_ce(void* stream, int dtype, const void* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask,
                       int rows, int V, float* loss_out, float* count_scratch, void* dlogits) {
   hipStream_t st = (hipStream_t)stream;

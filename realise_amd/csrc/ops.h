@@ -74,6 +74,10 @@ template <typename T>
 int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask, int rows, int V,
             float* loss_out, float* count_buf, T* dlogits);
 
+// ---- eval decode (run.py:262-263): ids[row] = argmax_v logits[row][v], first maximum wins (numpy / torch semantics), a NaN
+// counts as the maximum.  Only the ids leave the device (32 KB instead of the 692 MB fp32 logits of run.py:262).
+template <typename T> int argmax_rows(hipStream_t st, const T* logits, int64_t ld, int rows, int V, int64_t* ids);
+
 // ---- gate fusion (K11) --------------------------------------------------------------------------
 template <typename T> struct GateArgs {
   int B = 0, S = 0, H = 0;

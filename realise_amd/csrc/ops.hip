@@ -181,16 +181,23 @@ template int ln_bwd<float>(hipStream_t, const LnBwdArgs<float>&);
 // ---------------------------------------------------------------------------------------------
 // Embedding backward: thread owns 4 columns of one sequence position s and walks the batch.
 // ---------------------------------------------------------------------------------------------
+// Padded positions receive an exactly-zero gradient (masked as attention keys, excluded from the loss and from the
+// masked mean), and they all carry token id 0: skipping all-zero quads is exact and removes the thousands-way
+// same-address atomic pile-up on that one embedding row.
+__device__ __forceinline__ bool quad_is_zero(floatx4 d) { return d[0] == 0.f && d[1] == 0.f && d[2] == 0.f && d[3] == 0.f; }
 template <typename T>
 __global__ void embed_bwd_kernel(const T* __restrict__ de, const int64_t* __restrict__ ids, int B, int S, int H,
                                  float* word_grad, float* pos_grad, int pos_zero, float* type_grad) {
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int s = blockIdx.y;
   if (c >= H) return;
+  const int bchunk = (B + gridDim.z - 1) / gridDim.z;
+  const int b0 = blockIdx.z * bchunk, b1 = min(B, b0 + bchunk);
   floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
-  for (int b = 0; b < B; ++b) {
+  for (int b = b0; b < b1; ++b) {
     const int64_t row = (int64_t)b * S + s;
     const floatx4 d = load4<T>(de + row * H + c);
+    if (quad_is_zero(d)) continue;
     acc += d;
     if (word_grad != nullptr) {
       float* w = word_grad + ids[row] * H + c;
@@ -198,6 +205,7 @@ __global__ void embed_bwd_kernel(const T* __restrict__ de, const int64_t* __rest
       for (int j = 0; j < 4; ++j) atomicAdd(w + j, d[j]);
     }
   }
+  if (quad_is_zero(acc)) return;
   float* p = pos_grad + (int64_t)(pos_zero ? 0 : s) * H + c;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -210,7 +218,8 @@ int embed_bwd(hipStream_t st, const T* de, const int64_t* ids, int B, int S, int
               int pos_zero, float* type_grad) {
   if (H & 3) return RL_ERR_ARG;
   const int tx = 64;
-  hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3((H / 4 + tx - 1) / tx, S), dim3(tx), 0, st, de, ids, B, S, H, word_grad,
+  const int bz = B >= 32 ? 8 : (B >= 8 ? 4 : 1);
+  hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3((H / 4 + tx - 1) / tx, S, bz), dim3(tx), 0, st, de, ids, B, S, H, word_grad,
                      pos_grad, pos_zero, type_grad);
   return RL_LAUNCH_CHECK();
 }
@@ -707,6 +716,7 @@ __global__ void segsum_scatter_kernel(const T* __restrict__ x, const int* __rest
   const int t = blockIdx.y;
   if (c >= C) return;
   const floatx4 v = load4<T>(x + (int64_t)t * C + c);
+  if (quad_is_zero(v)) return;                       // padded tokens: exact zeros, all on the slot of token id 0
   float* o = acc + (int64_t)inv[t] * C + c;
 #pragma unroll
   for (int j = 0; j < 4; ++j) atomicAdd(o + j, v[j]);
@@ -726,5 +736,56 @@ template <typename T> int segment_sum(hipStream_t st, const T* x, const int* inv
 }
 template int segment_sum<bf16_t>(hipStream_t, const bf16_t*, const int*, int, int, float*, bf16_t*, const int*);
 template int segment_sum<float>(hipStream_t, const float*, const int*, int, int, float*, float*, const int*);
+
+// ---------------------------------------------------------------------------------------------
+// Row-wise argmax: one 256-thread workgroup per row, 16-byte loads, (value, index) pairs reduced with the
+// first-occurrence tie rule.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool amax_better(float v, int i, float bv, int bi) {
+  const bool vn = v != v, bn = bv != bv;
+  if (vn || bn) return vn && (!bn || i < bi);
+  return v > bv || (v == bv && i < bi);
+}
+template <typename T>
+__global__ void __launch_bounds__(256) argmax_kernel(const T* __restrict__ logits, int64_t ld, int V, int64_t* __restrict__ ids) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const T* row = logits + (int64_t)blockIdx.x * ld;
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  const int v8 = ((ld & 7) == 0) ? (V & ~7) : 0;          // 8-wide body when every row start is 16-byte aligned
+  for (int c = threadIdx.x * 8; c < v8; c += 256 * 8) {
+    floatx4 a, b;
+    load8<T>(row + c, a, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (amax_better(a[j], c + j, bv, bi)) { bv = a[j]; bi = c + j; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (amax_better(b[j], c + 4 + j, bv, bi)) { bv = b[j]; bi = c + 4 + j; }
+  }
+  for (int c = v8 + threadIdx.x; c < V; c += 256) {
+    const float v = to_f<T>(row[c]);
+    if (amax_better(v, c, bv, bi)) { bv = v; bi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(bv, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (amax_better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) if (amax_better(sv[w], si[w], bv, bi)) { bv = sv[w]; bi = si[w]; }
+    ids[blockIdx.x] = bi;
+  }
+}
+template <typename T> int argmax_rows(hipStream_t st, const T* logits, int64_t ld, int rows, int V, int64_t* ids) {
+  if (rows <= 0) return RL_OK;
+  if (V <= 0 || ld < V) return RL_ERR_ARG;
+  hipLaunchKernelGGL((argmax_kernel<T>), dim3(rows), dim3(256), 0, st, logits, ld, V, ids);
+  return RL_LAUNCH_CHECK();
+}
+template int argmax_rows<bf16_t>(hipStream_t, const bf16_t*, int64_t, int, int, int64_t*);
+template int argmax_rows<float>(hipStream_t, const float*, int64_t, int, int, int64_t*);
 
 }  // namespace rl

@@ -1,0 +1,123 @@
+"""Eval decode -> SIGHAN label lines -> sentence-level detection / correction scores.
+
+Host-side mirror of the reference's evaluation tail: ``Metric.write_pred`` / ``process_batch_item``
+(src/metric.py:27-78) turn the arg-max ids of a batch into ``id<TAB>text`` lines and
+``id, pos, char, pos, char ...`` label lines (the format of data_process/build_lbl.py:1-18; ``id, 0`` when the
+sentence is unchanged); ``metric_file`` (src/metric_core.py:4-86) scores a prediction label file against the
+gold one.  The ids themselves come from ``model.decode`` (``realise_argmax`` on the device).
+
+Behaviour kept from the reference, including its corner cases: word pieces lose their ``##`` prefix, the unknown
+token prints as ``U``, each token is cut / padded with ``x`` to the source token's character width
+(``tokens_size``), positions are 1-based character positions, and precision / recall divide by the number of
+sentences the prediction / the gold file marks as erroneous (a ZeroDivisionError when there are none, as there).
+"""
+import os
+
+
+class Vocab:
+    """id -> token table of a BERT ``vocab.txt`` (all the reference's tokenizer is used for here)."""
+
+    def __init__(self, vocab_path, unk_token="[UNK]"):
+        path = os.path.join(vocab_path, "vocab.txt") if os.path.isdir(vocab_path) else vocab_path
+        with open(path, "r", encoding="utf-8") as f:
+            self.tokens = [line.rstrip("\n") for line in f]
+        self.unk_token = unk_token
+
+    def convert_ids_to_tokens(self, ids):
+        n = len(self.tokens)
+        return [self.tokens[i] if 0 <= i < n else self.unk_token for i in ids]
+
+
+def decode_item(vocab, pred_ids, length, tokens_size, src, sent_id):
+    """One sentence: (``id<TAB>text``, label line).  ``pred_ids`` is the full padded row, [CLS] first."""
+    toks = vocab.convert_ids_to_tokens([int(i) for i in pred_ids[1:1 + length]])
+    pieces = []
+    for width, tok in zip(tokens_size, toks):
+        if tok.startswith("##"):
+            tok = tok[2:]
+        if tok == vocab.unk_token:
+            tok = "U"
+        pieces.append((tok[:width]).ljust(width, "x"))
+    pred = "".join(pieces)
+    src = src[:len(pred)]
+    if len(src) != len(pred):
+        raise AssertionError("prediction and source differ in length for %s" % sent_id)
+    fields = [sent_id]
+    for pos, (a, b) in enumerate(zip(src, pred), start=1):
+        if a != b:
+            fields += [str(pos), b]
+    if len(fields) == 1:
+        fields.append("0")
+    return sent_id + "\t" + pred, ", ".join(fields)
+
+
+def read_label_file(path):
+    """``id, pos, char, ...`` lines -> [(id, sorted [(pos, char), ...])]."""
+    out = []
+    with open(path, "r", encoding="utf-8") as f:
+        for line in f.read().splitlines():
+            parts = line.strip().split(", ")
+            edits = []
+            if not (len(parts) == 2 and parts[1] == "0"):
+                edits = [(int(parts[k]), parts[k + 1]) for k in range(1, len(parts), 2)]
+            out.append((parts[0], sorted(edits)))
+    return out
+
+
+def _prf(tp, pred_pos, targ_pos, hit, n, tag):
+    p, r = tp / pred_pos, tp / targ_pos
+    f1 = 2 * p * r / (p + r) if p + r > 0 else 0.0
+    return {"sent-%s-acc" % tag: hit / n * 100, "sent-%s-p" % tag: p * 100, "sent-%s-r" % tag: r * 100, "sent-%s-f1" % tag: f1 * 100}
+
+
+def score(preds, targs):
+    """Sentence-level scores: *detect* compares the edited positions, *correct* positions and characters."""
+    if len(preds) != len(targs):
+        raise AssertionError("prediction / gold sentence counts differ")
+    results = {}
+    for tag in ("detect", "correct"):
+        tp = hit = pred_pos = targ_pos = 0
+        for (pid, pe), (tid, te) in zip(preds, targs):
+            if pid != tid:
+                raise AssertionError("sentence ids differ: %s vs %s" % (pid, tid))
+            same = ([x[0] for x in pe] == [x[0] for x in te]) if tag == "detect" else (pe == te)
+            targ_pos += bool(te)
+            pred_pos += bool(pe)
+            hit += same
+            tp += bool(pe) and same
+        results.update(_prf(tp, pred_pos, targ_pos, hit, len(targs), tag))
+    return results
+
+
+def metric_file(pred_path, targ_path, do_char_metric=False):
+    return score(read_label_file(pred_path), read_label_file(targ_path))
+
+
+class Metric:
+    """Same surface as the reference's ``Metric`` (src/metric.py:9-25): built from the directory holding ``vocab.txt``."""
+
+    def __init__(self, vocab_path):
+        self.tokenizer = Vocab(vocab_path)
+
+    def process_batch_item(self, batch, idx):
+        return decode_item(self.tokenizer, batch["pred_idx"][idx], batch["lengths"][idx], batch["tokens_size"][idx],
+                           batch["src"][idx], batch["id"][idx])
+
+    def write_pred(self, batches, pred_txt_path, pred_lbl_path):
+        txt, lbl = [], []
+        for batch in batches:
+            for i in range(len(batch["src_idx"])):
+                a, b = self.process_batch_item(batch, i)
+                txt.append(a)
+                lbl.append(b)
+        os.makedirs(os.path.dirname(pred_lbl_path) or ".", exist_ok=True)
+        with open(pred_lbl_path, "w", encoding="utf-8") as f:
+            f.write("\n".join(lbl))
+        with open(pred_txt_path, "w", encoding="utf-8") as f:
+            f.write("\n".join(txt))
+
+    def metric(self, batches, pred_txt_path, pred_lbl_path, label_path, should_remove_de=False):
+        if should_remove_de:
+            raise NotImplementedError("remove_de post-processing is outside the hot path")
+        self.write_pred(batches, pred_txt_path, pred_lbl_path)
+        return metric_file(pred_lbl_path, label_path)

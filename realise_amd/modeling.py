@@ -351,6 +351,21 @@ class RealiseModule(nn.Module):
             loss = _EngineLoss.apply(self._anchor, loss, self)
         return (loss, logits)
 
+    @torch.no_grad()
+    def decode(self, batch_or_logits):
+        """Arg-max ids [B, S] (int64, on the device) of a batch or of logits already computed: the device-side form of
+        ``np.argmax(logits.cpu().numpy(), -1)`` (run.py:262-263); first maximum wins, as in numpy."""
+        logits = batch_or_logits if torch.is_tensor(batch_or_logits) else self(batch_or_logits)[-1]
+        if logits.dtype not in (torch.float32, torch.bfloat16) or not logits.is_cuda:
+            raise TypeError("decode needs float32 / bfloat16 logits on the GPU")
+        logits = logits.contiguous()
+        V = logits.shape[-1]
+        rows = logits.numel() // V
+        ids = torch.empty(logits.shape[:-1], dtype=torch.int64, device=logits.device)
+        _capi.check(_capi.load().realise_argmax(self._stream(), 0 if logits.dtype == torch.float32 else 1, logits.data_ptr(), V, rows, V,
+                                                ids.data_ptr()), "realise_argmax")
+        return ids
+
     def _attach_grads(self):
         for name, (arena, off, shape, param) in self._views.items():
             if arena == _AR_TRAIN and param is not None and param.grad is None:

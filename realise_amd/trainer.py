@@ -1,6 +1,6 @@
 """Thin trainer reproducing the call sites of the reference's ``src/run.py`` around the hot path:
 ``make_features`` (run.py:68-101), ``data_helper`` (run.py:104-123), the hot loop (run.py:184-211) and
-``evaluate`` (run.py:239-280, minus the string metric which needs SIGHAN data).  Everything between
+``evaluate`` (run.py:239-280; the label-line writer and the sentence-level scores live in ``metric.py``).  Everything between
 ``model(batch)`` and ``optimizer.step()`` runs in librealise_hip.so.
 """
 import random
@@ -82,13 +82,29 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
 
 
 @torch.no_grad()
-def evaluate(model, items, *, batch_size=64, max_seq_length=128, device="cuda", build_batch=None, tokenizer=None):
-    """run.py:239-280: mean eval loss and the arg-max ids (only ids leave the device)."""
+def evaluate(model, items, *, batch_size=64, max_seq_length=128, device="cuda", build_batch=None, tokenizer=None,
+             vocab_path=None, label_path=None, output_dir=None, prefix=""):
+    """run.py:239-280: mean eval loss and the arg-max ids.  The arg-max runs on the device (``model.decode``), so only
+    [B, S] ids cross PCIe instead of the [B, S, 21128] logits.  With ``vocab_path`` + ``label_path`` + ``output_dir`` the
+    predictions are also written as ``preds.txt`` / ``labels.txt`` and scored like the reference (``results`` dict)."""
+    from .metric import Metric
     build_batch = build_batch or type(model).build_batch
     model.eval()
-    losses, preds = [], []
+    losses, preds, batches = [], [], []
     for batch in data_helper(items, batch_size, max_seq_length, build_batch, tokenizer, is_eval=True):
-        loss, logits = model(batch)[:2]
+        with torch.no_grad():
+            loss, logits = model(batch)[:2]
         losses.append(loss.detach())
-        preds.append(logits.argmax(-1).cpu())
-    return torch.stack(losses).mean().item(), torch.cat(preds)
+        ids = model.decode(logits).cpu()
+        preds.append(ids)
+        if label_path is not None:
+            batch["src_idx"] = batch["src_idx"].cpu().numpy()
+            batch["pred_idx"] = ids.numpy()
+            batches.append(batch)
+    mean_loss = torch.stack(losses).mean().item()
+    if label_path is None:
+        return mean_loss, torch.cat(preds)
+    import os
+    results = Metric(vocab_path).metric(batches, os.path.join(output_dir, prefix, "preds.txt"),
+                                        os.path.join(output_dir, prefix, "labels.txt"), label_path)
+    return mean_loss, torch.cat(preds), results

@@ -331,3 +331,20 @@ def test_rejects_sequences_longer_than_the_kernels_support():
     m = SpellBert(cfg, compute_dtype="bf16").to("cuda").eval()
     with pytest.raises(_capi.RealiseHipError):
         m(synthetic_batch(1, 160, with_pho=False))          # the reference caps max_seq_length at 128 (run.py:304)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_decode_equals_host_argmax_and_golden_in_fp32(golden_dir, dtype):
+    """model.decode == np.argmax(logits.cpu()) (run.py:262-263) with only the ids leaving the device; in fp32 the ids are
+    also the reference's own (golden) arg-max ids."""
+    g = load_golden(golden_dir, "arch3_b4s128_eval")
+    cfg, sd_np, batch = golden_case_inputs(g, "arch3")
+    m = build("arch3", cfg, sd_np, dtype)
+    with torch.no_grad():
+        loss, logits = m(batch)
+    ids = m.decode(logits)
+    assert ids.dtype == torch.int64 and ids.is_cuda and tuple(ids.shape) == tuple(logits.shape[:2])
+    assert np.array_equal(ids.cpu().numpy(), np.argmax(logits.float().cpu().numpy(), axis=-1))
+    assert torch.equal(m.decode(batch), ids)
+    if dtype == "fp32":
+        assert np.array_equal(ids.cpu().numpy().astype(np.int32), g["argmax"])

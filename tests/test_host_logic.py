@@ -1,5 +1,7 @@
 """Host-side logic around the path (CPU): feature padding / masks (run.py:68-101), sharding (run.py:130-137),
 the synthetic SIGHAN-shaped batch generator, and the deterministic weight generator."""
+import pytest
+import os
 import numpy as np
 import torch
 
@@ -62,3 +64,47 @@ def test_weight_generator_is_reproducible_and_named():
     sd = init_state_dict_numpy(cfg, "bert", seed=0)
     assert sd["classifier.weight"] is sd["bert.embeddings.word_embeddings.weight"]
     assert float(sd["bert.embeddings.LayerNorm.weight"].min()) == 1.0 and float(np.abs(sd["classifier.bias"]).max()) == 0.0
+
+
+# ---- eval tail: label lines and sentence-level scores against vectors made by the reference ----
+def _metric_cases():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "metric_cases.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_label_lines_match_reference_vectors(tmp_path):
+    from realise_amd.metric import Metric
+    cases = _metric_cases()
+    (tmp_path / "vocab.txt").write_text("\n".join(cases["vocab"]) + "\n", encoding="utf-8")
+    m = Metric(str(tmp_path))
+    for c in cases["decode"]:
+        batch = {"id": [c["id"]], "src": [c["src"]], "lengths": [c["length"]], "tokens_size": [c["tokens_size"]],
+                 "pred_idx": np.array([c["pred_idx"]]), "src_idx": np.zeros((1, len(c["pred_idx"])), np.int64)}
+        txt, lbl = m.process_batch_item(batch, 0)
+        assert txt == c["txt"] and lbl == c["lbl"]
+
+
+def test_sentence_scores_match_reference_vectors(tmp_path):
+    from realise_amd.metric import metric_file
+    for k, c in enumerate(_metric_cases()["score"]):
+        p, g = tmp_path / ("p%d" % k), tmp_path / ("g%d" % k)
+        p.write_text("\n".join(c["pred"]), encoding="utf-8")
+        g.write_text("\n".join(c["gold"]), encoding="utf-8")
+        got = metric_file(str(p), str(g))
+        assert set(got) == set(c["results"])
+        for key, v in c["results"].items():
+            assert got[key] == pytest.approx(v, abs=1e-12), key
+
+
+def test_metric_end_to_end_writes_reference_format(tmp_path):
+    from realise_amd.metric import Metric
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "a", "b", "c"]
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    batch = {"id": ["x1", "x2"], "src": ["abc", "cb"], "lengths": [3, 2], "tokens_size": [[1, 1, 1], [1, 1]],
+             "src_idx": np.zeros((2, 6), np.int64), "pred_idx": np.array([[2, 4, 5, 6, 3, 0], [2, 6, 4, 3, 0, 0]])}
+    (tmp_path / "gold.txt").write_text("x1, 0\nx2, 2, a", encoding="utf-8")
+    res = Metric(str(tmp_path)).metric([batch], str(tmp_path / "out" / "preds.txt"), str(tmp_path / "out" / "labels.txt"), str(tmp_path / "gold.txt"))
+    assert (tmp_path / "out" / "labels.txt").read_text(encoding="utf-8") == "x1, 0\nx2, 2, a"
+    assert (tmp_path / "out" / "preds.txt").read_text(encoding="utf-8") == "x1\tabc\nx2\tca"
+    assert res["sent-correct-f1"] == 100.0 and res["sent-detect-acc"] == 100.0

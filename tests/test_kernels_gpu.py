@@ -380,3 +380,32 @@ def test_adamw_and_gradnorm_kernels(golden_dir):
     acc = torch.zeros((1,), device=dev())
     _capi.check(lib.realise_sumsq(stream(), P(big), big.numel(), P(acc)), "sumsq")
     assert abs(acc.item() - (big.double() ** 2).sum().item()) < 2e-6 * acc.item()
+
+
+# ---- eval decode (run.py:262-263): device argmax, first maximum wins like numpy -------------------------------------
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("rows,V,ld", [(37, 21128, 21128), (5, 1000, 1003), (64, 7, 8), (3, 70000, 70000)])
+def test_argmax_matches_numpy_first_occurrence(dtype, rows, V, ld):
+    tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+    g = torch.Generator().manual_seed(rows * 7 + V)
+    x = torch.randn((rows, ld), generator=g).to(tdt)
+    x[0, : min(V, 5)] = 3.0                                   # ties on purpose (bf16 rounds many values together anyway)
+    if rows > 2:
+        x[2, V - 1] = 100.0                                   # maximum in the ragged tail
+    xd = x.cuda()
+    ids = torch.empty(rows, dtype=torch.int64, device="cuda")
+    _capi.check(_capi.load().realise_argmax(stream(), 0 if dtype == "fp32" else 1, P(xd), ld, rows, V, P(ids)), "realise_argmax")
+    torch.cuda.synchronize()
+    want = np.argmax(x[:, :V].float().numpy(), axis=-1)
+    assert np.array_equal(ids.cpu().numpy(), want)
+
+
+def test_argmax_nan_counts_as_maximum_like_numpy():
+    x = torch.randn(4, 512)
+    x[1, 77] = float("nan")
+    x[1, 300] = float("nan")
+    xd = x.cuda()
+    ids = torch.empty(4, dtype=torch.int64, device="cuda")
+    _capi.check(_capi.load().realise_argmax(stream(), 0, P(xd), 512, 4, 512, P(ids)), "realise_argmax")
+    torch.cuda.synchronize()
+    assert np.array_equal(ids.cpu().numpy(), np.argmax(x.numpy(), axis=-1))

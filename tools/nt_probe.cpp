@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
   seti_fn variant = (seti_fn)dlsym(h, "realise_set_nt_variant");
   if (!gemm || !probe) { fprintf(stderr, "missing symbols\n"); return 1; }
   struct Shape { int M, N, K; const char* what; };
-  const Shape shapes[] = {{8192, 768, 768, "attn-out / dgrad"}, {8192, 2304, 768, "qkv"}, {8192, 3072, 768, "ffn1 / ffn2-dgrad"},
+  const Shape shapes[] = {{8192, 768, 64, "one K-tile"}, {8192, 768, 128, "two K-tiles"}, {8192, 3072, 64, "one K-tile"}, {8192, 768, 768, "attn-out / dgrad"}, {8192, 2304, 768, "qkv"}, {8192, 3072, 768, "ffn1 / ffn2-dgrad"},
                           {8192, 768, 3072, "ffn2 / ffn1-dgrad"}, {8192, 768, 2304, "qkv-dgrad"}, {8192, 21128, 768, "classifier"}};
   size_t maxA = (size_t)8192 * 3072, maxB = (size_t)21128 * 768, maxC = (size_t)8192 * 21128;
   uint16_t *A, *B, *C;
