@@ -163,11 +163,20 @@ typedef struct {
   const int64_t* pho_idx;     /* [B*S,Tp] (arch3) */
   const int32_t* pho_perm;    /* [B*S] tokens sorted by decreasing pinyin length (device) */
   const int32_t* pho_lens_sorted; /* [B*S] (device) */
-  const int32_t* n_alive;     /* HOST array [Tp]: #sequences with length > t */
+  const int32_t* n_alive;     /* HOST array [Tp]: #sequences with length > t; NULL when n_alive_dev is given */
   float* loss_out;            /* 1 float (device), nullable when tgt_idx is null */
   void* logits_out;           /* [B*S, vocab] in `dtype` (device) */
+  const int32_t* n_alive_dev; /* DEVICE array [Tp] written by realise_build_pho (used when n_alive == NULL) */
 } realise_batch;
 
+/* Device-side `build_batch` (src/models.py:797-804 with the per-character Pinyin2.convert of src/utils.py:58-99 folded into
+ * a per-vocabulary table built once on the host): for every token t of src_idx[T]
+ *     pho_idx[t][0..Tw) = table[src_idx[t]][0..Tw),   len[t] = vlens[src_idx[t]]
+ * then the tokens stably sorted by decreasing length (perm, lens_sorted) and n_alive[k] = #{t : len[t] > k}, all on the
+ * device: no per-character host loop and no host list `pho_lens` in the forward contract.  Feed the outputs to
+ * realise_batch {pho_idx, pho_perm, pho_lens_sorted, n_alive = NULL, n_alive_dev, Tp = Tw}. */
+int realise_build_pho(void* stream, const int64_t* src_idx, int T, const int64_t* table, const int32_t* vlens, int V, int Tw,
+                      int64_t* pho_idx, int32_t* perm, int32_t* lens_sorted, int32_t* n_alive_dev);
 int realise_engine_forward(realise_engine* e, void* stream, const realise_batch* batch);
 /* gradients of the loss computed by the last training forward are ACCUMULATED into the grads arena.
  * Runs buckets [first_bucket, last_bucket] of the backward pass (see realise_bucket_bounds) so a

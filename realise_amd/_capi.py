@@ -38,7 +38,8 @@ class Batch(C.Structure):
                 ("want_dlogits", C.c_int32), ("seed", C.c_uint64),
                 ("src_idx", C.c_void_p), ("masks", C.c_void_p), ("loss_masks", C.c_void_p), ("tgt_idx", C.c_void_p),
                 ("pho_idx", C.c_void_p), ("pho_perm", C.c_void_p), ("pho_lens_sorted", C.c_void_p),
-                ("n_alive", C.POINTER(C.c_int32)), ("loss_out", C.c_void_p), ("logits_out", C.c_void_p)]
+                ("n_alive", C.POINTER(C.c_int32)), ("loss_out", C.c_void_p), ("logits_out", C.c_void_p),
+                ("n_alive_dev", C.c_void_p)]
 
 
 # every symbol include/realise_hip.h declares: name -> (restype, argtypes)
@@ -64,6 +65,7 @@ SYMBOLS = {
     "realise_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I]),
     "realise_masked_ce": (_I, [_P, _I, _P, _L, _P, _P, _I, _I, _P, _P, _P]),
     "realise_argmax": (_I, [_P, _I, _P, _L, _I, _I, _P]),
+    "realise_build_pho": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
     "realise_layout_count": (_I, [C.POINTER(Config)]),
     "realise_layout_entry": (_I, [C.POINTER(Config), _I, C.c_char_p, _I, C.POINTER(C.c_int32), C.POINTER(_L),
                                   C.POINTER(C.c_int32), C.POINTER(_L)]),

@@ -139,6 +139,11 @@ int realise_layernorm_bwd(void* stream, int dtype, const void* dy, const void* x
   }
   return RL_ERR_ARG;
 }
+int realise_build_pho(void* stream, const int64_t* src_idx, int T, const int64_t* table, const int32_t* vlens, int V, int Tw,
+                      int64_t* pho_idx, int32_t* perm, int32_t* lens_sorted, int32_t* n_alive_dev) {
+  if (!src_idx || !table || !vlens || !pho_idx || !perm || !lens_sorted || !n_alive_dev) return RL_ERR_ARG;
+  return pho_prepare((hipStream_t)stream, src_idx, T, table, vlens, V, Tw, pho_idx, perm, lens_sorted, n_alive_dev);
+}
 int realise_argmax(void* stream, int dtype, const void* logits, int64_t ld, int rows, int V, int64_t* ids) {
   hipStream_t st = (hipStream_t)stream;
   if (dtype == 1) return argmax_rows<bf16_t>(st, (const bf16_t*)logits, ld, rows, V, ids);

@@ -81,6 +81,7 @@ template <typename T> struct Engine : EngineBase {
   // last forward
   realise_batch last;
   std::vector<int> last_alive;
+  const int32_t* alive_dev = nullptr;      // device-side n_alive[Tp] of the last batch (nullptr: host counts)
   bool have_fwd = false;
 
   template <typename U> U* wp(int64_t off) const { return (U*)(ws + off); }
@@ -569,15 +570,16 @@ template <typename T> struct Engine : EngineBase {
     for (int t = 0; t < Tp; ++t) {
       const int n = last_alive[t];
       if (n <= 0) break;
+      const int* nd = alive_dev ? (const int*)alive_dev + t : nullptr;
       T* hs_t = wp<T>(pl.gru_hs) + (int64_t)t * N * H;
       T* gh_t = wp<T>(pl.gru_gh) + (int64_t)t * N * 3 * H;
       const T* hs_prev = t > 0 ? wp<T>(pl.gru_hs) + (int64_t)(t - 1) * N * H : nullptr;
       if (t > 0) {
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gh_t; ep.ldo = 3 * H; ep.bias = pp(L.gru_b_hh);
-        RL_TRY(gemm_nt<T>(st, hs_prev, H, sp<T>(sh_gru_hh), H, n, 3 * H, H, ep));
+        RL_TRY(gemm_nt<T>(st, hs_prev, H, sp<T>(sh_gru_hh), H, n, 3 * H, H, ep, nd));
       }
       GruStepArgs<T> a;
-      a.n_alive = n; a.H = H; a.Tp = Tp; a.t = t; a.table = wp<float>(pl.gru_table); a.pho_idx = last.pho_idx;
+      a.n_alive = n; a.n_alive_dev = nd; a.H = H; a.Tp = Tp; a.t = t; a.table = wp<float>(pl.gru_table); a.pho_idx = last.pho_idx;
       a.perm = last.pho_perm; a.lens = last.pho_lens_sorted; a.gh = t > 0 ? gh_t : nullptr; a.b_hh = pp(L.gru_b_hh);
       a.h_prev = hs_prev; a.h_new = hs_t; a.rzn = wp<T>(pl.gru_rzn) + (int64_t)t * N * 3 * H; a.out = wp<T>(pl.gru_out);
       RL_TRY(gru_step_fwd<T>(st, a));
@@ -591,20 +593,21 @@ template <typename T> struct Engine : EngineBase {
     for (int t = Tp - 1; t >= 0; --t) {
       const int n = last_alive[t];
       if (n <= 0) continue;
+      const int* nd = alive_dev ? (const int*)alive_dev + t : nullptr;
       const T* hs_prev = t > 0 ? wp<T>(pl.gru_hs) + (int64_t)(t - 1) * N * H : nullptr;
       T* gh_t = wp<T>(pl.gru_gh) + (int64_t)t * N * 3 * H;
       GruStepArgs<T> a;
-      a.n_alive = n; a.H = H; a.Tp = Tp; a.t = t; a.pho_idx = last.pho_idx; a.perm = last.pho_perm; a.lens = last.pho_lens_sorted;
+      a.n_alive = n; a.n_alive_dev = nd; a.H = H; a.Tp = Tp; a.t = t; a.pho_idx = last.pho_idx; a.perm = last.pho_perm; a.lens = last.pho_lens_sorted;
       a.gh = t > 0 ? gh_t : nullptr; a.b_hh = pp(L.gru_b_hh); a.h_prev = hs_prev;
       a.rzn = wp<T>(pl.gru_rzn) + (int64_t)t * N * 3 * H; a.dout = dout; a.dh = wp<T>(pl.gru_dh); a.dgi = wp<T>(pl.gru_dgi);
       a.dgh = wp<T>(pl.gru_dgh); a.onehot = wp<T>(pl.gru_onehot);
       RL_TRY(gru_step_bwd<T>(st, a));
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = dtable; te.ldo = 3 * H; RL_TRY(gemm_tn<T>(st, a.onehot, 64, a.dgi, 3 * H, n, 64, 3 * H, te)); }
-      RL_TRY(bias_grad<T>(st, a.dgh, 3 * H, n, 3 * H, gp(L.gru_b_hh)));
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = dtable; te.ldo = 3 * H; RL_TRY(gemm_tn<T>(st, a.onehot, 64, a.dgi, 3 * H, n, 64, 3 * H, te, nd)); }
+      RL_TRY(bias_grad<T>(st, a.dgh, 3 * H, n, 3 * H, gp(L.gru_b_hh), nd));
       if (t > 0) {
-        { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(L.gru_w_hh); te.ldo = H; RL_TRY(gemm_tn<T>(st, a.dgh, 3 * H, hs_prev, H, n, 3 * H, H, te)); }
+        { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(L.gru_w_hh); te.ldo = H; RL_TRY(gemm_tn<T>(st, a.dgh, 3 * H, hs_prev, H, n, 3 * H, H, te, nd)); }
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = a.dh; ep.ldo = H; ep.accumulate = 1;
-        RL_TRY(gemm_nt<T>(st, a.dgh, 3 * H, sp<T>(sh_gru_hhT), 3 * H, n, H, 3 * H, ep));
+        RL_TRY(gemm_nt<T>(st, a.dgh, 3 * H, sp<T>(sh_gru_hhT), 3 * H, n, H, 3 * H, ep, nd));
       }
     }
     RL_TRY(gru_table_bwd(st, dtable, 3 * H, pp(L.pho_emb), pp(L.gru_w_ih), cfg.pho_vocab, H, gp(L.pho_emb), gp(L.gru_w_ih), gp(L.gru_b_ih)));
@@ -625,7 +628,7 @@ template <typename T> struct Engine : EngineBase {
     if (!sh || !ws) return RL_ERR_ARG;
     if (b.B < 1 || b.S < 1 || b.S > 128 || b.S > cfg.max_pos) return RL_ERR_ARG;
     const int Tp = cfg.model_type == 1 ? b.Tp : 1;
-    if (cfg.model_type == 1 && (Tp < 1 || !b.pho_idx || !b.pho_perm || !b.pho_lens_sorted || !b.n_alive)) return RL_ERR_ARG;
+    if (cfg.model_type == 1 && (Tp < 1 || !b.pho_idx || !b.pho_perm || !b.pho_lens_sorted || (!b.n_alive && !b.n_alive_dev))) return RL_ERR_ARG;
     if (pl.B != b.B || pl.S != b.S || pl.Tp != Tp) {
       pl = make_plan(b.B, b.S, Tp);
       if (pl.total > ws_bytes) { fprintf(stderr, "[realise_hip] workspace too small: need %lld have %lld\n", (long long)pl.total, (long long)ws_bytes); return RL_ERR_ARG; }
@@ -633,7 +636,10 @@ template <typename T> struct Engine : EngineBase {
     last = b;
     last.Tp = Tp;
     last_alive.assign(Tp, 0);
-    if (cfg.model_type == 1) for (int t = 0; t < Tp; ++t) last_alive[t] = b.n_alive[t];
+    // host counts (the reference's contract: pho_lens is a host list) or, after realise_build_pho, device counts: every
+    // step is then launched over all B*S rows and bounded on the device
+    if (cfg.model_type == 1) for (int t = 0; t < Tp; ++t) last_alive[t] = b.n_alive ? b.n_alive[t] : b.B * b.S;
+    alive_dev = (cfg.model_type == 1 && !b.n_alive) ? b.n_alive_dev : nullptr;
     last.n_alive = nullptr;
     have_fwd = false;
     const int Tk = b.B * b.S;

@@ -40,9 +40,10 @@ template <typename T> struct DenseLoader {
   const T* base;
   int64_t ld;
   int rows, K;
+  const int* rows_dev = nullptr;   // optional device-side row bound (pinyin GRU: #sequences still alive at this step)
   struct Ctx { const T* p; };
   struct KPos { int k; };
-  __device__ __forceinline__ void clamp_rows() {}
+  __device__ __forceinline__ void clamp_rows() { if (rows_dev != nullptr) rows = min(rows, *rows_dev); }
   __device__ __forceinline__ Ctx prepare(int row) const {
     Ctx c; c.p = (row < rows) ? base + (int64_t)row * ld : nullptr; return c;
   }
@@ -144,13 +145,14 @@ struct TnEpi {
 // C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)
 template <typename T>
 int gemm_nt(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K,
-            const EpiParams<T>& ep);
+            const EpiParams<T>& ep, const int* rows_dev = nullptr);
 template <typename T>
 int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la, const T* B, int64_t ldb, int M, int N, int K,
                  const EpiParams<T>& ep);
 // C[I,J] += sum_p A[p,i] * B[p,j]   (A: [P, >=I] row-major; B dense or gathered)
 template <typename T>
-int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep);
+int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep,
+            const int* rows_dev = nullptr);
 template <typename T>
 int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& lb, int P, int I, int J, const TnEpi& ep);
 

@@ -349,9 +349,11 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
 }
 
 template <typename T>
-int gemm_nt(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep) {
+int gemm_nt(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep,
+            const int* rows_dev) {
   if (lda % Geo<T>::VEC) return RL_ERR_ARG;
   DenseLoader<T> la{A, lda, M, K};
+  la.rows_dev = rows_dev;
   return launch_nt<T, DenseLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }
 template <typename T>
@@ -362,8 +364,8 @@ int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la_, const T* B, int64_t l
   if (la.K != K) return RL_ERR_ARG;
   return launch_nt<T, ConvLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }
-template int gemm_nt<bf16_t>(hipStream_t, const bf16_t*, int64_t, const bf16_t*, int64_t, int, int, int, const EpiParams<bf16_t>&);
-template int gemm_nt<float>(hipStream_t, const float*, int64_t, const float*, int64_t, int, int, int, const EpiParams<float>&);
+template int gemm_nt<bf16_t>(hipStream_t, const bf16_t*, int64_t, const bf16_t*, int64_t, int, int, int, const EpiParams<bf16_t>&, const int*);
+template int gemm_nt<float>(hipStream_t, const float*, int64_t, const float*, int64_t, int, int, int, const EpiParams<float>&, const int*);
 template int gemm_nt_conv<bf16_t>(hipStream_t, const ConvLoader<bf16_t>&, const bf16_t*, int64_t, int, int, int, const EpiParams<bf16_t>&);
 template int gemm_nt_conv<float>(hipStream_t, const ConvLoader<float>&, const float*, int64_t, int, int, int, const EpiParams<float>&);
 
@@ -700,9 +702,11 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb,
 }
 
 template <typename T>
-int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep) {
+int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep,
+            const int* rows_dev) {
   if (ldb % TnGeo<T>::VEC) return RL_ERR_ARG;
   DenseLoader<T> lb{B, ldb, P, J};
+  lb.rows_dev = rows_dev;
   return launch_tn<T, DenseLoader<T>>(st, A, lda, lb, P, I, J, ep);
 }
 template <typename T>
@@ -713,8 +717,8 @@ int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& l
   if (lb.K != J) return RL_ERR_ARG;
   return launch_tn<T, ConvLoader<T>>(st, A, lda, lb, P, I, J, ep);
 }
-template int gemm_tn<bf16_t>(hipStream_t, const bf16_t*, int64_t, const bf16_t*, int64_t, int, int, int, const TnEpi&);
-template int gemm_tn<float>(hipStream_t, const float*, int64_t, const float*, int64_t, int, int, int, const TnEpi&);
+template int gemm_tn<bf16_t>(hipStream_t, const bf16_t*, int64_t, const bf16_t*, int64_t, int, int, int, const TnEpi&, const int*);
+template int gemm_tn<float>(hipStream_t, const float*, int64_t, const float*, int64_t, int, int, int, const TnEpi&, const int*);
 template int gemm_tn_conv<bf16_t>(hipStream_t, const bf16_t*, int64_t, const ConvLoader<bf16_t>&, int, int, int, const TnEpi&);
 template int gemm_tn_conv<float>(hipStream_t, const float*, int64_t, const ConvLoader<float>&, int, int, int, const TnEpi&);
 

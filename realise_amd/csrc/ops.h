@@ -64,7 +64,7 @@ template <typename T>
 int embed_bwd(hipStream_t st, const T* de, const int64_t* ids, int B, int S, int H, float* word_grad, float* pos_grad,
               int pos_zero, float* type_grad);
 
-template <typename T> int bias_grad(hipStream_t st, const T* dy, int64_t ld, int rows, int N, float* out);
+template <typename T> int bias_grad(hipStream_t st, const T* dy, int64_t ld, int rows, int N, float* out, const int* rows_dev = nullptr);
 template <typename T> int dropout_apply(hipStream_t st, const T* x, T* y, int rows, int H, DropParams d);
 
 // ---- masked cross-entropy (K13) ---------------------------------------------------------------
@@ -102,6 +102,7 @@ template <typename T> int gate_bwd(hipStream_t st, const GateArgs<T>& a);
 int gru_table(hipStream_t st, const float* emb, const float* w_ih, const float* b_ih, int V, int H, float* table);
 template <typename T> struct GruStepArgs {
   int n_alive = 0, H = 0, Tp = 0, t = 0;
+  const int* n_alive_dev = nullptr; // optional device-side count: rows >= *n_alive_dev are skipped (n_alive is then the launch bound)
   const float* table = nullptr;     // [V][3H]
   const int64_t* pho_idx = nullptr; // [N][Tp] original order
   const int* perm = nullptr;        // sorted position -> original token
@@ -121,6 +122,10 @@ template <typename T> struct GruStepArgs {
 };
 template <typename T> int gru_step_fwd(hipStream_t st, const GruStepArgs<T>& a);
 template <typename T> int gru_step_bwd(hipStream_t st, const GruStepArgs<T>& a);
+// Device-side build_batch (models.py:797-804 + utils.py:58-99 as a per-vocabulary table): pho_idx[t] = table[src[t]],
+// len[t] = vlens[src[t]]; tokens stably sorted by decreasing length -> perm / lens_sorted; n_alive[k] = #{len > k}.
+int pho_prepare(hipStream_t st, const int64_t* src, int T_, const int64_t* table, const int32_t* vlens, int V, int Tw,
+                int64_t* pho_idx, int32_t* perm, int32_t* lens_sorted, int32_t* n_alive);
 int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const float* emb, const float* w_ih, int V, int H,
                   float* d_emb, float* d_w_ih, float* d_b_ih);
 

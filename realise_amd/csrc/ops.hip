@@ -318,13 +318,15 @@ template <typename T> struct SumF {
   const T* x; int64_t ld;
   __device__ __forceinline__ void operator()(int r, int c, floatx4& a0, floatx4&) const { a0 += load4<T>(x + (int64_t)r * ld + c); }
 };
-template <typename T> int bias_grad(hipStream_t st, const T* dy, int64_t ld, int rows, int N, float* out) {
+template <typename T> int bias_grad(hipStream_t st, const T* dy, int64_t ld, int rows, int N, float* out, const int* rows_dev) {
   if (ld & 3) return RL_ERR_ARG;
   SumF<T> f{dy, ld};
-  return launch_col_reduce(st, f, rows, N, out, nullptr);
+  RowBound rb;
+  rb.rows_dev = rows_dev;
+  return launch_col_reduce(st, f, rows, N, out, nullptr, rb);
 }
-template int bias_grad<bf16_t>(hipStream_t, const bf16_t*, int64_t, int, int, float*);
-template int bias_grad<float>(hipStream_t, const float*, int64_t, int, int, float*);
+template int bias_grad<bf16_t>(hipStream_t, const bf16_t*, int64_t, int, int, float*, const int*);
+template int bias_grad<float>(hipStream_t, const float*, int64_t, int, int, float*, const int*);
 
 template <typename T> struct WSumF {
   const T* x; int64_t ld; RowBound rb;

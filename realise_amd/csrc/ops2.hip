@@ -37,6 +37,7 @@ __global__ void gru_step_fwd_kernel(GruStepArgs<T> a) {    // grid (H/4/64, n_al
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int i = blockIdx.y;
   if (c >= a.H) return;
+  if (a.n_alive_dev != nullptr && i >= *a.n_alive_dev) return;
   const int H = a.H;
   const int tok = a.perm[i];
   const int64_t v = a.pho_idx[(int64_t)tok * a.Tp + a.t];
@@ -72,6 +73,58 @@ template <typename T> int gru_step_fwd(hipStream_t st, const GruStepArgs<T>& a) 
   hipLaunchKernelGGL((gru_step_fwd_kernel<T>), dim3((a.H / 4 + 63) / 64, a.n_alive), dim3(64), 0, st, a);
   return RL_LAUNCH_CHECK();
 }
+// ---- device-side pinyin batch ----------------------------------------------------------------------------------------
+// One 1024-thread workgroup: each thread owns a contiguous run of tokens (so ranks inside a length class follow the token
+// order = a STABLE sort, like the host's argsort(-lens, kind="stable")); one block-wide exclusive scan per length class.
+__global__ void __launch_bounds__(1024) pho_prepare_kernel(const int64_t* __restrict__ src, int T_, const int64_t* __restrict__ table,
+                                                            const int32_t* __restrict__ vlens, int V, int Tw, int64_t* __restrict__ pho_idx,
+                                                            int32_t* __restrict__ perm, int32_t* __restrict__ lens_sorted,
+                                                            int32_t* __restrict__ n_alive) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int per = (T_ + 1023) / 1024;
+  const int t0 = min(T_, tid * per), t1 = min(T_, t0 + per);
+  auto len_of = [&](int t) {
+    const int64_t v = src[t];
+    const int l = (v >= 0 && v < V) ? vlens[v] : 1;
+    return min(max(l, 1), Tw);
+  };
+  for (int t = t0; t < t1; ++t) {                         // gather the per-vocabulary rows
+    const int64_t v = src[t];
+    for (int k = 0; k < Tw; ++k) pho_idx[(int64_t)t * Tw + k] = (v >= 0 && v < V) ? table[v * Tw + k] : (k == 0 ? 32 : 0);
+  }
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int L = Tw; L >= 1; --L) {                         // longest first
+    int c = 0;
+    for (int t = t0; t < t1; ++t) c += len_of(t) == L;
+    int incl = c;                                         // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { const int x = wave_tot[w]; if (w < wv) before += x; total += x; }
+    const int base = base_s;
+    int pos = base + before + incl - c;
+    for (int t = t0; t < t1; ++t)
+      if (len_of(t) == L) { perm[pos] = t; lens_sorted[pos] = L; ++pos; }
+    __syncthreads();
+    if (tid == 0) {
+      base_s = base + total;
+      n_alive[L - 1] = base + total;                      // #{len > L - 1} = #{len >= L}
+    }
+    __syncthreads();
+  }
+}
+int pho_prepare(hipStream_t st, const int64_t* src, int T_, const int64_t* table, const int32_t* vlens, int V, int Tw,
+                int64_t* pho_idx, int32_t* perm, int32_t* lens_sorted, int32_t* n_alive) {
+  if (T_ <= 0) return RL_OK;
+  if (Tw < 1 || Tw > 16 || V < 1) return RL_ERR_ARG;
+  hipLaunchKernelGGL(pho_prepare_kernel, dim3(1), dim3(1024), 0, st, src, T_, table, vlens, V, Tw, pho_idx, perm, lens_sorted, n_alive);
+  return RL_LAUNCH_CHECK();
+}
 template int gru_step_fwd<bf16_t>(hipStream_t, const GruStepArgs<bf16_t>&);
 template int gru_step_fwd<float>(hipStream_t, const GruStepArgs<float>&);
 
@@ -82,6 +135,7 @@ __global__ void gru_step_bwd_kernel(GruStepArgs<T> a) {    // grid (H/4/64, n_al
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const int i = blockIdx.y;
   if (c >= a.H) return;
+  if (a.n_alive_dev != nullptr && i >= *a.n_alive_dev) return;
   const int H = a.H;
   const int tok = a.perm[i];
   const bool ends_here = a.lens[i] == a.t + 1;

@@ -320,7 +320,19 @@ class RealiseModule(nn.Module):
         cb.src_idx, cb.masks = src.data_ptr(), masks.data_ptr()
         cb.tgt_idx = tgt.data_ptr() if tgt is not None else None
         cb.loss_masks = loss_masks.data_ptr() if loss_masks is not None else None
-        if self.model_type == "arch3":
+        if self.model_type == "arch3" and "pho_idx" not in batch and getattr(self, "_pho_table", None) is not None:
+            batch = self.build_batch_device(batch)
+        if self.model_type == "arch3" and "_pho_device" in batch:
+            pho_idx = batch["pho_idx"]
+            perm_d, lens_d, alive_d = batch["_pho_device"]
+            if pho_idx.shape[0] != B * S:
+                raise ValueError("pho_idx must have B*S rows")
+            keep += [pho_idx, perm_d, lens_d, alive_d]
+            cb.Tp = int(pho_idx.shape[1])
+            cb.pho_idx, cb.pho_perm, cb.pho_lens_sorted = pho_idx.data_ptr(), perm_d.data_ptr(), lens_d.data_ptr()
+            cb.n_alive = None
+            cb.n_alive_dev = alive_d.data_ptr()
+        elif self.model_type == "arch3":
             pho_idx = self._dev(batch["pho_idx"])
             lens = np.asarray(batch["pho_lens"], dtype=np.int32)         # stays a HOST list in the reference (run.py:189)
             if pho_idx.shape[0] != B * S or lens.shape[0] != B * S:
@@ -350,6 +362,34 @@ class RealiseModule(nn.Module):
         if need_grad:
             loss = _EngineLoss.apply(self._anchor, loss, self)
         return (loss, logits)
+
+    def set_pinyin_table(self, table):
+        """Enable the device-side ``build_batch``: ``table`` is a ``realise_amd.pinyin.PinyinTable`` of this vocabulary.
+        A batch without ``pho_idx`` / ``pho_lens`` is then completed on the GPU from ``src_idx`` alone."""
+        if table.table.shape[0] != self.vocab_size:
+            raise ValueError("pinyin table has %d rows, vocabulary has %d" % (table.table.shape[0], self.vocab_size))
+        self._pho_table = torch.from_numpy(table.table).to(self.device)
+        self._pho_vlens = torch.from_numpy(table.lens).to(self.device)
+
+    def build_batch_device(self, batch):
+        """models.py:797-804 on the device: adds ``pho_idx`` [B*S, 7] and the length-sorted bookkeeping of the GRU
+        (device tensors; there is no host ``pho_lens`` list on this path)."""
+        if getattr(self, "_pho_table", None) is None:
+            raise RuntimeError("set_pinyin_table() first")
+        src = self._dev(batch["src_idx"])
+        T_, Tw = src.numel(), int(self._pho_table.shape[1])
+        pho_idx = torch.empty((T_, Tw), dtype=torch.int64, device=self.device)
+        perm = torch.empty(T_, dtype=torch.int32, device=self.device)
+        lens_sorted = torch.empty(T_, dtype=torch.int32, device=self.device)
+        alive = torch.empty(Tw, dtype=torch.int32, device=self.device)
+        _capi.check(_capi.load().realise_build_pho(self._stream(), src.data_ptr(), T_, self._pho_table.data_ptr(), self._pho_vlens.data_ptr(),
+                                                   self.vocab_size, Tw, pho_idx.data_ptr(), perm.data_ptr(), lens_sorted.data_ptr(),
+                                                   alive.data_ptr()), "realise_build_pho")
+        batch = dict(batch)
+        batch["src_idx"] = src
+        batch["pho_idx"] = pho_idx
+        batch["_pho_device"] = (perm, lens_sorted, alive)
+        return batch
 
     @torch.no_grad()
     def decode(self, batch_or_logits):

@@ -348,3 +348,41 @@ def test_decode_equals_host_argmax_and_golden_in_fp32(golden_dir, dtype):
     assert torch.equal(m.decode(batch), ids)
     if dtype == "fp32":
         assert np.array_equal(ids.cpu().numpy().astype(np.int32), g["argmax"])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_device_build_batch_equals_host_batch(dtype):
+    """a batch completed on the device from src_idx alone (per-vocabulary pinyin table, device sort, device
+    alive counts) gives the same loss, logits and gradients as the reference-style batch with host pho_idx / pho_lens."""
+    from realise_amd.init import init_state_dict_numpy
+    from realise_amd.pinyin import PinyinTable
+    from realise_amd.data import synthetic_batch
+    cfg = RealiseConfig(num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = init_state_dict_numpy(cfg, "arch3", seed=43, scheme="perturbed")
+    g = np.random.default_rng(5)
+    V = cfg.vocab_size
+    vlens = g.integers(2, 8, V).astype(np.int32)
+    vlens[[0, 101, 102]] = 1
+    table = np.zeros((V, 7), np.int64)
+    for v in range(V):
+        table[v, :vlens[v]] = 32 if vlens[v] == 1 else np.concatenate([g.integers(1, 6, 1), g.integers(6, 32, vlens[v] - 1)])
+    tab = PinyinTable(table, vlens)
+    batch = synthetic_batch(3, 40, seed=9)
+    host = dict(batch)
+    host["pho_idx"], host["pho_lens"] = tab.convert(batch["src_idx"].numpy())
+    host["pho_idx"] = torch.from_numpy(host["pho_idx"])
+    dev = {k: v for k, v in batch.items() if k not in ("pho_idx", "pho_lens")}
+    results = []
+    for b in (host, dev):
+        m = build("arch3", cfg, sd_np, dtype, train=True)
+        if b is dev:
+            m.set_pinyin_table(tab)
+        loss, logits = m(b)
+        loss.backward()
+        torch.cuda.synchronize()
+        results.append((loss.item(), logits.detach().float().cpu(), m.flat_gradients().clone().cpu()))
+    (l0, lg0, g0), (l1, lg1, g1) = results
+    tol = 1e-5 if dtype == "fp32" else 2e-2
+    assert abs(l0 - l1) < tol
+    assert (lg0 - lg1).abs().max().item() < (1e-4 if dtype == "fp32" else 6e-2)
+    assert ((g0 - g1).norm() / g0.norm()).item() < (1e-5 if dtype == "fp32" else 2e-2)

@@ -108,3 +108,24 @@ def test_metric_end_to_end_writes_reference_format(tmp_path):
     assert (tmp_path / "out" / "labels.txt").read_text(encoding="utf-8") == "x1, 0\nx2, 2, a"
     assert (tmp_path / "out" / "preds.txt").read_text(encoding="utf-8") == "x1\tabc\nx2\tca"
     assert res["sent-correct-f1"] == 100.0 and res["sent-detect-acc"] == 100.0
+
+
+# ---- device-side build_batch, host half: the per-vocabulary table against Pinyin2 vectors -----------
+def _pinyin_cases():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pinyin_cases.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_pinyin_table_reproduces_reference_convert():
+    from realise_amd.pinyin import PHO_INDEX, PinyinTable, token_pinyin
+    c = _pinyin_cases()
+    assert PHO_INDEX == c["pho_vocab"]
+    tone3 = lambda ch: c["tone3"][ch]
+    assert [token_pinyin(t, tone3) for t in c["tokens"]] == c["per_token"]
+    tab = PinyinTable.build(c["tokens"], tone3)
+    assert tab.table.shape == (len(c["tokens"]), 7) and tab.lens.min() >= 1
+    for case in c["cases"]:
+        pho_idx, lens = tab.convert(case["src_idx"])
+        assert lens == case["pho_lens"]
+        assert pho_idx.tolist() == case["pho_idx"]            # same width (batch max) and 0-padding as pad_sequence

@@ -409,3 +409,31 @@ def test_argmax_nan_counts_as_maximum_like_numpy():
     _capi.check(_capi.load().realise_argmax(stream(), 0, P(xd), 512, 4, 512, P(ids)), "realise_argmax")
     torch.cuda.synchronize()
     assert np.array_equal(ids.cpu().numpy(), np.argmax(x.numpy(), axis=-1))
+
+
+# ---- device-side build_batch (models.py:797-804): gather + stable length sort + alive counts ------------------------
+@pytest.mark.parametrize("T_", [1, 37, 1024, 8192, 20000])
+def test_build_pho_matches_host_bookkeeping(T_):
+    V, Tw = 500, 7
+    g = np.random.default_rng(T_)
+    vlens = g.integers(1, Tw + 1, V).astype(np.int32)
+    table = np.zeros((V, Tw), np.int64)
+    for v in range(V):
+        table[v, :vlens[v]] = g.integers(1, 33, vlens[v])
+    src = g.integers(0, V, T_).astype(np.int64)
+    if T_ > 8:
+        src[3:8] = 0                                             # equal lengths next to each other: stability matters
+    d = lambda a: torch.from_numpy(a).cuda()
+    srcd, tabd, vld = d(src), d(table), d(vlens)
+    pho = torch.empty((T_, Tw), dtype=torch.int64, device="cuda")
+    perm = torch.empty(T_, dtype=torch.int32, device="cuda")
+    ls = torch.empty(T_, dtype=torch.int32, device="cuda")
+    alive = torch.empty(Tw, dtype=torch.int32, device="cuda")
+    _capi.check(_capi.load().realise_build_pho(stream(), P(srcd), T_, P(tabd), P(vld), V, Tw, P(pho), P(perm), P(ls), P(alive)), "build_pho")
+    torch.cuda.synchronize()
+    lens = vlens[src]
+    want_perm = np.argsort(-lens, kind="stable").astype(np.int32)          # what modeling.py does on the host
+    assert np.array_equal(pho.cpu().numpy(), table[src])
+    assert np.array_equal(perm.cpu().numpy(), want_perm)
+    assert np.array_equal(ls.cpu().numpy(), lens[want_perm])
+    assert alive.cpu().tolist() == [int((lens > t).sum()) for t in range(Tw)]
