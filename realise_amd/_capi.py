@@ -58,6 +58,7 @@ SYMBOLS = {
     "realise_set_tn_split": (None, [_I]),
     "realise_set_nt_wide_epilogue": (None, [_I]),
     "realise_set_glyph_dedup": (None, [_I]),
+    "realise_set_wgrad_overlap": (None, [_I]),
     "realise_attention_fwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _U, _U, _F]),
     "realise_attention_bwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _U, _U, _F]),
     "realise_mask_to_additive": (_I, [_P, _P, _P, _I]),
@@ -115,6 +116,10 @@ def load():
         fn = getattr(lib, name)      # AttributeError here == header / library mismatch
         fn.restype = res
         fn.argtypes = args
+    # A/B knobs for measurements (defaults are the production settings)
+    for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup)):
+        if os.environ.get(env) is not None:
+            fn(int(os.environ[env]))
     _lib = lib
     return lib
 

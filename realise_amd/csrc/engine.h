@@ -5,6 +5,8 @@
 #include "../../include/realise_hip.h"
 
 namespace rl {
+void set_wgrad_overlap(int on);   // weight-gradient GEMMs of the BERT layers on an engine-owned side stream (default on)
+
 struct EngineBase {
   virtual ~EngineBase() {}
   virtual int64_t shadow_bytes() const = 0;

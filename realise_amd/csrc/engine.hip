@@ -18,6 +18,9 @@
 
 namespace rl {
 
+static int g_wgrad_overlap = 1;
+void set_wgrad_overlap(int on) { g_wgrad_overlap = on; }
+
 #define RL_TRY(expr) do { const int _rc = (expr); if (_rc != RL_OK) { fprintf(stderr, "[realise_hip] %s failed (%d) at %s:%d\n", #expr, _rc, __FILE__, __LINE__); return _rc; } } while (0)
 
 static constexpr int64_t TN_SLAB_ELEMS = 16LL << 20;   // fp32 partial slabs of the split weight-gradient reductions (64 MiB)
@@ -73,6 +76,7 @@ template <typename T> struct Engine : EngineBase {
     int64_t gu_first, gu_flag, gu_ids, gu_counts, gu_inv, gu_bounds, seg_acc;   // glyph dedup
     // backward scratch
     int64_t gA, gB, gC, gE, gD, gF, rowdot, X1, X2, X3, dz, tn_slab, ln_slots;
+    int64_t wC1[2], wC2[2], wD[2], wF[2], tn_slab2;      // per-parity dY copies + second slab: weight gradients on the side stream
     int64_t gru_dh, gru_dgi, gru_dgh, gru_onehot, gru_dtable;
     int64_t r_dout, r_dc2, r_dcs, r_dh1, r_dc1, r_dx;
   } pl;
@@ -81,6 +85,34 @@ template <typename T> struct Engine : EngineBase {
   // last forward
   realise_batch last;
   std::vector<int> last_alive;
+  // weight-gradient overlap: the four wgrad GEMMs of a BERT layer run on an engine-owned side stream while the caller's
+  // stream continues with the data-gradient chain (see layers_backward)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_ready[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  hipEvent_t ev_done[2] = {nullptr, nullptr};
+  bool done_pending[2] = {false, false};
+  int bw_layers = 0;
+  bool side_ok() {
+    if (side != nullptr) return true;
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+    for (int p = 0; p < 2; ++p) {
+      for (int k = 0; k < 4; ++k) (void)hipEventCreateWithFlags(&ev_ready[p][k], hipEventDisableTiming);
+      (void)hipEventCreateWithFlags(&ev_done[p], hipEventDisableTiming);
+    }
+    return true;
+  }
+  int join_side(hipStream_t st) {
+    for (int p = 0; p < 2; ++p)
+      if (done_pending[p]) { if (hipStreamWaitEvent(st, ev_done[p], 0) != hipSuccess) return RL_ERR_LAUNCH; done_pending[p] = false; }
+    return RL_OK;
+  }
+  ~Engine() override {
+    if (side != nullptr) {
+      (void)hipStreamSynchronize(side);
+      for (int p = 0; p < 2; ++p) { for (int k = 0; k < 4; ++k) (void)hipEventDestroy(ev_ready[p][k]); (void)hipEventDestroy(ev_done[p]); }
+      (void)hipStreamDestroy(side);
+    }
+  }
   const int32_t* alive_dev = nullptr;      // device-side n_alive[Tp] of the last batch (nullptr: host counts)
   bool have_fwd = false;
 
@@ -223,6 +255,11 @@ template <typename T> struct Engine : EngineBase {
     // shared backward scratch
     p.gA = b.take(Tk * H * e); p.gB = b.take(Tk * H * e); p.gC = b.take(Tk * H * e); p.gE = b.take(Tk * H * e);
     p.gD = b.take(Tk * I * e); p.gF = b.take(Tk * 3 * H * e); p.rowdot = b.take((int64_t)B * nh * S * 4);
+    // operands of the deferred weight gradients: a layer's four dY matrices live in the buffer set of its parity until the
+    // side stream has consumed them (set 0 aliases the classic gC / gD / gF scratch)
+    p.wC1[0] = p.gC; p.wD[0] = p.gD; p.wF[0] = p.gF; p.wC2[0] = b.take(Tk * H * e);
+    p.wC1[1] = b.take(Tk * H * e); p.wC2[1] = b.take(Tk * H * e); p.wD[1] = b.take(Tk * I * e); p.wF[1] = b.take(Tk * 3 * H * e);
+    p.tn_slab2 = b.take(TN_SLAB_ELEMS * 4);
     p.tn_slab = b.take(TN_SLAB_ELEMS * 4);
     p.ln_slots = b.take(32 * 2 * 1024 * 4);
     tap("d_x0", p.gB, Tk * H);
@@ -374,7 +411,8 @@ template <typename T> struct Engine : EngineBase {
   int layers_backward(hipStream_t st, int sid, const StackOff& so, const std::vector<LayerSh>& shs, StackAct& a, int hi, int lo,
                       T* gA) {
     const int B = pl.B, S = pl.S, Tk = B * S;
-    T* gB = wp<T>(pl.gB); T* gC = wp<T>(pl.gC); T* gE = wp<T>(pl.gE); T* gD = wp<T>(pl.gD); T* gF = wp<T>(pl.gF);
+    T* gB = wp<T>(pl.gB); T* gE = wp<T>(pl.gE);
+    const bool ov = g_wgrad_overlap && side_ok();
     for (int l = hi; l >= lo; --l) {
       const LayerOff& o = so.layers[l];
       const LayerSh& w = shs[l];
@@ -383,31 +421,49 @@ template <typename T> struct Engine : EngineBase {
       const DropParams d3 = site(sid * 1000 + l * 10 + 3, cfg.hidden_dropout);
       const DropParams d2 = site(sid * 1000 + l * 10 + 2, cfg.hidden_dropout);
       const DropParams d1 = site(sid * 1000 + l * 10 + 1, cfg.attn_dropout);
-      {  // output LayerNorm: gA = d y2 -> gB = d s2 (residual part of d y1), gC = d(dense out) = d s2 * dropmask
+      // Overlap: this layer's dY matrices go to the buffer set of its parity and stay untouched until the side stream has
+      // run the four weight-gradient GEMMs on them; the caller's stream only waits before it re-uses that set (two layers
+      // later).  Without overlap everything stays on `st` and set 0 is the plain scratch.
+      const int p = ov ? (bw_layers++ & 1) : 0;
+      T* gC1 = wp<T>(pl.wC1[p]); T* gC2 = wp<T>(pl.wC2[p]); T* gD = wp<T>(pl.wD[p]); T* gF = wp<T>(pl.wF[p]);
+      if (ov && done_pending[p]) {
+        if (hipStreamWaitEvent(st, ev_done[p], 0) != hipSuccess) return RL_ERR_LAUNCH;
+        done_pending[p] = false;
+      }
+      auto wgrad = [&](int k, const T* dy, int64_t ldy, const T* x, int64_t ldx, int Iw, int Jw, float* bias_g, float* w_g) -> int {
+        hipStream_t ws_ = st;
+        TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = bias_g; te.out = w_g; te.ldo = Jw;
+        if (ov) {
+          if (hipEventRecord(ev_ready[p][k], st) != hipSuccess || hipStreamWaitEvent(side, ev_ready[p][k], 0) != hipSuccess) return RL_ERR_LAUNCH;
+          ws_ = side; te.slab = wp<float>(pl.tn_slab2);
+        }
+        return gemm_tn<T>(ws_, dy, ldy, x, ldx, Tk, Iw, Jw, te);
+      };
+      {  // output LayerNorm: gA = d y2 -> gB = d s2 (residual part of d y1), gC1 = d(dense out) = d s2 * dropmask
         LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
-        ln.gamma = pp(o.out_ln_g); ln.dx = gB; ln.dx_drop = d3.thresh ? gC : nullptr; ln.out_drop = d3;
+        ln.gamma = pp(o.out_ln_g); ln.dx = gB; ln.dx_drop = (d3.thresh || ov) ? gC1 : nullptr; ln.out_drop = d3;
         ln.dgamma = gp(o.out_ln_g); ln.dbeta = gp(o.out_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
       }
-      const T* dso = d3.thresh ? gC : gB;
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(o.out_b); te.out = gp(o.out_w); te.ldo = I; RL_TRY(gemm_tn<T>(st, dso, H, wp<T>(t.post), I, Tk, H, I, te)); }
+      const T* dso = (d3.thresh || ov) ? gC1 : gB;
+      RL_TRY(wgrad(0, dso, H, wp<T>(t.post), I, H, I, gp(o.out_b), gp(o.out_w)));
       {  // d pre = (d s2' . W_out) * gelu'(pre)
         EpiParams<T> ep; ep.mode = EPI_GELU_BWD; ep.out = gD; ep.ldo = I; ep.aux = wp<T>(t.pre); ep.ldaux = I;
         RL_TRY(gemm_nt<T>(st, dso, H, sp<T>(w.out_wT), H, Tk, I, H, ep));
       }
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(o.in_b); te.out = gp(o.in_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gD, I, wp<T>(t.y1), H, Tk, I, H, te)); }
+      RL_TRY(wgrad(1, gD, I, wp<T>(t.y1), H, I, H, gp(o.in_b), gp(o.in_w)));
       {  // d y1 = d s2 + d pre . W_in
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gB; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
       }
-      {  // attention-output LayerNorm: gB = d y1 -> gA = d s1, gC = d(dense out)
+      {  // attention-output LayerNorm: gB = d y1 -> gA = d s1, gC2 = d(dense out)
         LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
-        ln.gamma = pp(o.ao_ln_g); ln.dx = gA; ln.dx_drop = d2.thresh ? gC : nullptr; ln.out_drop = d2;
+        ln.gamma = pp(o.ao_ln_g); ln.dx = gA; ln.dx_drop = (d2.thresh || ov) ? gC2 : nullptr; ln.out_drop = d2;
         ln.dgamma = gp(o.ao_ln_g); ln.dbeta = gp(o.ao_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
       }
-      const T* dsa = d2.thresh ? gC : gA;
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(o.ao_b); te.out = gp(o.ao_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dsa, H, wp<T>(t.ctx), H, Tk, H, H, te)); }
+      const T* dsa = (d2.thresh || ov) ? gC2 : gA;
+      RL_TRY(wgrad(2, dsa, H, wp<T>(t.ctx), H, H, H, gp(o.ao_b), gp(o.ao_w)));
       {  // d ctx = d s1' . W_ao
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gE; ep.ldo = H;
         RL_TRY(gemm_nt<T>(st, dsa, H, sp<T>(w.ao_wT), H, Tk, H, H, ep));
@@ -417,10 +473,14 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(attn_bwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), gE, H, wp<float>(t.lse),
                            wp<float>(pl.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale));
       }
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(o.qkv_b); te.out = gp(o.qkv_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, gF, 3 * H, x_in, H, Tk, 3 * H, H, te)); }
+      RL_TRY(wgrad(3, gF, 3 * H, x_in, H, 3 * H, H, gp(o.qkv_b), gp(o.qkv_w)));
       {  // d x_in = d s1 + d qkv . W_qkv
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, gF, 3 * H, sp<T>(w.qkv_wT), 3 * H, Tk, H, 3 * H, ep));
+      }
+      if (ov) {
+        if (hipEventRecord(ev_done[p], side) != hipSuccess) return RL_ERR_LAUNCH;
+        done_pending[p] = true;
       }
     }
     return RL_OK;
@@ -756,7 +816,7 @@ template <typename T> struct Engine : EngineBase {
     if (last_stage < 0) last_stage = n - 1;
     if (first < 0 || last_stage >= n || first > last_stage) return RL_ERR_ARG;
     for (int s = first; s <= last_stage; ++s) RL_TRY(run_stage(st, s));
-    return RL_OK;
+    return join_side(st);          // the caller's stream owns every gradient of these stages once this returns
   }
 };
 
