@@ -5,7 +5,7 @@
 #include "../../include/realise_hip.h"
 
 namespace rl {
-void set_wgrad_overlap(int on);   // weight-gradient GEMMs of the BERT layers on an engine-owned side stream (default on)
+void set_wgrad_overlap(int on);   // weight-gradient GEMMs of the BERT layers on an engine-owned side stream (default off)
 
 struct EngineBase {
   virtual ~EngineBase() {}
