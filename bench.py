@@ -189,9 +189,10 @@ def main():
         }
         if "gemm_nt" in fams:
             f = fams["gemm_nt"]
+            traffic = pmc_traffic_per_launch("gemm_nt_kernel<bf16_t, DenseLoader<bf16_t>")
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16, DenseLoader> (v_mfma_f32_16x16x32_bf16)",
                                "achieved": round(f["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(f["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                               "frac": round(f["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                                "avg_launch_us": round(f["avg_launch_us"], 2),
                                "launches_per_step": f["launches_per_step"],
                                "flops_per_launch": round(f["tflops"] * 1e12 * f["avg_launch_us"] * 1e-6)}
@@ -201,6 +202,25 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic_per_launch(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel family from the committed PMC passes (profiles/round1_pmc_traffic.json:
+    separate rocprofv3 --pmc runs of this same command, FETCH_SIZE x2 and KiB units as MI355X_MICROARCH.md prescribes;
+    tools/gpu_pmc_bench.sh + tools/pmc_summary.py).  Counters cannot be read inside a timed run, so this is null when the
+    summary is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    n = b = 0.0
+    for name, v in t.items():
+        if name.startswith(kernel_prefix):
+            n += v["launches"]
+            b += v["launches"] * (v["hbm_read_bytes_per_launch"] + v["hbm_write_bytes_per_launch"])
+    return round(b / n) if n else None
 
 
 if __name__ == "__main__":

@@ -386,3 +386,32 @@ def test_device_build_batch_equals_host_batch(dtype):
     assert abs(l0 - l1) < tol
     assert (lg0 - lg1).abs().max().item() < (1e-4 if dtype == "fp32" else 6e-2)
     assert ((g0 - g1).norm() / g0.norm()).item() < (1e-5 if dtype == "fp32" else 2e-2)
+
+
+def test_wgrad_side_stream_overlap_gives_the_same_gradients(golden_dir):
+    """realise_set_wgrad_overlap(1): the weight-gradient GEMMs of the BERT layers run on the engine's side stream with
+    double-buffered operands; losses and weight gradients must be identical to the in-order schedule."""
+    from realise_amd import _capi
+    lib = _capi.load()
+    g = load_golden(golden_dir, "arch3_b3s40_train")
+    cfg, sd_np, batch = golden_case_inputs(g, "arch3")
+    out = []
+    try:
+        for on in (0, 1):
+            lib.realise_set_wgrad_overlap(on)
+            m = build("arch3", cfg, sd_np, "fp32", train=True)
+            for _ in range(2):                                  # two steps: the second re-uses both operand sets
+                m.zero_grad()
+                loss, logits = m(batch)
+                loss.backward()
+            torch.cuda.synchronize()
+            out.append((loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        lib.realise_set_wgrad_overlap(0)
+    assert abs(out[0][0] - out[1][0]) < 1e-5                 # the loss sum itself uses fp32 atomics
+    for n, g0 in out[0][1].items():
+        g1 = out[1][1][n]
+        if n.endswith("weight") and g0.dim() == 2 and "embeddings" not in n and "LayerNorm" not in n:
+            assert torch.equal(g0, g1), n                      # slab-reduced GEMM results: bitwise
+        else:
+            assert (g0 - g1).abs().max().item() <= 1e-5 * (g0.abs().max().item() + 1e-12) + 1e-9, n
