@@ -320,7 +320,7 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
   // Tile width by chip balance: 256 CUs x 2 resident workgroups.  The column count per tile (128 or 96) is chosen to
   // minimise  width x f(tiles per CU)  with f(1) = 1 and f(n) = 0.75 n (two co-resident tiles overlap each other's
   // stalls): e.g. M = 8192, N = 768 -> 8 x 96 columns = 512 tiles, two per CU on every CU, instead of 384 tiles of
-  // 128 columns (half the CUs run two, half run one): +25 % measured (tools/bench_nt_variants.py).
+  // 128 columns (half the CUs run two, half run one): +25 % measured (tools/nt_probe.cpp, n96 knob).
   auto cost = [&](int bn) {
     const long tiles = (long)((M + 127) / 128) * ((N + bn - 1) / bn);
     const long tpc = (tiles + 255) / 256;
