@@ -143,7 +143,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    sampled = 0
+    for i in range(args.steps):
+        if profile:                                          # bracket launches on every 5th timed step only
+            on = (i % PROFILE_EVERY) == 0
+            lib.realise_profile_pause(0 if on else 1)
+            sampled += on
         step()
     torch.cuda.synchronize()
     if world > 1:
@@ -161,7 +166,7 @@ def main():
         for i, name in enumerate(FAMILIES):
             lib.realise_profile_read(i, C.byref(cnt), C.byref(ms), C.byref(work))
             if cnt.value:
-                fams[name] = {"launches_per_step": cnt.value / args.steps, "ms_per_step": ms.value / args.steps,
+                fams[name] = {"launches_per_step": cnt.value / sampled, "ms_per_step": ms.value / sampled,
                               "avg_launch_us": 1e3 * ms.value / cnt.value,
                               "tflops": work.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0}
         lib.realise_profile_disable()
@@ -202,6 +207,11 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+# HIP-event pairs around every launch of the MFMA kernel families cost ~4 us of stream time each (~8 % of a step when every
+# step is bracketed): the timed region brackets every 5th step, which leaves the averages intact and the cost at ~1.5 %.
+PROFILE_EVERY = 5
 
 
 def pmc_traffic_per_launch(kernel_prefix):

@@ -88,6 +88,7 @@ SYMBOLS = {
     "realise_fill_f32": (_I, [_P, _P, _F, _L]),
     "realise_profile_enable": (_I, [_I]),
     "realise_profile_disable": (None, []),
+    "realise_profile_pause": (None, [_I]),
     "realise_profile_read": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

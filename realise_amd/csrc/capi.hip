@@ -228,6 +228,7 @@ int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, in
   return adamw_flat((hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_norm_sq, max_grad_norm);
 }
 int realise_profile_enable(int max_launches) { return prof_enable(max_launches); }
+void realise_profile_pause(int paused) { prof_pause(paused); }
 void realise_profile_disable(void) { prof_disable(); }
 int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work) {
   if (kernel_family < 0 || kernel_family >= PK_COUNT || !count || !total_ms || !total_work) return RL_ERR_ARG;

@@ -9,6 +9,7 @@ void prof_begin(hipStream_t st, int kid, double work);
 void prof_end(hipStream_t st);
 int prof_enable(int max_launches);
 void prof_disable();
+void prof_pause(int paused);      // keep the collected records, stop / resume bracketing launches (sampled steps)
 int prof_read(int kid, long long* count, double* total_ms, double* total_work);
 struct ProfScope {
   hipStream_t st;

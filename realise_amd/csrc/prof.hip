@@ -9,6 +9,7 @@ std::vector<hipEvent_t> g_ev;
 std::vector<Rec> g_recs;
 size_t g_used = 0;
 bool g_open = false;
+bool g_paused = false;
 }  // namespace
 
 int prof_enable(int max_launches) {
@@ -20,6 +21,7 @@ int prof_enable(int max_launches) {
   g_recs.reserve(max_launches);
   g_used = 0;
   g_on = true;
+  g_paused = false;
   return 0;
 }
 void prof_disable() {
@@ -30,9 +32,10 @@ void prof_disable() {
   g_on = false;
   g_open = false;
 }
+void prof_pause(int paused) { g_paused = paused != 0; }
 void prof_begin(hipStream_t st, int kid, double work) {
   g_open = false;
-  if (!g_on || g_used + 2 > g_ev.size()) return;
+  if (!g_on || g_paused || g_used + 2 > g_ev.size()) return;
   (void)hipEventRecord(g_ev[g_used], st);
   g_recs.push_back({kid, work, g_used});
   g_open = true;
