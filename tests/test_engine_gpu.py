@@ -415,3 +415,53 @@ def test_wgrad_side_stream_overlap_gives_the_same_gradients(golden_dir):
             assert torch.equal(g0, g1), n                      # slab-reduced GEMM results: bitwise
         else:
             assert (g0 - g1).abs().max().item() <= 1e-5 * (g0.abs().max().item() + 1e-12) + 1e-9, n
+
+
+def test_full_size_config2_properties_bf16():
+    """BASELINE configs[1] at full size (B=64, S=128, 12+4+3 layers, bf16): the oracle would need minutes per pass, so
+    the checks are size-independent properties: (1) running the glyph ResNet once per distinct token (dedup) equals the
+    dense per-token pass; (2) the loss is permutation-invariant over the sentences of the batch and the logits permute
+    with them (BatchNorm statistics and the masked-mean gate see the same multiset); (3) decode == host arg-max;
+    (4) every gradient is finite and its global norm is dedup-invariant; (5) a step with lr = 0 leaves the weights and
+    the next loss untouched (clip + AdamW plumbing at full arena size)."""
+    from realise_amd import _capi
+    from realise_amd.data import synthetic_batch
+    from realise_amd.optim import FusedAdamW
+    lib = _capi.load()
+    cfg = RealiseConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    m = SpellBertPho2ResArch3(cfg, compute_dtype="bf16", seed=3).to("cuda").train()
+    batch = synthetic_batch(64, 128, seed=77)
+    res = {}
+    try:
+        for on in (1, 0):
+            lib.realise_set_glyph_dedup(on)
+            m.zero_grad()
+            loss, logits = m(batch)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[on] = (loss.item(), logits.detach().float(), m.flat_gradients().clone())
+    finally:
+        lib.realise_set_glyph_dedup(1)
+    (l1, lg1, g1), (l0, lg0, g0) = res[1], res[0]
+    assert np.isfinite(l1) and abs(l1 - l0) < 2e-3 * abs(l0)
+    assert (lg1 - lg0).abs().max().item() < 6e-2
+    assert torch.isfinite(g1).all() and abs(g1.norm().item() - g0.norm().item()) < 2e-2 * g0.norm().item()
+    assert ((g1 - g0).norm() / g0.norm()).item() < 5e-2
+    # (3)
+    assert torch.equal(m.decode(lg1.to(torch.bfloat16)).cpu(), lg1.to(torch.bfloat16).float().cpu().argmax(-1))
+    # (2) permute the sentences
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(5))
+    pb = {k: (v[perm] if torch.is_tensor(v) and v.shape[0] == 64 else v) for k, v in batch.items()}
+    tok = (perm[:, None] * 128 + torch.arange(128)[None, :]).reshape(-1)
+    pb["pho_idx"] = batch["pho_idx"][tok]
+    pb["pho_lens"] = [batch["pho_lens"][i] for i in tok.tolist()]
+    m.zero_grad()
+    lp, lgp = m(pb)
+    assert abs(lp.item() - l1) < 2e-3 * abs(l1)
+    assert (lgp.detach().float() - lg1[perm]).abs().max().item() < 6e-2
+    # (5)
+    lp.backward()
+    before = m.flat_parameters().clone()
+    FusedAdamW(m, [{"params": list(m.parameters()), "weight_decay": 0.0}], lr=0.0, max_grad_norm=1.0).step()
+    torch.cuda.synchronize()
+    assert torch.equal(before, m.flat_parameters())
