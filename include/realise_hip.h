@@ -80,6 +80,8 @@ void realise_set_nt_variant(int v);
 void realise_set_tn_probe(int mode);
 /* Diagnostics: force the number of reduction splits of the TN kernel (0 = heuristic). */
 void realise_set_tn_split(int n);
+/* Diagnostics for the attention forward kernel: 1 stop after operand staging, 2 skip the softmax (results WRONG). */
+void realise_set_attn_probe(int mode);
 /* A/B knob: 1 (default) the NT epilogue goes through a per-wave LDS transpose so every global access is 16 B per lane over
  * whole 128-byte row segments; 0 stores the MFMA fragments directly (8 B per lane). Identical results. */
 void realise_set_nt_wide_epilogue(int on);

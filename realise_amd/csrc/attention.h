@@ -3,6 +3,7 @@
 #include "common.h"
 
 namespace rl {
+void set_attn_probe(int mode);
 // q/k/v: token-major [B*S][ldq] matrices (head h at columns h*64..h*64+63); mask_add: [B][S] fp32
 // additive mask ((1-m) * -10000); ctx: [B*S][ldc]; lse: [B][nh][S] fp32 row log-sum-exp.
 template <typename T>

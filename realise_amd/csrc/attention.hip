@@ -19,6 +19,9 @@
 
 namespace rl {
 
+static int g_attn_probe = 0;       // diagnostics (tools/nt_probe.cpp): 1 stop after staging, 2 skip the softmax
+void set_attn_probe(int mode) { g_attn_probe = mode; }
+
 static constexpr int HD = 64;      // head dim
 static constexpr int SMAX = 128;
 
@@ -63,10 +66,10 @@ template <> __device__ __forceinline__ float gfrag<float>(const float* __restric
 
 __device__ __forceinline__ bf16x8_t pack8(floatx4 a, floatx4 b) {
   uint4 u;
-  u.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
-  u.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
-  u.z = (uint32_t)f2bf(b[0]) | ((uint32_t)f2bf(b[1]) << 16);
-  u.w = (uint32_t)f2bf(b[2]) | ((uint32_t)f2bf(b[3]) << 16);
+  u.x = pack2bf(a[0], a[1]);
+  u.y = pack2bf(a[2], a[3]);
+  u.z = pack2bf(b[0], b[1]);
+  u.w = pack2bf(b[2], b[3]);
   return __builtin_bit_cast(bf16x8_t, u);
 }
 // bf16 fragment from a [64][S] image: row d, contraction slots (g,e) <-> seq = base + 16*(e>>2) + 4*g + (e&3)
@@ -108,7 +111,7 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
                 const float* __restrict__ mask_add, T* __restrict__ ctx, int64_t ldc,
-                float* __restrict__ lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+                float* __restrict__ lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, int probe) {
   typedef typename MmaOf<T>::type Mma;
   typedef AttnGeo<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,18 +124,17 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
   const T* K = k_ + (int64_t)b * S * ldq + h * HD;
   const T* V = v_ + (int64_t)b * S * ldq + h * HD;
 
-  stage_rows<T, true, false>(K, ldq, S, Ks, nullptr, tid);
-  stage_rows<T, false, true>(V, ldq, S, nullptr, Vt, tid);
-  if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
-  __syncthreads();
   const int q0 = wave * 32;
-  if (q0 >= S) return;
-
-  typename Mma::Frag qf[2][G::KSTEPS];
+  typename Mma::Frag qf[2][G::KSTEPS];          // this wave's query fragments: fetched first, they land during the staging pass
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) qf[m][ks] = gfrag<T>(Q, ldq, q0 + 16 * m + l15, S, ks, g);
+  stage_rows<T, true, false>(K, ldq, S, Ks, nullptr, tid);
+  stage_rows<T, false, true>(V, ldq, S, nullptr, Vt, tid);
+  if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
+  __syncthreads();
+  if (q0 >= S || probe == 1) return;
 
   floatx4 sc[8][2];
 #pragma unroll
@@ -153,6 +155,7 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
   // softmax over keys; lane owns query (q0 + 16m + l15), keys 16n + 4g + r
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
+    if (probe == 2) break;
     const int q = q0 + 16 * m + l15;
     float mx = -3.0e38f;
 #pragma unroll
@@ -174,7 +177,7 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * n + 4 * g + r;
-        const float p = key < S ? expf(sc[n][m][r] - mx) : 0.0f;
+        const float p = key < S ? exp_t<T>(sc[n][m][r] - mx) : 0.0f;
         sc[n][m][r] = p;
         sum += p;
       }
@@ -308,7 +311,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
         for (int r = 0; r < 4; ++r) {
           const int q = 32 * mm + 16 * mi + 4 * g + r;
           const bool ok = (q < S) && (key < S);
-          const float p = ok ? expf(s[mi][n][r] * 0.125f + ma[n] - l4[r]) : 0.0f;
+          const float p = ok ? exp_t<T>(s[mi][n][r] * 0.125f + ma[n] - l4[r]) : 0.0f;
           const float dm = drop_mult(drop_seed, drop_thresh, drop_scale,
                                      ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)key);
           pd[mi][n][r] = p * dm;
@@ -414,7 +417,7 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
         for (int r = 0; r < 4; ++r) {
           const int key = 32 * nn + 16 * ni + 4 * g + r;
           const bool ok = (q < S) && (key < S);
-          const float p = ok ? expf(s[ni][m][r] * 0.125f + ma[r] - lq[m]) : 0.0f;
+          const float p = ok ? exp_t<T>(s[ni][m][r] * 0.125f + ma[r] - lq[m]) : 0.0f;
           const float dm = drop_mult(drop_seed, drop_thresh, drop_scale,
                                      ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)key);
           ds[ni][m][r] = p * (dp[ni][m][r] * dm - dq_[m]) * 0.125f;
@@ -450,7 +453,7 @@ int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
   if (!once) { set_lds(attn_fwd_kernel<T>, lds); once = true; }
   ProfScope ps(st, PK_ATTN_FWD, 4.0 * B * nh * (double)S * S * 64);
   hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(B * nh), dim3(256), lds, st, q, k, v, ldq, mask_add, ctx, ldc, lse, B, nh, S,
-                     drop_seed, drop_thresh, drop_scale);
+                     drop_seed, drop_thresh, drop_scale, g_attn_probe);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 

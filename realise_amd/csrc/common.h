@@ -13,11 +13,18 @@ typedef __attribute__((ext_vector_type(4))) short short4_t;
 struct bf16_t { uint16_t v; };                                    // storage-only bf16
 
 __device__ __forceinline__ float bf2f(uint16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f) {                // round-to-nearest-even
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;              // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, on the hardware converter (gfx950: v_cvt_pk_bf16_f32, two values per instruction)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
+typedef __attribute__((ext_vector_type(2))) float floatx2_hw_t;
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  const floatx2_hw_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
+}
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)(pack2bf(f, 0.0f) & 0xffffu); }
+// exp for the softmax / cross-entropy kernels: full-precision expf in parity mode (T = float), the 2-instruction
+// v_exp_f32 form in speed mode (relative error ~1e-6, far inside bf16 resolution)
+template <typename T> __device__ __forceinline__ float exp_t(float x) {
+  if constexpr (sizeof(T) == 4) return expf(x); else return __expf(x);
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T x);
@@ -41,8 +48,8 @@ template <typename T> __device__ __forceinline__ void store4(T* p, floatx4 v);
 template <> __device__ __forceinline__ void store4<float>(float* p, floatx4 v) { *(floatx4*)p = v; }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, floatx4 v) {
   uint2 u;
-  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  u.x = pack2bf(v[0], v[1]);
+  u.y = pack2bf(v[2], v[3]);
   *(uint2*)p = u;
 }
 
@@ -60,10 +67,10 @@ template <typename T> __device__ __forceinline__ void store8(T* p, floatx4 a, fl
 template <> __device__ __forceinline__ void store8<float>(float* p, floatx4 a, floatx4 b) { *(floatx4*)p = a; *(floatx4*)(p + 4) = b; }
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, floatx4 a, floatx4 b) {
   uint4 u;
-  u.x = (uint32_t)f2bf(a[0]) | ((uint32_t)f2bf(a[1]) << 16);
-  u.y = (uint32_t)f2bf(a[2]) | ((uint32_t)f2bf(a[3]) << 16);
-  u.z = (uint32_t)f2bf(b[0]) | ((uint32_t)f2bf(b[1]) << 16);
-  u.w = (uint32_t)f2bf(b[2]) | ((uint32_t)f2bf(b[3]) << 16);
+  u.x = pack2bf(a[0], a[1]);
+  u.y = pack2bf(a[2], a[3]);
+  u.z = pack2bf(b[0], b[1]);
+  u.w = pack2bf(b[2], b[3]);
   *(uint4*)p = u;
 }
 

@@ -443,7 +443,7 @@ ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ 
   float s = 0.f;
   for (int c = threadIdx.x * 4; c < V; c += 1024) {
     const floatx4 v = load4<T>(x + c);
-    s += expf(v[0] - mx) + expf(v[1] - mx) + expf(v[2] - mx) + expf(v[3] - mx);
+    s += exp_t<T>(v[0] - mx) + exp_t<T>(v[1] - mx) + exp_t<T>(v[2] - mx) + exp_t<T>(v[3] - mx);
   }
   s = block_reduce(s, sm, false);
   const float inv_n = 1.0f / count[0];
@@ -456,7 +456,7 @@ ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ 
       const floatx4 v = load4<T>(x + c);
       floatx4 d;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) d[j] = (expf(v[j] - mx) * inv_s - ((c + j) == lab ? 1.0f : 0.0f)) * inv_n;
+      for (int j = 0; j < 4; ++j) d[j] = (exp_t<T>(v[j] - mx) * inv_s - ((c + j) == lab ? 1.0f : 0.0f)) * inv_n;
       store4<T>(dx + c, d);
     }
   }

@@ -96,6 +96,30 @@ int main(int argc, char** argv) {
              2.0 * 8192 * 768 * (2304 + 768 + 3072 + 3072) * layers / (ms * 1e-3) * 1e-12);
     }
   }
+  {   // attention forward, B = 64, 12 heads, S = 128 (q/k/v = column slices of one [T, 2304] matrix)
+    typedef int (*attn_fn)(void*, int, const void*, const void*, const void*, int64_t, const float*, void*, int64_t, float*, int, int, int, uint32_t, uint32_t, float);
+    attn_fn attn = (attn_fn)dlsym(h, "realise_attention_fwd");
+    seti_fn aprobe = (seti_fn)dlsym(h, "realise_set_attn_probe");
+    float *maskadd, *lse;
+    hipMalloc(&maskadd, 8192 * 4); hipMemset(maskadd, 0, 8192 * 4); hipMalloc(&lse, 64 * 12 * 128 * 4);
+    if (attn && aprobe) {
+      printf("attention fwd (768 workgroups):");
+      for (int mode = 0; mode <= 2; ++mode) {
+        aprobe(mode);
+        for (int drop = 0; drop < 2; ++drop) {
+          if (mode != 0 && drop) continue;
+          for (int i = 0; i < 3; ++i) attn(st, 1, A, A + 768, A + 1536, 2304, maskadd, C, 768, lse, 64, 12, 128, 7u, drop ? 429496730u : 0u, drop ? 1.0f / 0.9f : 1.0f);
+          hipEventRecord(e0, st);
+          for (int i = 0; i < 20; ++i) attn(st, 1, A, A + 768, A + 1536, 2304, maskadd, C, 768, lse, 64, 12, 128, 7u, drop ? 429496730u : 0u, drop ? 1.0f / 0.9f : 1.0f);
+          hipEventRecord(e1, st); hipEventSynchronize(e1);
+          float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+          printf("  mode %d%s %.1f us", mode, drop ? " +dropout" : "", ms * 1000.0 / 20);
+        }
+      }
+      aprobe(0);
+      printf("\n");
+    }
+  }
   {   // weight-gradient shapes: out[I,J] += sum_p A[p,i] B[p,j], P = 8192 (kernel + fold)
     typedef int (*gemm_tn_fn)(void*, int, const void*, int64_t, const void*, int64_t, int, int, int, float*, int64_t, float*, int64_t, float*);
     gemm_tn_fn tn = (gemm_tn_fn)dlsym(h, "realise_gemm_tn");
