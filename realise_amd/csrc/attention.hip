@@ -107,8 +107,9 @@ __device__ __forceinline__ void contract_seq32(floatx4 (&acc)[4], const char* tt
 }
 
 // ================================= forward ======================================================
+// 3 workgroups per CU (<= 168 registers, 34 KB LDS each): the 768 (batch, head) workgroups of config 2 run in ONE round
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
                 const float* __restrict__ mask_add, T* __restrict__ ctx, int64_t ldc,
                 float* __restrict__ lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, int probe) {
@@ -339,7 +340,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
 
 // ================================= backward: dQ =================================================
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
                    const float* __restrict__ mask_add, const T* __restrict__ dctx, int64_t ldc,
                    const float* __restrict__ lse, const float* __restrict__ rowdot, T* __restrict__ dq_out, int64_t ldd,

@@ -124,20 +124,24 @@ template <> __device__ __forceinline__ float ktile_frag<float, 64>(const char* t
 }
 
 // ---- counter-based dropout RNG (K17): mask is recomputed in backward, never stored ----------
-__device__ __forceinline__ uint32_t rng_hash(uint32_t seed, uint32_t idx) {
-  uint32_t x = idx ^ seed;
-  x ^= x >> 16; x *= 0x7feb352du;
-  x ^= x >> 15; x *= 0x846ca68bu;
+// One 32-bit hash serves TWO neighbouring elements (16 bits each): two rounds of multiply + xor-shift (integer multiplies
+// are quarter-rate on CDNA, so the per-element cost is what matters in the epilogues / softmax that call this per value).
+__device__ __forceinline__ uint32_t rng_hash(uint32_t seed, uint32_t pair) {
+  uint32_t x = (pair ^ seed) * 0x9E3779B1u;
+  x ^= x >> 15;
+  x = (x + seed) * 0x85EBCA77u;
+  x ^= x >> 13;
+  x *= 0xC2B2AE3Du;
   x ^= x >> 16;
-  x += seed * 0x9E3779B1u;
-  x ^= x >> 15; x *= 0x2c1b3c6du;
-  x ^= x >> 12;
   return x;
 }
-// keep element idx?  thresh = p * 2^32 (0 disables dropout)
+// keep element idx?  thresh = p * 2^32 (0 disables dropout); the comparison uses the top 16 bits of thresh, i.e. the drop
+// probability is p rounded down to a multiple of 2^-16.
 __device__ __forceinline__ float drop_mult(uint32_t seed, uint32_t thresh, float scale, uint32_t idx) {
   if (thresh == 0u) return 1.0f;
-  return rng_hash(seed, idx) >= thresh ? scale : 0.0f;
+  const uint32_t h = rng_hash(seed, idx >> 1);
+  const uint32_t v = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
+  return v >= (thresh >> 16) ? scale : 0.0f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
