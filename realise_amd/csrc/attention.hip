@@ -12,8 +12,8 @@
 //   forward :  S^T = K Q^T  (lane <-> query, regs <-> keys)  feeds  O^T = V^T P^T
 //   bwd dK/dV: S   = Q K^T  (lane <-> key,   regs <-> queries) feeds dV^T = dO^T P, dK^T = Q^T dS
 //   bwd dQ   : S^T = K Q^T                                       feeds dQ^T = K^T dS^T
-// Operands contracted over the sequence dimension (V^T, dO^T, Q^T, K^T) are kept in LDS in a
-// [64][S] sequence-contiguous image with a 16-byte row pad (conflict-free ds_read_b64).
+// Operands contracted over the sequence dimension (V^T, dO^T, Q^T, K^T) are read from the natural [S][64] tile with the
+// transposing LDS load (ds_read_b64_tr_b16): one staged image per matrix, 33 KB of LDS per workgroup, 3 workgroups per CU.
 #include "attention.h"
 #include "prof.h"
 
@@ -34,21 +34,15 @@ template <typename T> struct AttnGeo {
   static constexpr int TT_BYTES = HD * TPITCH;
 };
 
-// stage rows [0,S) of a [S][64] matrix (row stride `stride`) into a K-contiguous swizzled tile
-// and/or its [64][S] transposed image; rows >= S are zero-filled up to 128.
-template <typename T, bool WITH_K, bool WITH_T>
-__device__ __forceinline__ void stage_rows(const T* __restrict__ src, int64_t stride, int S, char* kt, char* tt, int tid) {
+// stage rows [0,S) of a [S][64] matrix (row stride `stride`) into a 64-wide swizzled tile; rows >= S are zero-filled up to 128
+template <typename T>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ src, int64_t stride, int S, char* kt, int tid) {
   typedef AttnGeo<T> G;
   for (int c = tid; c < SMAX * G::CH; c += 256) {
     const int row = c / G::CH, ch = c - row * G::CH;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < S) v = *(const uint4*)(src + (int64_t)row * stride + ch * G::VEC);
-    if (WITH_K) *(uint4*)(kt + KTile<T, HD>::off(row, ch)) = v;
-    if (WITH_T) {
-      const T* e = (const T*)&v;
-#pragma unroll
-      for (int j = 0; j < G::VEC; ++j) *(T*)(tt + (ch * G::VEC + j) * G::TPITCH + row * (int)sizeof(T)) = e[j];
-    }
+    *(uint4*)(kt + KTile<T, HD>::off(row, ch)) = v;
   }
 }
 
@@ -72,24 +66,34 @@ __device__ __forceinline__ bf16x8_t pack8(floatx4 a, floatx4 b) {
   u.w = pack2bf(b[2], b[3]);
   return __builtin_bit_cast(bf16x8_t, u);
 }
-// bf16 fragment from a [64][S] image: row d, contraction slots (g,e) <-> seq = base + 16*(e>>2) + 4*g + (e&3)
-__device__ __forceinline__ bf16x8_t tfrag_bf16(const char* tt, int d, int base, int g) {
-  const char* p = tt + d * AttnGeo<bf16_t>::TPITCH + (base + 4 * g) * 2;
-  const uint2 lo = *(const uint2*)p;
-  const uint2 hi = *(const uint2*)(p + 32);
-  uint4 u; u.x = lo.x; u.y = lo.y; u.z = hi.x; u.w = hi.y;
-  return __builtin_bit_cast(bf16x8_t, u);
+// Operands contracted over the sequence dimension (V^T, dO^T, Q^T, K^T) come from the SAME natural [S][64] swizzled tile
+// the row-contracted products use, transposed on the LDS read: ds_read_b64_tr_b16 hands lane q of a 16-lane group column q
+// of the [4 rows][16 columns] block the group's lanes point at, i.e. 4 consecutive sequence positions of one feature.
+// Contraction slots (g, e) <-> seq = base + 16*(e>>2) + 4*g + (e&3), the order of the score registers (pack8).  With the
+// chunk ^ (row & 7) swizzle the 8 rows a half-wave touches land on 8 distinct 16-byte slots: conflict-free.
+__device__ __forceinline__ bf16x8_t tfrag_bf16(const char* kt, int dn, int base, int l15, int g) {
+  typedef short4_t __attribute__((address_space(3))) * lds_s4;
+  typedef __attribute__((ext_vector_type(8))) short short8_t;
+  short4_t h[2];
+  const int col = 16 * dn + 4 * (l15 & 3);
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int row = base + 16 * hh + 4 * g + (l15 >> 2);
+    h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(kt + KTile<bf16_t, HD>::off(row, col >> 3) + (col & 7) * 2));
+  }
+  const short8_t r = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+  return __builtin_bit_cast(bf16x8_t, r);
 }
 
-// acc[dn] += X^T-image(d = 16*dn + l15, seq slots of the 32-block starting at base) x regs(c0,c1)
-// where c0/c1 are the two 16-row result tiles covering seq base..base+15 / base+16..base+31.
+// acc[dn] += X[seq, d = 16*dn + l15]^T (seq slots of the 32-block starting at base) x regs(c0,c1)
+// where c0/c1 are the two 16-row result tiles covering seq base..base+15 / base+16..base+31; kt = natural tile of X.
 template <typename T>
-__device__ __forceinline__ void contract_seq32(floatx4 (&acc)[4], const char* tt, int base, floatx4 c0, floatx4 c1, int l15, int g) {
+__device__ __forceinline__ void contract_seq32(floatx4 (&acc)[4], const char* kt, int base, floatx4 c0, floatx4 c1, int l15, int g) {
   typedef typename MmaOf<T>::type Mma;
   if constexpr (sizeof(T) == 2) {
     const bf16x8_t y = pack8(c0, c1);
 #pragma unroll
-    for (int dn = 0; dn < 4; ++dn) acc[dn] = Mma::mma(tfrag_bf16(tt, dn * 16 + l15, base, g), y, acc[dn]);
+    for (int dn = 0; dn < 4; ++dn) acc[dn] = Mma::mma(tfrag_bf16(kt, dn, base, l15, g), y, acc[dn]);
   } else {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -99,7 +103,8 @@ __device__ __forceinline__ void contract_seq32(floatx4 (&acc)[4], const char* tt
         const float y = h ? c1[r] : c0[r];
 #pragma unroll
         for (int dn = 0; dn < 4; ++dn) {
-          const float x = *(const float*)(tt + (dn * 16 + l15) * AttnGeo<float>::TPITCH + seq * 4);
+          const int d = dn * 16 + l15;
+          const float x = *(const float*)(kt + KTile<float, HD>::off(seq, d >> 2) + (d & 3) * 4);
           acc[dn] = Mma::mma(x, y, acc[dn]);
         }
       }
@@ -117,8 +122,8 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
   typedef AttnGeo<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
-  char* Vt = smem + G::KT_BYTES;
-  float* madd = (float*)(smem + G::KT_BYTES + G::TT_BYTES);
+  char* Vs = smem + G::KT_BYTES;
+  float* madd = (float*)(smem + 2 * G::KT_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
   const T* Q = q_ + (int64_t)b * S * ldq + h * HD;
@@ -131,8 +136,8 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) qf[m][ks] = gfrag<T>(Q, ldq, q0 + 16 * m + l15, S, ks, g);
-  stage_rows<T, true, false>(K, ldq, S, Ks, nullptr, tid);
-  stage_rows<T, false, true>(V, ldq, S, nullptr, Vt, tid);
+  stage_rows<T>(K, ldq, S, Ks, tid);
+  stage_rows<T>(V, ldq, S, Vs, tid);
   if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
   __syncthreads();
   if (q0 >= S || probe == 1) return;
@@ -201,7 +206,7 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
     for (int dn = 0; dn < 4; ++dn) o[dn] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-      if (32 * kk < S) contract_seq32<T>(o, Vt, 32 * kk, sc[2 * kk][m], sc[2 * kk + 1][m], l15, g);
+      if (32 * kk < S) contract_seq32<T>(o, Vs, 32 * kk, sc[2 * kk][m], sc[2 * kk + 1][m], l15, g);
     const int q = q0 + 16 * m + l15;
     if (q < S) {
       T* dst = ctx + ((int64_t)b * S + q) * ldc + h * HD + 4 * g;
@@ -213,7 +218,7 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
 
 // ================================= backward: dK, dV (+ row dots) ================================
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
                     const float* __restrict__ mask_add, const T* __restrict__ ctx, const T* __restrict__ dctx, int64_t ldc,
                     const float* __restrict__ lse, float* __restrict__ rowdot, T* __restrict__ dk_, T* __restrict__ dv_,
@@ -223,9 +228,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
   char* dOs = Qs + G::KT_BYTES;
-  char* Qt = dOs + G::KT_BYTES;
-  char* dOt = Qt + G::TT_BYTES;
-  float* lse_s = (float*)(dOt + G::TT_BYTES);
+  float* lse_s = (float*)(dOs + G::KT_BYTES);
   float* dot_s = lse_s + SMAX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
@@ -236,8 +239,8 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
   const T* O = ctx + (int64_t)b * S * H + h * HD;
   const T* dO = dctx + (int64_t)b * S * H + h * HD;
 
-  stage_rows<T, true, true>(Q, ldq, S, Qs, Qt, tid);
-  stage_rows<T, true, true>(dO, H, S, dOs, dOt, tid);
+  stage_rows<T>(Q, ldq, S, Qs, tid);
+  stage_rows<T>(dO, H, S, dOs, tid);
   {  // rowdot[q] = sum_d dO[q,d] * O[q,d]  (two threads per row)
     const int row = tid >> 1, half = tid & 1;
     float acc = 0.f;
@@ -261,79 +264,59 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
   const int k0 = wave * 32;
   if (k0 >= S) return;
 
-  typename Mma::Frag kf[2][G::KSTEPS], vf[2][G::KSTEPS];
-  float ma[2];
-#pragma unroll
+  // One 16-key tile at a time (two passes over the queries): half the live accumulators / fragments of a 32-key pass, which
+  // is what lets three workgroups share a CU (<= 168 registers) without spilling.
+#pragma unroll 1
   for (int n = 0; n < 2; ++n) {
     const int key = k0 + 16 * n + l15;
-    ma[n] = key < S ? mask_add[b * S + key] : 0.0f;
+    if (k0 + 16 * n >= S) break;
+    const float ma = key < S ? mask_add[b * S + key] : 0.0f;
+    typename Mma::Frag kf[G::KSTEPS], vf[G::KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
-      kf[n][ks] = gfrag<T>(K, ldq, key, S, ks, g);
-      vf[n][ks] = gfrag<T>(V, ldq, key, S, ks, g);
+      kf[ks] = gfrag<T>(K, ldq, key, S, ks, g);
+      vf[ks] = gfrag<T>(V, ldq, key, S, ks, g);
     }
-  }
-  floatx4 dv[2][4], dk[2][4];
+    floatx4 dv[4], dk[4];
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
+    for (int dn = 0; dn < 4; ++dn) { dv[dn] = floatx4{0.f, 0.f, 0.f, 0.f}; dk[dn] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+    for (int mm = 0; mm < 4; ++mm) {
+      if (32 * mm >= S) break;
+      floatx4 s[2], dp[2];   // [mi] : queries 32mm + 16mi + 4g + r, key k0 + 16n + l15
 #pragma unroll
-    for (int dn = 0; dn < 4; ++dn) { dv[n][dn] = floatx4{0.f, 0.f, 0.f, 0.f}; dk[n][dn] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-
-  for (int mm = 0; mm < 4; ++mm) {
-    if (32 * mm >= S) break;
-    floatx4 s[2][2], dp[2][2];   // [mi][n] : queries 32mm + 16mi + 4g + r, key k0 + 16n + l15
+      for (int mi = 0; mi < 2; ++mi) {
+        s[mi] = floatx4{0.f, 0.f, 0.f, 0.f}; dp[mi] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const int qrow = 32 * mm + 16 * mi + l15;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) { s[mi][n] = floatx4{0.f, 0.f, 0.f, 0.f}; dp[mi][n] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const int qrow = 32 * mm + 16 * mi + l15;
-#pragma unroll
-      for (int ks = 0; ks < G::KSTEPS; ++ks) {
-        const typename Mma::Frag qx = ktile_frag<T, HD>(Qs, qrow, ks, g);
-        const typename Mma::Frag dx = ktile_frag<T, HD>(dOs, qrow, ks, g);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          s[mi][n] = Mma::mma(qx, kf[n][ks], s[mi][n]);
-          dp[mi][n] = Mma::mma(dx, vf[n][ks], dp[mi][n]);
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+          s[mi] = Mma::mma(ktile_frag<T, HD>(Qs, qrow, ks, g), kf[ks], s[mi]);
+          dp[mi] = Mma::mma(ktile_frag<T, HD>(dOs, qrow, ks, g), vf[ks], dp[mi]);
         }
       }
-    }
-    floatx4 pd[2][2], ds[2][2];
+      floatx4 pd[2], ds[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      const floatx4 l4 = *(const floatx4*)(lse_s + 32 * mm + 16 * mi + 4 * g);
-      const floatx4 d4 = *(const floatx4*)(dot_s + 32 * mm + 16 * mi + 4 * g);
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int key = k0 + 16 * n + l15;
+      for (int mi = 0; mi < 2; ++mi) {
+        const floatx4 l4 = *(const floatx4*)(lse_s + 32 * mm + 16 * mi + 4 * g);
+        const floatx4 d4 = *(const floatx4*)(dot_s + 32 * mm + 16 * mi + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = 32 * mm + 16 * mi + 4 * g + r;
           const bool ok = (q < S) && (key < S);
-          const float p = ok ? exp_t<T>(s[mi][n][r] * 0.125f + ma[n] - l4[r]) : 0.0f;
+          const float p = ok ? exp_t<T>(s[mi][r] * 0.125f + ma - l4[r]) : 0.0f;
           const float dm = drop_mult(drop_seed, drop_thresh, drop_scale,
                                      ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)key);
-          pd[mi][n][r] = p * dm;
-          ds[mi][n][r] = p * (dp[mi][n][r] * dm - d4[r]) * 0.125f;
+          pd[mi][r] = p * dm;
+          ds[mi][r] = p * (dp[mi][r] * dm - d4[r]) * 0.125f;
         }
       }
+      contract_seq32<T>(dv, dOs, 32 * mm, pd[0], pd[1], l15, g);
+      contract_seq32<T>(dk, Qs, 32 * mm, ds[0], ds[1], l15, g);
     }
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      contract_seq32<T>(dv[n], dOt, 32 * mm, pd[0][n], pd[1][n], l15, g);
-      contract_seq32<T>(dk[n], Qt, 32 * mm, ds[0][n], ds[1][n], l15, g);
-    }
-  }
-#pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int key = k0 + 16 * n + l15;
     if (key < S) {
       T* pk = dk_ + ((int64_t)b * S + key) * ldd + h * HD + 4 * g;
       T* pv = dv_ + ((int64_t)b * S + key) * ldd + h * HD + 4 * g;
 #pragma unroll
-      for (int dn = 0; dn < 4; ++dn) { store4<T>(pk + 16 * dn, dk[n][dn]); store4<T>(pv + 16 * dn, dv[n][dn]); }
+      for (int dn = 0; dn < 4; ++dn) { store4<T>(pk + 16 * dn, dk[dn]); store4<T>(pv + 16 * dn, dv[dn]); }
     }
   }
 }
@@ -350,8 +333,7 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ks = smem;
   char* Vs = Ks + G::KT_BYTES;
-  char* Kt = Vs + G::KT_BYTES;
-  float* madd = (float*)(Kt + G::TT_BYTES);
+  float* madd = (float*)(Vs + G::KT_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
   const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
   const int64_t H = ldc;
@@ -360,8 +342,8 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
   const T* V = v_ + (int64_t)b * S * ldq + h * HD;
   const T* dO = dctx + (int64_t)b * S * H + h * HD;
 
-  stage_rows<T, true, true>(K, ldq, S, Ks, Kt, tid);
-  stage_rows<T, true, false>(V, ldq, S, Vs, nullptr, tid);
+  stage_rows<T>(K, ldq, S, Ks, tid);
+  stage_rows<T>(V, ldq, S, Vs, tid);
   if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
   __syncthreads();
   const int q0 = wave * 32;
@@ -426,7 +408,7 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
       }
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m) contract_seq32<T>(dq[m], Kt, 32 * nn, ds[0][m], ds[1][m], l15, g);
+    for (int m = 0; m < 2; ++m) contract_seq32<T>(dq[m], Ks, 32 * nn, ds[0][m], ds[1][m], l15, g);
   }
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
@@ -449,7 +431,7 @@ int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
              float* lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
   if (S < 1 || S > SMAX || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC)) return RL_ERR_ARG;
   typedef AttnGeo<T> G;
-  const size_t lds = G::KT_BYTES + G::TT_BYTES + SMAX * sizeof(float);
+  const size_t lds = 2 * G::KT_BYTES + SMAX * sizeof(float);
   static bool once = false;
   if (!once) { set_lds(attn_fwd_kernel<T>, lds); once = true; }
   ProfScope ps(st, PK_ATTN_FWD, 4.0 * B * nh * (double)S * S * 64);
@@ -464,8 +446,8 @@ int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
              int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
   if (S < 1 || S > SMAX || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC) || (ldd & 3)) return RL_ERR_ARG;
   typedef AttnGeo<T> G;
-  const size_t lds1 = 2 * G::KT_BYTES + 2 * G::TT_BYTES + 2 * SMAX * sizeof(float);
-  const size_t lds2 = 2 * G::KT_BYTES + G::TT_BYTES + SMAX * sizeof(float);
+  const size_t lds1 = 2 * G::KT_BYTES + 2 * SMAX * sizeof(float);
+  const size_t lds2 = 2 * G::KT_BYTES + SMAX * sizeof(float);
   static bool once = false;
   if (!once) { set_lds(attn_bwd_dkv_kernel<T>, lds1); set_lds(attn_bwd_dq_kernel<T>, lds2); once = true; }
   ProfScope ps(st, PK_ATTN_BWD, 10.0 * B * nh * (double)S * S * 64);

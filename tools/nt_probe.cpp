@@ -118,6 +118,20 @@ int main(int argc, char** argv) {
       }
       aprobe(0);
       printf("\n");
+      typedef int (*attnb_fn)(void*, int, const void*, const void*, const void*, int64_t, const float*, const void*, const void*, int64_t, const float*,
+                              float*, void*, void*, void*, int64_t, int, int, int, uint32_t, uint32_t, float);
+      attnb_fn attnb = (attnb_fn)dlsym(h, "realise_attention_bwd");
+      float* rowdot; hipMalloc(&rowdot, 64 * 12 * 128 * 4);
+      if (attnb) {
+        for (int drop = 0; drop < 2; ++drop) {
+          for (int i = 0; i < 3; ++i) attnb(st, 1, A, A + 768, A + 1536, 2304, maskadd, C2, AUX, 768, lse, rowdot, C, C + 768, C + 1536, 2304, 64, 12, 128, 7u, drop ? 429496730u : 0u, drop ? 1.0f / 0.9f : 1.0f);
+          hipEventRecord(e0, st);
+          for (int i = 0; i < 20; ++i) attnb(st, 1, A, A + 768, A + 1536, 2304, maskadd, C2, AUX, 768, lse, rowdot, C, C + 768, C + 1536, 2304, 64, 12, 128, 7u, drop ? 429496730u : 0u, drop ? 1.0f / 0.9f : 1.0f);
+          hipEventRecord(e1, st); hipEventSynchronize(e1);
+          float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+          printf("attention bwd (dkv + dq)%s: %.1f us\n", drop ? " +dropout" : "", ms * 1000.0 / 20);
+        }
+      }
     }
   }
   {   // weight-gradient shapes: out[I,J] += sum_p A[p,i] B[p,j], P = 8192 (kernel + fold)
