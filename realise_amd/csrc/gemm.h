@@ -9,7 +9,6 @@ enum EpiMode {
   EPI_STORE = 0,       // out = alpha*acc (+bias) (+= if accumulate)
   EPI_GELU = 1,        // out2 = pre = acc+bias ; out = gelu(pre)                (K5)
   EPI_DROP_RESID = 2,  // out = dropout(acc+bias) + aux                            (K4 minus LN)
-  EPI_QKV = 3,         // acc+bias scattered to [3][B][nh][S][64]                  (K2)
   EPI_GELU_BWD = 4,    // out = acc * gelu'(aux)                                   (K14)
 };
 
@@ -25,8 +24,6 @@ template <typename T> struct EpiParams {
   int accumulate = 0;
   uint32_t drop_seed = 0, drop_thresh = 0;
   float drop_scale = 1.0f;
-  int S = 1, nh = 1;            // EPI_QKV: tokens per sentence, heads
-  int64_t qkv_plane = 0;        // EPI_QKV: elements per Q/K/V plane
   int wide = 0;                 // set by the launcher: rows are 8-element aligned -> LDS-staged epilogue, 16 B per lane
   int probe = 0;                // diagnostics (tools/nt_probe.cpp): 1 all tiles fetch tile 0, 2 no fetches, 3 no MFMA
 };
