@@ -145,7 +145,7 @@ def main():
     t0 = time.perf_counter()
     sampled = 0
     for i in range(args.steps):
-        if profile:                                          # bracket launches on every 5th timed step only
+        if profile:                                          # bracket launches on every 10th timed step only
             on = (i % PROFILE_EVERY) == 0
             lib.realise_profile_pause(0 if on else 1)
             sampled += on
@@ -210,8 +210,8 @@ def main():
 
 
 # HIP-event pairs around every launch of the MFMA kernel families cost ~4 us of stream time each (~8 % of a step when every
-# step is bracketed): the timed region brackets every 5th step, which leaves the averages intact and the cost at ~1.5 %.
-PROFILE_EVERY = 5
+# step is bracketed): the timed region brackets every 10th step, which leaves the averages intact and the cost below 1 %.
+PROFILE_EVERY = 10
 
 
 def pmc_traffic_per_launch(kernel_prefix):

@@ -206,7 +206,7 @@ int realise_fill_f32(void* stream, float* p, float value, int64_t n);
 int realise_profile_enable(int max_launches);
 void realise_profile_disable(void);
 /* 1: stop bracketing launches but keep what was recorded, 0: resume (an event pair costs ~4 us of stream time per launch, so
- * bench.py samples every 5th timed step instead of all of them) */
+ * bench.py samples every 10th timed step instead of all of them) */
 void realise_profile_pause(int paused);
 int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work);
 
