@@ -147,10 +147,13 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
   typename ALoader::KPos aq = la.kpos(kchunk);
   typename DenseLoader<T>::KPos bq = lb.kpos(kchunk);
   const int nk = (K + G::BK - 1) / G::BK;
-  // Fast addressing when no chunk can fall off the K end: each lane keeps one 64-bit source pointer per
-  // wave-instruction and just adds the K-tile stride (0 for lanes parked on the zero page).
+  // Fast addressing for the K-tiles that lie completely inside K: each lane keeps one 64-bit source pointer per
+  // wave-instruction and just adds the K-tile stride (0 for lanes parked on the zero page).  A ragged last tile
+  // (K % BK != 0, e.g. the classifier's data gradient with K = 21128) falls back to checked addressing for that tile only.
   constexpr bool kDenseA = sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
-  const bool fast = (K % G::BK) == 0;
+  const int nfast = K / G::BK;
+  const bool fast = nfast > 0, fast_all = (K % G::BK) == 0;
+  int kt_issue = 0;
   const char* pa[NA];
   const char* pb[NB];
   int inca[NA], incb[NB];
@@ -178,22 +181,26 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
   auto issue = [&](int stage) {                      // fetch the next K-tile, then advance the positions
     if (ep.probe == 2) return;
     char* base = smem + stage * STAGE;
-    if (kDenseA && fast) {
+    const bool f = kt_issue < nfast;                 // this tile is addressed by pointer stepping
+    if (kDenseA && f) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) { glds16(pa[j], base + (wave * NA + j) * 1024); pa[j] += inca[j]; }
     } else {
+      if (kDenseA && fast && kt_issue == nfast) aq = la.kpos(kchunk + nfast * G::BK);
 #pragma unroll
       for (int j = 0; j < NA; ++j) glds16(la.addr(actx[j], aq, zero), base + (wave * NA + j) * 1024);
       la.advance(aq, G::BK);
     }
-    if (fast) {
+    if (f) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) { glds16(pb[j], base + A_BYTES + (wave * NB + j) * 1024); pb[j] += incb[j]; }
     } else {
+      if (fast && kt_issue == nfast) bq = lb.kpos(kchunk + nfast * G::BK);
 #pragma unroll
       for (int j = 0; j < NB; ++j) glds16(lb.addr(bctx[j], bq, zero), base + A_BYTES + (wave * NB + j) * 1024);
       lb.advance(bq, G::BK);
     }
+    ++kt_issue;
   };
 
   // One 1-KiB piece of the next K-tile (fast addressing only): lets the main loop spread the NA + NB fetch instructions
@@ -229,7 +236,7 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
     const bool more = kt + NSTAGE - 1 < nk;
     const int nstage = (kt + NSTAGE - 1) % NSTAGE;
     constexpr bool kSpread = SPREAD && kDenseA && sizeof(T) == 2;
-    const bool spread = kSpread && fast && ep.probe == 0;
+    const bool spread = kSpread && fast_all && ep.probe == 0;
     if (more && !spread) issue(nstage);
     const char* As = smem + (kt % NSTAGE) * STAGE;
     const char* Bs = As + A_BYTES;
