@@ -166,7 +166,7 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
   if (a.rows <= 0) return RL_OK;
   if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
   int blocks = (a.rows + 3) / 4;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 1024) blocks = 1024;          // 4096 waves: two rows each at config 2 (memory-level parallelism; 112 VGPRs -> 4 waves/SIMD)
   LnBwdArgs<T> b = a;
   if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr;
   if (b.slots != nullptr) (void)hipMemsetAsync(b.slots, 0, (size_t)32 * 2 * a.H * sizeof(float), st);
