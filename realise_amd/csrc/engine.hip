@@ -628,7 +628,10 @@ template <typename T> struct Engine : EngineBase {
   // ---------------------------------------------------------------- pinyin GRU (models.py:818-826)
   int gru_forward(hipStream_t st) {
     const int N = pl.B * pl.S, Tp = last.Tp;
-    RL_TRY(gru_table(st, pp(L.pho_emb), pp(L.gru_w_ih), pp(L.gru_b_ih), cfg.pho_vocab, H, wp<float>(pl.gru_table)));
+    {   // W_ih x + b_ih for the 33 pinyin symbols: one exact-fp32 MFMA GEMM from the fp32 masters ([33,768] x [2304,768]^T)
+      EpiParams<float> ep; ep.mode = EPI_STORE; ep.out = wp<float>(pl.gru_table); ep.ldo = 3 * H; ep.bias = pp(L.gru_b_ih);
+      RL_TRY(gemm_nt<float>(st, pp(L.pho_emb), H, pp(L.gru_w_ih), H, cfg.pho_vocab, 3 * H, H, ep));
+    }
     for (int t = 0; t < Tp; ++t) {
       const int n = last_alive[t];
       if (n <= 0) break;

@@ -99,7 +99,6 @@ template <typename T> int gate_fwd(hipStream_t st, const GateArgs<T>& a);
 template <typename T> int gate_bwd(hipStream_t st, const GateArgs<T>& a);
 
 // ---- pinyin GRU (K6) ------------------------------------------------------------------------------
-int gru_table(hipStream_t st, const float* emb, const float* w_ih, const float* b_ih, int V, int H, float* table);
 template <typename T> struct GruStepArgs {
   int n_alive = 0, H = 0, Tp = 0, t = 0;
   const int* n_alive_dev = nullptr; // optional device-side count: rows >= *n_alive_dev are skipped (n_alive is then the launch bound)

@@ -10,28 +10,6 @@ namespace rl {
 // GRU (models.py:661-669, 818-826).  The input projection only ever sees 33 distinct embedding
 // rows, so W_ih x + b_ih is a [33][3H] table computed once per forward (fp32, from the masters).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-gru_table_kernel(const float* __restrict__ emb, const float* __restrict__ w_ih, const float* __restrict__ b_ih, int V, int H,
-                 float* __restrict__ table) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + wave;          // output unit in [0, 3H)
-  if (j >= 3 * H) return;
-  float w[16];
-  const int nper = (H + 63) / 64;               // <= 16 for H <= 1024
-  for (int i = 0; i < nper; ++i) { const int k = i * 64 + lane; w[i] = k < H ? w_ih[(int64_t)j * H + k] : 0.f; }
-  for (int v = 0; v < V; ++v) {
-    float s = 0.f;
-    for (int i = 0; i < nper; ++i) { const int k = i * 64 + lane; if (k < H) s += w[i] * emb[(int64_t)v * H + k]; }
-    s = wave_sum(s);
-    if (lane == 0) table[(int64_t)v * 3 * H + j] = s + b_ih[j];
-  }
-}
-int gru_table(hipStream_t st, const float* emb, const float* w_ih, const float* b_ih, int V, int H, float* table) {
-  if (H > 1024) return RL_ERR_ARG;
-  hipLaunchKernelGGL(gru_table_kernel, dim3((3 * H + 3) / 4), dim3(256), 0, st, emb, w_ih, b_ih, V, H, table);
-  return RL_LAUNCH_CHECK();
-}
-
 template <typename T>
 __global__ void gru_step_fwd_kernel(GruStepArgs<T> a) {    // grid (H/4/64, n_alive)
   const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
