@@ -129,3 +129,43 @@ def test_pinyin_table_reproduces_reference_convert():
         pho_idx, lens = tab.convert(case["src_idx"])
         assert lens == case["pho_lens"]
         assert pho_idx.tolist() == case["pho_idx"]            # same width (batch max) and 0-padding as pad_sequence
+
+
+def test_evaluate_plumbing_writes_label_files_and_scores(tmp_path):
+    """run.py:239-280 end to end on the host side: features -> batches -> (stub) model -> decode -> preds.txt / labels.txt ->
+    sentence scores.  The stub returns logits whose arg-max is the target except one planted error."""
+    from realise_amd.trainer import evaluate
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]"] + list("abcdefgh")
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    tok = {c: i for i, c in enumerate(vocab)}
+
+    def item(sid, src, tgt):
+        ids = lambda s: [2] + [tok[c] for c in s] + [3]
+        return {"id": sid, "src": src, "tgt": tgt, "tokens_size": [1] * len(src), "lengths": len(src), "src_idx": ids(src), "tgt_idx": ids(tgt)}
+
+    items = [item("s1", "abca", "abcd"), item("s2", "efgh", "efgh"), item("s3", "aabb", "abab")]
+    (tmp_path / "gold.txt").write_text("s1, 4, d\ns2, 0\ns3, 2, b, 3, a", encoding="utf-8")
+
+    class Stub(torch.nn.Module):
+        @staticmethod
+        def build_batch(batch, tokenizer=None):
+            return batch
+
+        def forward(self, batch):
+            tgt = batch["tgt_idx"].clone()
+            if "s3" in batch["id"]:
+                tgt[batch["id"].index("s3"), 2] = tok["h"]          # planted wrong correction at position 2 of s3
+            logits = torch.nn.functional.one_hot(tgt, len(vocab)).float()
+            return torch.tensor(0.5), logits
+
+        def decode(self, logits):
+            return logits.argmax(-1)
+
+    loss, preds, res = evaluate(Stub(), items, batch_size=2, max_seq_length=8, vocab_path=str(tmp_path), label_path=str(tmp_path / "gold.txt"),
+                                output_dir=str(tmp_path / "out"))
+    assert loss == pytest.approx(0.5) and tuple(preds.shape) == (3, 8)
+    assert (tmp_path / "out" / "labels.txt").read_text(encoding="utf-8") == "s1, 4, d\ns2, 0\ns3, 2, h, 3, a"
+    assert (tmp_path / "out" / "preds.txt").read_text(encoding="utf-8") == "s1\tabcd\ns2\tefgh\ns3\tahab"
+    assert res["sent-detect-f1"] == pytest.approx(100.0)             # positions all found
+    assert res["sent-correct-p"] == pytest.approx(50.0) and res["sent-correct-r"] == pytest.approx(50.0)
+    assert res["sent-correct-acc"] == pytest.approx(100.0 * 2 / 3)
