@@ -119,7 +119,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # A/B knobs for measurements (defaults are the production settings)
-    for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup)):
+    for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup),
+                    ("REALISE_NT_VARIANT", lib.realise_set_nt_variant)):
         if os.environ.get(env) is not None:
             fn(int(os.environ[env]))
     _lib = lib

@@ -298,6 +298,148 @@ void set_tn_probe(int mode) { g_tn_probe = mode; }
 void set_nt_wide_epilogue(int on) { g_nt_wide = on; }
 void set_nt_probe(int mode) { g_nt_probe = mode; }
 
+
+// =================================================================================================
+// Phase-shifted 8-wave NT kernel (EXPERIMENTAL, variant 8 of realise_set_nt_variant): 256 x 128 tile, waves
+// 0-3 (group A) and 4-7 (group B) share the SIMDs pairwise and run half a K-tile out of phase - one group's MFMA phase
+// (32 MFMAs on register-resident fragments) covers the other's memory phase (fragment reads of a whole K-tile + its share
+// of the LDS-DMA fetches of tile t+2).  bf16, dense operands, K % 64 == 0.
+// =================================================================================================
+__global__ void __launch_bounds__(512, 1)
+gemm_nt_pp_kernel(DenseLoader<bf16_t> la, DenseLoader<bf16_t> lb, int M, int N, int K, int tiles_n, int ntiles, EpiParams<bf16_t> ep) {
+  typedef bf16_t T;
+  typedef MmaBF16 Mma;
+  constexpr int BM_ = 256, BN_ = 128, BK = 64, NST = 3;
+  constexpr int A_BYTES = BM_ * 128, B_BYTES = BN_ * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int NA = 4, NB = 2;                       // 1-KiB pieces per wave per tile (8 waves)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wm = wave & 3, wn = grp;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM_, n0 = tn * BN_;
+  const void* zero = (const void*)g_zero16;
+  const int lrow = lane >> 3;
+  const int kchunk = ((lane & 7) ^ lrow) * 8;
+  const char* pa[NA];
+  const char* pb[NB];
+  int inca[NA], incb[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const void* p0 = la.addr(la.prepare(m0 + (wave * NA + j) * 8 + lrow), la.kpos(kchunk), zero);
+    pa[j] = (const char*)p0; inca[j] = (p0 != zero) ? BK * 2 : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const void* p0 = lb.addr(lb.prepare(n0 + (wave * NB + j) * 8 + lrow), lb.kpos(kchunk), zero);
+    pb[j] = (const char*)p0; incb[j] = (p0 != zero) ? BK * 2 : 0;
+  }
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t fa[2][4], fb[2][4];
+
+  auto issue_tile = [&](int stage) {
+    char* base = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { glds16(pa[j], base + (wave * NA + j) * 1024); pa[j] += inca[j]; }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { glds16(pb[j], base + A_BYTES + (wave * NB + j) * 1024); pb[j] += incb[j]; }
+  };
+  auto read_frags = [&](int stage) {
+    const char* As = smem + stage * STAGE;
+    const char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[ks][i] = ktile_frag<T, 64>(As, wm * 64 + i * 16 + l15, ks, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[ks][j] = ktile_frag<T, 64>(Bs, wn * 64 + j * 16 + l15, ks, g);
+    }
+  };
+  auto mma_all = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mma::mma(fb[ks][j], fa[ks][i], acc[i][j]);
+  };
+#define RL_PP_BARRIER() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+  const int nk = K / BK;
+  issue_tile(0);
+  if (nk > 1) { issue_tile(1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RL_PP_BARRIER();                                   // tile 0 landed for every wave
+  if (grp == 0) {                                    // half 1(0): group A's first memory phase
+    read_frags(0);
+    if (2 < nk) issue_tile(2 % NST);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  RL_PP_BARRIER();
+  for (int t = 0; t < nk; ++t) {
+    // half 2(t): A multiplies tile t, B reads its fragments of tile t and fetches its share of tile t+2
+    if (grp == 0) {
+      mma_all();
+    } else {
+      read_frags(t % NST);
+      if (t + 2 < nk) issue_tile((t + 2) % NST);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // own pieces of tile t+1 done (t+2 may fly)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RL_PP_BARRIER();
+    // half 1(t+1): A reads tile t+1 and fetches its share of tile t+3, B multiplies tile t
+    if (grp == 0) {
+      if (t + 1 < nk) {
+        read_frags((t + 1) % NST);
+        if (t + 3 < nk) issue_tile((t + 3) % NST);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else {
+      mma_all();
+    }
+    RL_PP_BARRIER();
+  }
+#undef RL_PP_BARRIER
+  if (ep.wide) {
+    constexpr int RS = 68, ITEMS = 8;
+    __syncthreads();
+    float* et = (float*)smem + wave * (64 * RS);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(floatx4*)(et + (i * 16 + l15) * RS + j * 16 + 4 * g) = acc[i][j];
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+      const int e = lane + 64 * t, r = e / ITEMS, c8 = e - r * ITEMS;
+      const floatx4 v0 = *(const floatx4*)(et + r * RS + c8 * 8), v1 = *(const floatx4*)(et + r * RS + c8 * 8 + 4);
+      epilogue8<T>(ep, M, N, m0 + wm * 64 + r, n0 + wn * 64 + c8 * 8, v0, v1);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) epilogue4<T>(ep, M, N, m0 + wm * 64 + i * 16 + l15, n0 + wn * 64 + j * 16 + 4 * g, acc[i][j]);
+}
+static int launch_nt_pp(hipStream_t st, const DenseLoader<bf16_t>& la, const DenseLoader<bf16_t>& lb, int M, int N, int K,
+                        const EpiParams<bf16_t>& ep) {
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128, ntiles = tiles_m * tiles_n;
+  const size_t lds = 3 * (size_t)(256 + 128) * 128;      // 144 KB ring >= 8 x 64 x 68 x 4 epilogue tiles
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
+  EpiParams<bf16_t> epp = ep;
+  epp.wide = g_nt_wide && (N % 8 == 0) && (ep.ldo % 8 == 0) && (ep.aux == nullptr || ep.ldaux % 8 == 0);
+  hipLaunchKernelGGL(gemm_nt_pp_kernel, dim3(ntiles), dim3(512), lds, st, la, lb, M, N, K, tiles_n, ntiles, epp);
+  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+}
+
 template <typename T, typename ALoader, int WM, int WN, int NSTAGE = 2, int NF = 4, bool SPREAD = false>
 static int launch_nt_tile(hipStream_t st, const ALoader& la, const DenseLoader<T>& lb, int M, int N, int K, const EpiParams<T>& ep) {
   constexpr int BM_ = 64 * WM, BN_ = 16 * NF * WN;
@@ -343,6 +485,8 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
               return launch_nt_tile<T, ALoader, 2, 2, 2, 4, true>(st, la, lb, M, N, K, ep);   // production tiles, spread fetch issue
       case 6: return launch_nt_tile<T, ALoader, 4, 2, 3, 4, true>(st, la, lb, M, N, K, ep);     // 256 x 128, 3 stages, spread
       case 7: return launch_nt_tile<T, ALoader, 2, 4, 3, 3, true>(st, la, lb, M, N, K, ep);     // 128 x 192, 3 stages, spread
+      case 8: if ((K % 64) == 0 && la.rows_dev == nullptr) return launch_nt_pp(st, la, lb, M, N, K, ep);     // phase-shifted 256 x 128
+              break;
       default: break;
     }
     // very wide outputs (the 21128-column classifier: > 20 rounds of 128x128 tiles): 8-wave 256x128 tiles cut the

@@ -437,3 +437,28 @@ def test_build_pho_matches_host_bookkeeping(T_):
     assert np.array_equal(perm.cpu().numpy(), want_perm)
     assert np.array_equal(ls.cpu().numpy(), lens[want_perm])
     assert alive.cpu().tolist() == [int((lens > t).sum()) for t in range(Tw)]
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_gemm_nt_experimental_tile_variants(variant):
+    """realise_set_nt_variant: the alternative tile shapes / schedules kept for measurements (8-wave 128x192 and 256x128 tiles,
+    3-stage rings, spread fetch issue, the phase-shifted two-group kernel) must give the production kernel's results."""
+    lib = _capi.load()
+    code, tdt, tol = DT["bf16"]
+    outs = []
+    try:
+        for v in (0, variant):
+            lib.realise_set_nt_variant(v)
+            for (M, N, K) in ((520, 768, 768), (256, 3072, 128)):
+                a, b = rnd((M, K), 1).to(tdt).cuda(), rnd((N, K), 2, 0.05).to(tdt).cuda()
+                bias = rnd((N,), 3).cuda()
+                out = torch.empty((M, N), dtype=tdt, device="cuda")
+                ep = _capi.Epilogue()
+                ep.mode, ep.out, ep.ldo, ep.bias, ep.alpha, ep.drop_scale = 0, out.data_ptr(), N, bias.data_ptr(), 1.0, 1.0
+                _capi.check(lib.realise_gemm_nt(stream(), code, P(a), K, P(b), K, M, N, K, C.byref(ep)), "gemm_nt")
+                torch.cuda.synchronize()
+                outs.append(out.float().cpu())
+    finally:
+        lib.realise_set_nt_variant(0)
+    for ref, got in zip(outs[:2], outs[2:]):
+        assert torch.allclose(ref, got, rtol=1e-2, atol=1e-3)       # same math; at most a bf16 rounding apart
