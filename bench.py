@@ -138,7 +138,7 @@ def main():
         step()
     profile = (rank == 0) and not args.no_profile
     if profile:
-        _capi.check(lib.realise_profile_enable(args.steps * 1200 + 64), "realise_profile_enable")
+        _capi.check(lib.realise_profile_enable((args.steps // PROFILE_EVERY + 1) * 1200 + 64), "realise_profile_enable")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
