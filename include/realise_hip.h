@@ -149,7 +149,7 @@ realise_engine* realise_engine_create(const realise_config* cfg, float* params, 
                                       float* frozen, float* buffers_f32, int64_t* buffers_i64);
 void realise_engine_destroy(realise_engine* e);
 int64_t realise_engine_shadow_bytes(const realise_engine* e);
-int64_t realise_engine_workspace_bytes(const realise_engine* e, int B, int S, int Tp);
+int64_t realise_engine_workspace_bytes(const realise_engine* e, int B, int S, int Tp);   /* Tp = -1: glyph-only plan */
 /* hand the engine its operand-shadow arena and its activation workspace (caller-allocated) */
 int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_t workspace_bytes);
 /* re-derive the compute-dtype operand copies from the fp32 masters (after any parameter update) */
@@ -188,6 +188,13 @@ int realise_engine_forward(realise_engine* e, void* stream, const realise_batch*
  * Runs buckets [first_bucket, last_bucket] of the backward pass (see realise_bucket_bounds) so a
  * caller can overlap the all-reduce of finished buckets; pass 0, -1 for the whole pass. */
 int realise_engine_backward(realise_engine* e, void* stream, int first_bucket, int last_bucket);
+/* Glyph-only entry points (BASELINE configs[3], the glyph-CNN stress run): CharResNet.forward (src/char_cnn.py:46-55) on the
+ * B*S glyph stacks char_images_multifonts[src_idx] (src/models.py:829-836), before resnet_layernorm.  res_out / d_res are
+ * [B*S, 768] in the engine's compute dtype.  The workspace is sized with realise_engine_workspace_bytes(e, B, S, -1).
+ * training != 0: BatchNorm uses batch statistics and updates the running buffers; realise_engine_glyph_backward then
+ * ACCUMULATES the conv / BatchNorm parameter gradients for d_res into the grads arena. */
+int realise_engine_glyph_forward(realise_engine* e, void* stream, const int64_t* src_idx, int B, int S, int training, void* res_out);
+int realise_engine_glyph_backward(realise_engine* e, void* stream, const void* d_res);
 /* named view of an internal activation (parity tests): returns 0 and fills ptr/numel if it exists */
 int realise_engine_tap(realise_engine* e, const char* name, void** ptr, int64_t* numel);
 

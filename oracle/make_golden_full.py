@@ -1,0 +1,123 @@
+"""Full-size golden vectors (BASELINE configs[1] and configs[3]) from the UPSTREAM REFERENCE run in this container.
+
+TEST INFRASTRUCTURE; run only where /root/reference exists (a few minutes on 8 cores):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_full.py
+
+* ``arch3_b64s128_eval``  - the reference SpellBertPho2ResArch3 (12 + 4 + 3 layers) eval forward on the B=64, S=128
+  SIGHAN-shaped synthetic batch of bench.py: arg-max ids of all 8192 tokens, top-1/top-2 margins, loss, 8192 sampled logits
+  (one vocabulary slot per token) and strided samples of the intermediate taps.
+* ``resnet_b256s128``     - the reference CharResNet (src/char_cnn.py:35-55) alone on the 32768 glyph stacks of a B=256, S=128
+  batch (BASELINE configs[3]), in train mode (batch statistics; updated BN buffers stored) and in eval mode: per-block output
+  statistics and strided samples of the [32768, 768] result.
+
+Inputs are regenerated from seeds (realise_amd.data / realise_amd.init); only outputs are stored.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from realise_amd.config import RealiseConfig          # noqa: E402
+from realise_amd.data import synthetic_batch          # noqa: E402
+from realise_amd.init import init_state_dict_numpy    # noqa: E402
+from _ref_import import import_reference              # noqa: E402
+from make_golden import build_reference, put          # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def case_full_eval(models, BertConfig, name="arch3_b64s128_eval", B=64, S=128, seed=8):
+    t0 = time.time()
+    cfg = RealiseConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = init_state_dict_numpy(cfg, "arch3", seed=seed, scheme="perturbed")
+    batch = synthetic_batch(B, S, seed=seed)
+    m = build_reference(models, BertConfig, cfg, "arch3", sd_np, False)
+    taps = {}
+    hooks = [
+        m.bert.register_forward_hook(lambda mod, i, o: taps.__setitem__("bert_h", o[0])),
+        m.pho_gru.register_forward_hook(lambda mod, i, o: taps.__setitem__("pho_gru", o[1].squeeze(0))),
+        m.pho_model.register_forward_hook(lambda mod, i, o: taps.__setitem__("pho_h", o[0])),
+        m.resnet.register_forward_hook(lambda mod, i, o: taps.__setitem__("res", o)),
+        m.resnet_layernorm.register_forward_hook(lambda mod, i, o: taps.__setitem__("res_h", o)),
+        m.output_block.register_forward_hook(lambda mod, i, o: taps.__setitem__("out", o[0])),
+    ]
+    with torch.no_grad():
+        loss, logits = m(batch)[:2]
+    for h in hooks:
+        h.remove()
+    store = {"meta/B": np.int64(B), "meta/S": np.int64(S), "meta/seed": np.int64(seed), "meta/n_layers": np.int64(12),
+             "meta/train": np.int64(0), "loss": np.float64(loss.item())}
+    for k, v in taps.items():
+        put(store, "tap/" + k, v)
+    put(store, "logits", logits)
+    store["argmax"] = logits.argmax(-1).to(torch.int32).numpy()
+    top2 = logits.topk(2, dim=-1).values
+    store["margin"] = (top2[..., 0] - top2[..., 1]).to(torch.float32).numpy()
+    # one sampled vocabulary slot per token (deterministic): the arg-max slot of every 4th token, a hashed slot otherwise
+    V = logits.shape[-1]
+    flat = logits.reshape(-1, V)
+    tok = np.arange(flat.shape[0], dtype=np.int64)
+    slot = (tok * 2654435761 % V).astype(np.int64)
+    am = store["argmax"].reshape(-1).astype(np.int64)
+    slot[::4] = am[::4]
+    store["sample_slot"] = slot.astype(np.int32)
+    store["sample_logit"] = flat[torch.from_numpy(tok), torch.from_numpy(slot)].to(torch.float32).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print("[%s] loss %.6f, min margin %.3e, %.1fs" % (name, loss.item(), float(store["margin"][batch["masks"].numpy() == 1].min()),
+                                                      time.time() - t0))
+
+
+def case_resnet(models, BertConfig, name="resnet_b256s128", B=256, S=128, seed=9):
+    t0 = time.time()
+    cfg = RealiseConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = init_state_dict_numpy(cfg, "arch3", seed=seed, scheme="perturbed")
+    batch = synthetic_batch(B, S, seed=seed, with_pho=False)
+    m = build_reference(models, BertConfig, cfg, "arch3", sd_np, True)
+    ids = batch["src_idx"].view(-1)
+    store = {"meta/B": np.int64(B), "meta/S": np.int64(S), "meta/seed": np.int64(seed)}
+    for mode in ("train", "eval"):
+        m.resnet.train(mode == "train")
+        taps = {}
+        hooks = [getattr(m.resnet, "res_block%d" % b).register_forward_hook(
+            lambda mod, i, o, b=b: taps.__setitem__("block%d" % b, o)) for b in range(1, 6)]
+        with torch.no_grad():
+            images = m.char_images_multifonts.index_select(0, ids)        # src/models.py:831-834
+            res = m.resnet(images)                                        # [B*S, 768]
+        for h in hooks:
+            h.remove()
+        for k, v in taps.items():
+            put(store, "%s/%s" % (mode, k), v)
+        put(store, mode + "/res", res)
+        rows = np.arange(0, res.shape[0], 61)                             # full 768-wide rows of ~540 tokens
+        store[mode + "/rows"] = rows.astype(np.int32)
+        store[mode + "/res_rows"] = res[torch.from_numpy(rows)].to(torch.float32).numpy()
+        if mode == "train":
+            for k, v in m.resnet.state_dict().items():
+                if "running_" in k or "num_batches" in k:
+                    put(store, "buf/resnet." + k, v.to(torch.float64))
+        print("[%s] %s forward done, %.1fs" % (name, mode, time.time() - t0))
+        del taps, images, res
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    models, BertConfig = import_reference()
+    which = sys.argv[1:] or ["eval", "resnet"]
+    if "eval" in which:
+        case_full_eval(models, BertConfig)
+    if "resnet" in which:
+        case_resnet(models, BertConfig)
+
+
+if __name__ == "__main__":
+    main()

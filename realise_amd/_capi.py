@@ -83,6 +83,8 @@ SYMBOLS = {
     "realise_engine_invalidate_frozen": (None, [_P]),
     "realise_engine_forward": (_I, [_P, _P, C.POINTER(Batch)]),
     "realise_engine_backward": (_I, [_P, _P, _I, _I]),
+    "realise_engine_glyph_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "realise_engine_glyph_backward": (_I, [_P, _P, _P]),
     "realise_engine_tap": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_L)]),
     "realise_sumsq": (_I, [_P, _P, _L, _P]),
     "realise_adamw": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _I, _P, _F]),

@@ -213,6 +213,12 @@ int realise_engine_forward(realise_engine* e, void* stream, const realise_batch*
 int realise_engine_backward(realise_engine* e, void* stream, int first_bucket, int last_bucket) {
   return e ? e->impl->backward((hipStream_t)stream, first_bucket, last_bucket) : RL_ERR_ARG;
 }
+int realise_engine_glyph_forward(realise_engine* e, void* stream, const int64_t* src_idx, int B, int S, int training, void* res_out) {
+  return e ? e->impl->glyph_forward((hipStream_t)stream, src_idx, B, S, training, res_out) : RL_ERR_ARG;
+}
+int realise_engine_glyph_backward(realise_engine* e, void* stream, const void* d_res) {
+  return e ? e->impl->glyph_backward((hipStream_t)stream, d_res) : RL_ERR_ARG;
+}
 int realise_engine_tap(realise_engine* e, const char* name, void** ptr, int64_t* numel) {
   return (e && name && ptr && numel) ? e->impl->get_tap(name, ptr, numel) : RL_ERR_ARG;
 }

@@ -226,8 +226,10 @@ template <typename T> struct Engine : EngineBase {
   // ---------------------------------------------------------------- workspace planning
   void tap(const std::string& name, int64_t off, int64_t numel) { taps[name] = {off, numel}; }
 
+  // Tp < 0: glyph-only plan (BASELINE configs[3]: the CharResNet alone on B*S glyph stacks) - no BERT stacks, no logits
   Plan make_plan(int B, int S, int Tp) {
     Plan p;
+    const bool glyph_only = Tp < 0;
     p.B = B; p.S = S; p.Tp = Tp;
     Bump b;
     const int64_t e = sizeof(T), Tk = (int64_t)B * S;
@@ -248,32 +250,37 @@ template <typename T> struct Engine : EngineBase {
       }
     };
     p.mask_add = b.take(Tk * 4);
-    plan_stack(p.bert, cfg.bert_layers, "bert");
-    p.out_d = b.take(Tk * H * e);
-    p.dlogits = b.take(Tk * V * e);
-    tap("dlogits", p.dlogits, Tk * V);
+    if (!glyph_only) {
+      plan_stack(p.bert, cfg.bert_layers, "bert");
+      p.out_d = b.take(Tk * H * e);
+      p.dlogits = b.take(Tk * V * e);
+      tap("dlogits", p.dlogits, Tk * V);
+    }
     p.count = b.take(256);
     p.loss_internal = b.take(256);
     // shared backward scratch
     p.gA = b.take(Tk * H * e); p.gB = b.take(Tk * H * e); p.gC = b.take(Tk * H * e); p.gE = b.take(Tk * H * e);
-    p.gD = b.take(Tk * I * e); p.gF = b.take(Tk * 3 * H * e); p.rowdot = b.take((int64_t)B * nh * S * 4);
+    const int64_t Tw = glyph_only ? 1 : Tk;               // the wide BERT scratch is not needed by the glyph-only plan
+    p.gD = b.take(Tw * I * e); p.gF = b.take(Tw * 3 * H * e); p.rowdot = b.take((int64_t)B * nh * S * 4);
     // operands of the deferred weight gradients: a layer's four dY matrices live in the buffer set of its parity until the
     // side stream has consumed them (set 0 aliases the classic gC / gD / gF scratch)
-    p.wC1[0] = p.gC; p.wD[0] = p.gD; p.wF[0] = p.gF; p.wC2[0] = b.take(Tk * H * e);
-    p.wC1[1] = b.take(Tk * H * e); p.wC2[1] = b.take(Tk * H * e); p.wD[1] = b.take(Tk * I * e); p.wF[1] = b.take(Tk * 3 * H * e);
+    p.wC1[0] = p.gC; p.wD[0] = p.gD; p.wF[0] = p.gF; p.wC2[0] = b.take(Tw * H * e);
+    p.wC1[1] = b.take(Tw * H * e); p.wC2[1] = b.take(Tw * H * e); p.wD[1] = b.take(Tw * I * e); p.wF[1] = b.take(Tw * 3 * H * e);
     p.tn_slab2 = b.take(TN_SLAB_ELEMS * 4);
     p.tn_slab = b.take(TN_SLAB_ELEMS * 4);
     p.ln_slots = b.take(32 * 2 * 1024 * 4);
     tap("d_x0", p.gB, Tk * H);
     if (cfg.model_type == 1) {
-      plan_stack(p.pho, cfg.pho_layers, "pho_model");
-      plan_stack(p.outb, cfg.out_layers, "output_block");
-      p.gru_table = b.take(64LL * 3 * H * 4);
-      p.gru_hs = b.take((int64_t)Tp * Tk * H * e);
-      p.gru_rzn = b.take((int64_t)Tp * Tk * 3 * H * e);
-      p.gru_gh = b.take((int64_t)Tp * Tk * 3 * H * e);
-      p.gru_out = b.take(Tk * H * e);
-      tap("pho_gru", p.gru_out, Tk * H);
+      if (!glyph_only) {
+        plan_stack(p.pho, cfg.pho_layers, "pho_model");
+        plan_stack(p.outb, cfg.out_layers, "output_block");
+        p.gru_table = b.take(64LL * 3 * H * 4);
+        p.gru_hs = b.take((int64_t)Tp * Tk * H * e);
+        p.gru_rzn = b.take((int64_t)Tp * Tk * 3 * H * e);
+        p.gru_gh = b.take((int64_t)Tp * Tk * 3 * H * e);
+        p.gru_out = b.take(Tk * H * e);
+        tap("pho_gru", p.gru_out, Tk * H);
+      }
       int hin = cfg.glyph_size;
       for (int k = 0; k < 5; ++k) {
         BlockAct& a = p.blk[k];
@@ -299,8 +306,8 @@ template <typename T> struct Engine : EngineBase {
       p.fused = b.take(Tk * H * e);
       tap("res_h", p.res_h, Tk * H); tap("fused", p.fused, Tk * H);
       p.X1 = b.take(Tk * H * e); p.X2 = b.take(Tk * H * e); p.X3 = b.take(Tk * H * e); p.dz = b.take(Tk * 16);
-      p.gru_dh = b.take(Tk * H * e); p.gru_dgi = b.take(Tk * 3 * H * e); p.gru_dgh = b.take(Tk * 3 * H * e);
-      p.gru_onehot = b.take(Tk * 64 * e); p.gru_dtable = b.take(64LL * 3 * H * 4);
+      p.gru_dh = b.take(Tw * H * e); p.gru_dgi = b.take(Tw * 3 * H * e); p.gru_dgh = b.take(Tw * 3 * H * e);
+      p.gru_onehot = b.take(Tw * 64 * e); p.gru_dtable = b.take(64LL * 3 * H * 4);
       const int64_t big = (int64_t)p.blk[0].Pout * 64 * e;     // block 1 is the largest activation
       p.r_dout = b.take(big); p.r_dc2 = b.take(big); p.r_dcs = b.take(big); p.r_dh1 = b.take(big); p.r_dc1 = b.take(big);
       p.r_dx = b.take(big);
@@ -310,7 +317,7 @@ template <typename T> struct Engine : EngineBase {
       auto stap = [&](const char* n, int64_t off, int64_t bytes) { tap(std::string("scratch.") + n, off, bytes / e1); };
       stap("tn_slab", p.tn_slab, TN_SLAB_ELEMS * 4); stap("ln_slots", p.ln_slots, 32 * 2 * 1024 * 4);
       stap("gA", p.gA, Tk * H * e); stap("gB", p.gB, Tk * H * e); stap("gC", p.gC, Tk * H * e); stap("gE", p.gE, Tk * H * e);
-      stap("gD", p.gD, Tk * I * e); stap("gF", p.gF, Tk * 3 * H * e);
+      stap("gD", p.gD, Tw * I * e); stap("gF", p.gF, Tw * 3 * H * e);
       if (cfg.model_type == 1) {
         const int64_t big = (int64_t)p.blk[0].Pout * 64 * e;
         stap("r_dout", p.r_dout, big); stap("r_dc2", p.r_dc2, big); stap("r_dcs", p.r_dcs, big); stap("r_dh1", p.r_dh1, big);
@@ -325,7 +332,7 @@ template <typename T> struct Engine : EngineBase {
 
   int64_t workspace_bytes(int B, int S, int Tp) override {
     std::map<std::string, std::pair<int64_t, int64_t>> keep = taps;
-    const Plan p = make_plan(B, S, Tp > 0 ? Tp : 1);
+    const Plan p = make_plan(B, S, Tp != 0 ? Tp : 1);
     taps = keep;
     return p.total;
   }
@@ -740,6 +747,34 @@ template <typename T> struct Engine : EngineBase {
                         b.want_dlogits ? wp<T>(pl.dlogits) : nullptr));
     }
     have_fwd = b.training && b.tgt_idx != nullptr && b.want_dlogits;
+    return RL_OK;
+  }
+
+  // ---------------------------------------------------------------- glyph-only entry points (BASELINE configs[3])
+  // CharResNet alone (src/char_cnn.py:46-55) on the B*S glyph stacks selected by src_idx (src/models.py:829-836):
+  // res_out[t, :] = resnet(char_images_multifonts[src_idx[t]]), before resnet_layernorm.
+  bool have_glyph_fwd = false;
+  int glyph_forward(hipStream_t st, const int64_t* ids, int B, int S, int training, void* res_out) override {
+    if (!sh || !ws || cfg.model_type != 1 || !ids || !res_out || B < 1 || S < 1) return RL_ERR_ARG;
+    if (pl.B != B || pl.S != S || pl.Tp != -1) {
+      pl = make_plan(B, S, -1);
+      if (pl.total > ws_bytes) { fprintf(stderr, "[realise_hip] workspace too small: need %lld have %lld\n", (long long)pl.total, (long long)ws_bytes); return RL_ERR_ARG; }
+    }
+    last = realise_batch();
+    last.B = B; last.S = S; last.Tp = 1; last.training = training; last.src_idx = ids;
+    have_fwd = false; have_glyph_fwd = false;
+    const T* res = nullptr;
+    RL_TRY(resnet_forward(st, ids, &res));
+    RL_TRY(gather_rows<T>(st, res, wp<int>(pl.gu_inv), B * S, H, (T*)res_out));
+    have_glyph_fwd = training != 0;
+    return RL_OK;
+  }
+  // accumulates the gradients of the 15 conv / BatchNorm parameter tensors for d_res [B*S, 768] (per token)
+  int glyph_backward(hipStream_t st, const void* d_res) override {
+    if (!have_glyph_fwd || !d_res) { fprintf(stderr, "[realise_hip] glyph_backward without a training glyph_forward\n"); return RL_ERR_ARG; }
+    const int Tk = pl.B * pl.S;
+    RL_TRY(segment_sum<T>(st, (const T*)d_res, wp<int>(pl.gu_inv), Tk, H, wp<float>(pl.seg_acc), wp<T>(pl.r_dout), wp<int>(pl.gu_bounds)));
+    RL_TRY(resnet_backward(st, wp<T>(pl.r_dout)));
     return RL_OK;
   }
 

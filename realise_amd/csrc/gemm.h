@@ -153,6 +153,13 @@ int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, in
 template <typename T>
 int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& lb, int P, int I, int J, const TnEpi& ep);
 
+// Ping-pong 8-wave kernel (gemm_nt8.hip): bf16, dense operands, K % 64 == 0.  tile: 0 heuristic, 1 256x256, 2 256x192,
+// 3 256x128, 4 128x192.
+bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb);
+int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
+             const EpiParams<bf16_t>& ep, int tile);
+void set_nt8_probe(int mode);             // 2 no fetches, 3 no MFMA / fragment reads (results wrong)
+
 void set_tn_transpose_read(int use_tr);
 void set_nt_wide_epilogue(int on);        // A/B knob: LDS-staged 16-B-per-lane epilogue (default on)
 void set_tn_probe(int mode);

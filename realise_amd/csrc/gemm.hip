@@ -13,99 +13,10 @@
 // stages, one barrier per K-tile: the loads of tile t+1 are in flight while tile t is multiplied.
 // Operands are passed to the MFMA swapped (B-fragment first) so each lane ends up with 4 CONSECUTIVE
 // OUTPUT COLUMNS of one row: epilogue loads/stores are 8-16 B per lane.
-#include "gemm.h"
+#include "gemm_dev.h"
 #include "prof.h"
 
 namespace rl {
-
-template <typename T> struct Geo;
-template <> struct Geo<bf16_t> { static constexpr int BK = 64, VEC = 8, KSTEPS = 2; };
-template <> struct Geo<float> { static constexpr int BK = 32, VEC = 4, KSTEPS = 8; };
-
-__device__ uint4 g_zero16[4];
-
-__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-template <typename T>
-__device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, int row, int col, floatx4 v) {
-  if (row >= M || col >= N) return;
-  if (ep.alpha != 1.0f) v *= ep.alpha;
-  if (ep.bias != nullptr) v += *(const floatx4*)(ep.bias + col);
-  switch (ep.mode) {
-    case EPI_STORE: {
-      T* o = ep.out + (int64_t)row * ep.ldo + col;
-      if (ep.accumulate) v += load4<T>(o);
-      store4<T>(o, v);
-    } break;
-    case EPI_GELU: {
-      if (ep.out2 != nullptr) store4<T>(ep.out2 + (int64_t)row * ep.ldo + col, v);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = gelu_fwd<T>(v[j]);
-      store4<T>(ep.out + (int64_t)row * ep.ldo + col, v);
-    } break;
-    case EPI_DROP_RESID: {
-      const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)col;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] *= drop_mult(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + j);
-      v += load4<T>(ep.aux + (int64_t)row * ep.ldaux + col);
-      store4<T>(ep.out + (int64_t)row * ep.ldo + col, v);
-    } break;
-    case EPI_GELU_BWD: {
-      const floatx4 x = load4<T>(ep.aux + (int64_t)row * ep.ldaux + col);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] *= gelu_bwd<T>(x[j]);
-      T* o = ep.out + (int64_t)row * ep.ldo + col;
-      if (ep.accumulate) v += load4<T>(o);
-      store4<T>(o, v);
-    } break;
-    default: break;
-  }
-}
-
-// Same epilogues over 8 consecutive columns of one row (col % 8 == 0, N % 8 == 0): every global access is one
-// dwordx4 per lane (bf16) and a wave-instruction covers whole 128-byte row segments.
-template <typename T>
-__device__ __forceinline__ void epilogue8(const EpiParams<T>& ep, int M, int N, int row, int col, floatx4 a, floatx4 b) {
-  if (row >= M || col >= N) return;
-  if (ep.alpha != 1.0f) { a *= ep.alpha; b *= ep.alpha; }
-  if (ep.bias != nullptr) { a += *(const floatx4*)(ep.bias + col); b += *(const floatx4*)(ep.bias + col + 4); }
-  T* o = ep.out + (int64_t)row * ep.ldo + col;
-  switch (ep.mode) {
-    case EPI_STORE: {
-      if (ep.accumulate) { floatx4 pa, pb; load8<T>(o, pa, pb); a += pa; b += pb; }
-      store8<T>(o, a, b);
-    } break;
-    case EPI_GELU: {
-      if (ep.out2 != nullptr) store8<T>(ep.out2 + (int64_t)row * ep.ldo + col, a, b);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { a[j] = gelu_fwd<T>(a[j]); b[j] = gelu_fwd<T>(b[j]); }
-      store8<T>(o, a, b);
-    } break;
-    case EPI_DROP_RESID: {
-      const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)col;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a[j] *= drop_mult(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + j);
-        b[j] *= drop_mult(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + 4 + j);
-      }
-      floatx4 ra, rb;
-      load8<T>(ep.aux + (int64_t)row * ep.ldaux + col, ra, rb);
-      store8<T>(o, a + ra, b + rb);
-    } break;
-    case EPI_GELU_BWD: {
-      floatx4 xa, xb;
-      load8<T>(ep.aux + (int64_t)row * ep.ldaux + col, xa, xb);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { a[j] *= gelu_bwd<T>(xa[j]); b[j] *= gelu_bwd<T>(xb[j]); }
-      if (ep.accumulate) { floatx4 pa, pb; load8<T>(o, pa, pb); a += pa; b += pb; }
-      store8<T>(o, a, b);
-    } break;
-    default: break;
-  }
-}
 
 // =================================================================================================
 // NT.  WM x WN waves: (2,2) -> 128x128 tile; (4,1) -> 256x64 tile for the 64-channel glyph convs.
@@ -296,7 +207,7 @@ static int g_tn_probe = 0, g_tn_split = 0;
 void set_tn_split(int n) { g_tn_split = n; }
 void set_tn_probe(int mode) { g_tn_probe = mode; }
 void set_nt_wide_epilogue(int on) { g_nt_wide = on; }
-void set_nt_probe(int mode) { g_nt_probe = mode; }
+void set_nt_probe(int mode) { g_nt_probe = mode; set_nt8_probe(mode); }
 
 
 // =================================================================================================
@@ -476,6 +387,11 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
     return bn * (tpc == 1 ? 1.0 : 0.75 * (double)tpc);
   };
   if constexpr (sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos) && sizeof(T) == 2) {
+    // Production path for the big dense GEMMs: the ping-pong 8-wave kernel (gemm_nt8.hip), tile by chip fill.  Variants 10..34
+    // force one of its tiles / issue flavours, variant 9 forces the 4-wave kernel below (tools/nt8_probe.cpp).
+    if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 34))) {
+      if (nt8_supported(M, N, K, ep, la.ld, ldb)) return gemm_nt8(st, la.base, la.ld, B, ldb, M, N, K, ep, g_nt_variant >= 10 ? g_nt_variant - 10 : 0);
+    }
     switch (g_nt_variant) {       // experimental tile shapes (tools/nt_probe.cpp)
       case 1: return launch_nt_tile<T, ALoader, 2, 4, 2, 3>(st, la, lb, M, N, K, ep);     // 128 x 192, 8 waves, 2 stages
       case 2: return launch_nt_tile<T, ALoader, 2, 4, 3, 3>(st, la, lb, M, N, K, ep);     // 128 x 192, 3 stages

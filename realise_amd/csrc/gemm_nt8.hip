@@ -1,0 +1,349 @@
+// Ping-pong 8-wave NT GEMM for gfx950 (bf16 operands, K % 8 == 0, dense rows):  C[M,N] = A[M,K] . B[N,K]^T + fused epilogue.
+//
+// Why a second NT kernel: the LDS-DMA fill path delivers ~40 B/clk per CU whatever the tile shape, so the
+// FLOPs one fetched byte feeds - the workgroup tile - decide how close the MFMA pipe can get to its peak:
+//   128 x 128 (gemm.hip, two 4-wave workgroups per CU)   64 FLOP/B  -> fetch-bound at 62 % of the MFMA peak
+//   256 x 192 / 256 x 256 (this kernel, one per CU)      110 / 128  -> MFMA-bound
+// One 512-thread workgroup per CU, 2 waves per SIMD: waves 0-3 (group 0) and 4-7 (group 1) sit pairwise on the four SIMDs and
+// run HALF A PHASE apart (group 1 executes one extra s_barrier up front), so on every SIMD one wave is in its MEMORY segment
+// (fragment ds_reads + its share of the LDS-DMA fetches + the counted vmcnt wait) while its partner is in its MFMA segment
+// (16 v_mfma_f32_16x16x32_bf16 on register-resident fragments, s_setprio 1).
+//
+// K-tile = 64 (one 128-byte LDS row per operand row, 16-byte chunks XOR-swizzled by row: KTile).  A K-tile is consumed in NPH
+// phases: the HELD operand's fragments of the whole K-tile are read once (phase 0) and stay in registers, the STREAMED operand
+// is read SQ 16-row tiles per phase.  The ring has NS K-tile stages; the 1-KiB pieces (8 rows) of a stage are fetched in the
+// order the phases need them (held operand + streamed group 0 first) and are issued LEAD phases ahead of the phase that reads
+// their tile's first fragment, a fixed number per phase, so every s_waitcnt vmcnt(N) in the loop is a compile-time count and
+// never 0 in steady state.  Hazards (both groups, half a phase apart):
+//   RAW  a piece is waited for (own vmcnt, then a barrier) in the phase BEFORE the one that reads it;
+//   WAR  a region is re-filled >= 2 phases after the phase that read it last.
+// Both are static_assert-ed on the schedule below.
+#include "gemm_dev.h"
+#include "prof.h"
+
+namespace rl {
+
+template <int N> struct IC { static constexpr int value = N; };
+template <int N, int... Is> struct SeqGen : SeqGen<N - 1, N - 1, Is...> {};
+template <int... Is> struct SeqGen<0, Is...> {
+  template <typename F> static __device__ __forceinline__ void run(F&& f) { (f(IC<Is>{}), ...); }
+};
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { SeqGen<N>::run(f); }
+
+template <int BM_, int BN_, int WM_, int WN_, bool HOLD_B_, int SQ_, int NS_, int LEAD_, int ISSUE_AT_ = 0>
+struct Nt8Cfg {
+  // where a phase issues its fetches: 0 end of the memory segment (after the fragment reads), 1 between the MFMAs, 2 head of the
+  // memory segment (the texture-address unit serialises the 4 waves' 1-KiB requests, ~29 clk each: issuing them FIRST lets that
+  // queueing run under the fragment reads instead of after them)
+  static constexpr int ISSUE_AT = ISSUE_AT_;
+  static constexpr bool ISSUE_C = ISSUE_AT_ == 1;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, SQ = SQ_, NS = NS_, LEAD = LEAD_;
+  static constexpr bool HOLD_B = HOLD_B_;
+  static constexpr int RM = BM / WM, RN = BN / WN, MT = RM / 16, NT = RN / 16;        // per-wave tile, in rows / 16x16 tiles
+  static constexpr int HT = HOLD_B ? NT : MT, ST = HOLD_B ? MT : NT, NPH = ST / SQ;   // held / streamed tiles, phases per K-tile
+  static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static constexpr int NP = (BM + BN) / 8, NPW = NP / 8;                               // 1-KiB pieces per K-tile, per wave
+  static constexpr int HP = (HOLD_B ? BN : BM) / 8, HPW = HP / 8;                      // pieces of the held operand
+  static constexpr int SW = HOLD_B ? WM : WN, SR = HOLD_B ? RM : RN;                   // wave slices of the streamed operand
+  static constexpr int GP = SW * SQ * 2, GPW = GP / 8;                                 // pieces of one streamed group
+  static_assert(WM * WN == 8, "8 waves");
+  static_assert(RM % 16 == 0 && RN % 16 == 0 && ST % SQ == 0, "wave tile");
+  static_assert((BM + BN) % 64 == 0 && HP % 8 == 0 && GP % 8 == 0, "pieces must split evenly over the 8 waves");
+  static_assert(HPW + NPH * GPW == NPW, "piece census");
+  static_assert(NS * STAGE <= 160 * 1024, "LDS");
+  // local issue slot of a wave's s-th piece of a tile, the phase that first reads it, the last piece phase q needs
+  static constexpr int cum(int q) { return (q * NPW + NPH - 1) / NPH; }
+  static constexpr int qissue(int s) { int q = 0; while (cum(q + 1) <= s) ++q; return q; }
+  static constexpr int need_q(int s) { return s < HPW ? 0 : (s - HPW) / GPW; }
+  static constexpr int nmax(int q) { return HPW + (q + 1) * GPW - 1; }
+  static constexpr bool valid() {
+    for (int s = 0; s < NPW; ++s) {
+      // RAW: issued no later than the memory segment of the phase before its reader (MFMA-segment issue: one phase earlier)
+      if (qissue(s) - LEAD > need_q(s) - 1 - (ISSUE_C ? 1 : 0)) return false;
+      // WAR: >= 2 phases after the last reader of the region (MFMA-segment issue sits half a phase later: >= 1 phase)
+      if (qissue(s) - LEAD < need_q(s) - NS * NPH + 2 - (ISSUE_C ? 1 : 0)) return false;
+    }
+    return true;
+  }
+  static_assert(valid(), "fetch schedule violates the RAW / WAR phase rules");
+  // steady-state wait of phase q (after its own issues): everything phase q+1 reads has landed
+  static constexpr int vm(int q) {
+    const int q1 = (q + 1) % NPH, dt1 = (q + 1) / NPH;
+    const int slot = q + LEAD - (ISSUE_C ? 1 : 0);          // last issue slot completed when phase q waits
+    const int dt2 = slot / NPH, q2 = slot % NPH;
+    return dt2 * NPW + cum(q2 + 1) - 1 - (dt1 * NPW + nmax(q1));
+  }
+  // prologue: every (tile, piece) whose issue phase is negative
+  static constexpr int PRO_TILES = (LEAD + NPH - 1) / NPH;
+  static constexpr bool in_prologue(int dt, int s) { return dt * NPH + qissue(s) - LEAD < 0; }
+  static constexpr int pro_count() {
+    int n = 0;
+    for (int dt = 0; dt < PRO_TILES; ++dt) for (int s = 0; s < NPW; ++s) if (in_prologue(dt, s)) ++n;
+    return n;
+  }
+  static constexpr int VM_PRO = pro_count() - 1 - nmax(0);
+  static_assert(VM_PRO >= 0, "prologue");
+  // epilogue: per-wave fp32 transpose tile of ER rows x (RN + 4) floats inside the ring
+  static constexpr int RS = RN + 4;
+  static constexpr int er_fit() { int er = RM; while (er > 16 && 8 * er * RS * 4 > 160 * 1024) er >>= 1; return er; }
+  static constexpr int ER = er_fit();
+  static_assert((ER * RN / 8) % 64 == 0, "epilogue items per wave");
+  static constexpr int LDS = (NS * STAGE > 8 * ER * RS * 4) ? NS * STAGE : 8 * ER * RS * 4;
+};
+
+template <typename C, int PROBE, bool KTAIL = false>
+__global__ void __launch_bounds__(512)
+gemm_nt8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int M, int N, int K, int tiles_n,
+                int ntiles, EpiParams<bf16_t> ep) {
+  typedef bf16_t T;
+  typedef MmaBF16 Mma;
+  constexpr int NPW = C::NPW, NPH = C::NPH, NS = C::NS, LEAD = C::LEAD, SQ = C::SQ, HT = C::HT, MT = C::MT, NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int wm = wave / C::WN, wn = wave - wm * C::WN;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+  const int nk = (K + 63) >> 6;
+  const int ktail = KTAIL ? (K & 63) : 0;   // elements of a ragged last K-tile (multiple of 8); KTAIL = false: K % 64 == 0
+
+  // ---- this wave's pieces: LDS offset inside a stage (scalar) and per-lane source offset (row clamped into the matrix: rows
+  //      beyond M / N only feed accumulators that the epilogue never stores)
+  const int lrow = lane >> 3;
+  const int kchunk_b = (((lane & 7) ^ lrow) << 4);            // byte offset of the 16-byte chunk this lane fetches (source-side swizzle)
+  int lo[NPW];
+  uint32_t go[NPW];
+#pragma unroll
+  for (int s = 0; s < NPW; ++s) {
+    const int p = s * 8 + wave;
+    int row, is_b;
+    if (s < C::HPW) { row = p * 8; is_b = C::HOLD_B ? 1 : 0; }
+    else {
+      const int pp = p - C::HP, q = pp / C::GP, rem = pp - q * C::GP, slice = rem / (SQ * 2), j = rem - slice * (SQ * 2);
+      row = slice * C::SR + q * SQ * 16 + j * 8; is_b = C::HOLD_B ? 0 : 1;
+    }
+    lo[s] = (is_b ? C::A_BYTES : 0) + row * 128;
+    const int grow = is_b ? min(n0 + row + lrow, N - 1) : min(m0 + row + lrow, M - 1);
+    go[s] = (uint32_t)((int64_t)grow * (is_b ? ldb : lda) * 2 + kchunk_b);
+  }
+  // Fetches are raw-buffer LDS-DMA loads: resource descriptor + K-tile byte offset in SGPRs, the per-lane row/chunk offset in
+  // ONE 32-bit VGPR per piece - no vector ALU work per fetch (a 64-bit flat address costs two v_lshl_add_u64 each, which showed
+  // up as +40 % on the fetch-only probe).  A ragged last K-tile (K % 64 != 0) parks the chunks past K on an offset beyond
+  // num_records: the buffer range check returns zeros for them.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((int64_t)(M - 1) * lda + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(((int64_t)(N - 1) * ldb + K) * 2), 0x00020000);
+  const bool lane_past_k = KTAIL && ktail != 0 && kchunk_b >= 2 * ktail;
+  auto issue = [&](auto s_c, int stage, int ktile) {
+    constexpr int s = decltype(s_c)::value;
+    if constexpr (PROBE == 2) return;
+    constexpr bool is_b = (s < C::HPW) ? C::HOLD_B : !C::HOLD_B;
+    uint32_t voff = go[s];
+    if constexpr (KTAIL) { if (ktail != 0 && ktile == nk - 1) voff = lane_past_k ? 0xFFFFFF00u : voff; }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_b ? rsB : rsA, (__attribute__((address_space(3))) void*)(smem + stage * C::STAGE + lo[s]), 16,
+                                             voff, ktile * 128, 0, 0);
+  };
+
+  // ---- fragment addressing: lane part (row l15 of a 16-row tile, chunk ks*4+g swizzled by the row) + wave slice
+  int fa[2], fb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int lane_sw = l15 * 128 + ((((ks << 2) + g) ^ (l15 & 7)) << 4);
+    fa[ks] = wm * C::RM * 128 + lane_sw;
+    fb[ks] = C::A_BYTES + wn * C::RN * 128 + lane_sw;
+  }
+  floatx4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t hf[HT][2], sf[SQ][2];
+
+  // ---- prologue: the pieces the steady state would have issued before phase 0
+  static_for<C::PRO_TILES>([&](auto dt_c) {
+    constexpr int dt = decltype(dt_c)::value;
+    if (dt < nk) {
+      static_for<NPW>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        if constexpr (C::in_prologue(dt, s)) issue(s_c, dt % NS, dt);
+      });
+    }
+  });
+  if (nk >= C::PRO_TILES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::VM_PRO) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }     // group 1 runs half a phase behind
+
+  auto phase = [&](auto par_c, auto q_c, int t) {
+    constexpr int PAR = decltype(par_c)::value, q = decltype(q_c)::value;
+    constexpr int dt2 = (q + LEAD) / NPH, q2 = (q + LEAD) % NPH, SBASE = PAR * C::STAGE;
+    // ---------------- memory segment
+    constexpr int dtw = (q + LEAD - (C::ISSUE_C ? 1 : 0)) / NPH;       // tile of the last issue slot before this phase's wait
+    const bool do_issue = t + dt2 < nk;
+    auto issue_all = [&]() {
+      if (do_issue) {
+        static_for<NPW>([&](auto s_c) {
+          constexpr int s = decltype(s_c)::value;
+          if constexpr (s >= C::cum(q2) && s < C::cum(q2 + 1)) issue(s_c, (PAR + dt2) % NS, t + dt2);
+        });
+      }
+    };
+    if constexpr (C::ISSUE_AT == 2) { issue_all(); __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (PROBE != 3) {
+      if constexpr (q == 0) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            hf[h][ks] = *(const bf16x8_t*)(smem + SBASE + h * 2048 + (C::HOLD_B ? fb[ks] : fa[ks]));
+      }
+#pragma unroll
+      for (int i = 0; i < SQ; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          sf[i][ks] = *(const bf16x8_t*)(smem + SBASE + (q * SQ + i) * 2048 + (C::HOLD_B ? fa[ks] : fb[ks]));
+    }
+    if constexpr (C::ISSUE_AT == 0) { __builtin_amdgcn_sched_barrier(0); issue_all(); }
+    if (t + dtw < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::vm(q)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- MFMA segment (ISSUE_C: this phase's fetches are spread between the MFMAs)
+    constexpr int NM = 2 * SQ * HT, NI = C::cum(q2 + 1) - C::cum(q2);
+    if constexpr (PROBE != 3) __builtin_amdgcn_s_setprio(1);
+    static_for<NM>([&](auto m_c) {
+      constexpr int m = decltype(m_c)::value, ks = m / (SQ * HT), i = (m / HT) % SQ, h = m % HT;
+      if constexpr (PROBE != 3) {
+        if constexpr (C::HOLD_B) acc[q * SQ + i][h] = Mma::mma(hf[h][ks], sf[i][ks], acc[q * SQ + i][h]);
+        else acc[h][q * SQ + i] = Mma::mma(sf[i][ks], hf[h][ks], acc[h][q * SQ + i]);
+      }
+      if constexpr (C::ISSUE_C) {
+        static_for<NI>([&](auto j_c) {
+          constexpr int j = decltype(j_c)::value;
+          if constexpr (m + 1 == ((j + 1) * NM) / (NI + 1)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (do_issue) issue(IC<C::cum(q2) + j>{}, (PAR + dt2) % NS, t + dt2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+      }
+    });
+    if constexpr (PROBE != 3) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  for (int tb = 0; tb < nk; tb += NS) {
+    static_for<NS>([&](auto par_c) {
+      constexpr int PAR = decltype(par_c)::value;
+      if (tb + PAR < nk) static_for<NPH>([&](auto q_c) { phase(par_c, q_c, tb + PAR); });
+    });
+  }
+  if (grp == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }     // barrier census: group 1 took one extra up front
+
+  // ---------------- epilogue: per-wave fp32 transpose through LDS, 8 consecutive columns (16 B of bf16) per lane
+  constexpr int RS = C::RS, ER = C::ER, ITEMS = C::RN / 8, NIT = ER * ITEMS / 64;
+  float* et = (float*)smem + wave * (ER * RS);
+  const int row_w = m0 + wm * C::RM, col_w = n0 + wn * C::RN;
+#pragma unroll
+  for (int c = 0; c < C::RM / ER; ++c) {
+#pragma unroll
+    for (int i = 0; i < ER / 16; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) *(floatx4*)(et + (i * 16 + l15) * RS + j * 16 + 4 * g) = acc[c * (ER / 16) + i][j];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = lane + 64 * it, r = e / ITEMS, c8 = e - r * ITEMS;
+      const floatx4 v0 = *(const floatx4*)(et + r * RS + c8 * 8), v1 = *(const floatx4*)(et + r * RS + c8 * 8 + 4);
+      epilogue8<T>(ep, M, N, row_w + c * ER + r, col_w + c8 * 8, v0, v1);
+    }
+  }
+}
+
+static int g_nt8_probe = 0;
+void set_nt8_probe(int mode) { g_nt8_probe = mode; }
+
+template <typename C, bool KTAIL = false>
+static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
+                          const EpiParams<bf16_t>& ep) {
+  const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (N + C::BN - 1) / C::BN, ntiles = tiles_m * tiles_n;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<C, 0, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    if constexpr (!KTAIL) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<C, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    }
+    attr_set = true;
+  }
+  ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
+  if constexpr (!KTAIL) {
+    if (g_nt8_probe == 2) { hipLaunchKernelGGL((gemm_nt8_kernel<C, 2>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
+    if (g_nt8_probe == 3) { hipLaunchKernelGGL((gemm_nt8_kernel<C, 3>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
+  }
+  hipLaunchKernelGGL((gemm_nt8_kernel<C, 0, KTAIL>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
+  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+}
+
+//             BM   BN  WM WN hold_B SQ NS LEAD issue_in_MFMA_segment
+typedef Nt8Cfg<256, 256, 2, 4, true, 2, 2, 5> Cfg256x256;      // wave 128 x 64, 4 phases of 16 MFMAs
+typedef Nt8Cfg<256, 192, 4, 2, false, 2, 2, 4> Cfg256x192;     // wave  64 x 96, 3 phases of 16 MFMAs
+typedef Nt8Cfg<256, 128, 4, 2, true, 2, 3, 4> Cfg256x128;      // wave  64 x 64, 2 phases of 16 MFMAs, 3 stages
+typedef Nt8Cfg<128, 192, 2, 4, true, 2, 3, 4> Cfg128x192;      // wave  64 x 48, 2 phases of 12 MFMAs, 3 stages
+typedef Nt8Cfg<256, 256, 2, 4, true, 2, 2, 6, 1> Cfg256x256c;
+typedef Nt8Cfg<256, 192, 4, 2, false, 2, 2, 5, 1> Cfg256x192c;
+typedef Nt8Cfg<256, 128, 4, 2, true, 2, 3, 5, 1> Cfg256x128c;
+typedef Nt8Cfg<128, 192, 2, 4, true, 2, 3, 5, 1> Cfg128x192c;
+typedef Nt8Cfg<256, 256, 2, 4, true, 2, 2, 5, 2> Cfg256x256f;
+typedef Nt8Cfg<256, 192, 4, 2, false, 2, 2, 4, 2> Cfg256x192f;
+typedef Nt8Cfg<256, 128, 4, 2, true, 2, 3, 4, 2> Cfg256x128f;
+typedef Nt8Cfg<128, 192, 2, 4, true, 2, 3, 4, 2> Cfg128x192f;
+
+bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb) {
+  return (K % 8) == 0 && K >= 64 && (N % 8) == 0 && (ep.ldo % 8) == 0 && (ep.aux == nullptr || (ep.ldaux % 8) == 0) &&
+         (lda % 8) == 0 && (ldb % 8) == 0 && M >= 1 && N >= 8 &&
+         (int64_t)M * lda * 2 < 0xFFFFFF00ll && (int64_t)N * ldb * 2 < 0xFFFFFF00ll;
+}
+
+// tile: 0 = heuristic, 1 = 256x256, 2 = 256x192, 3 = 256x128, 4 = 128x192; +10: fetches issued inside the MFMA segments
+int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
+             const EpiParams<bf16_t>& ep, int tile) {
+  if (!nt8_supported(M, N, K, ep, lda, ldb)) return RL_ERR_ARG;
+  if (K % 64) return launch_nt8_cfg<Cfg128x192, true>(st, A, lda, B, ldb, M, N, K, ep);     // ragged K: one tile shape carries the tail code
+  const int flavour = (tile / 10) * 10;      // 10..14: fetches issued between the MFMAs; 20..24: at the head of the memory segment
+  tile -= flavour;
+  if (tile == 0) {
+    // chip fill: rounds of 256 one-per-CU workgroups; among the shapes pick the least (rounds x MFMA time of one tile), ties to
+    // the larger tile (fewer fetched bytes per flop)
+    struct Cand { int id, bm, bn; } cands[4] = {{1, 256, 256}, {2, 256, 192}, {3, 256, 128}, {4, 128, 192}};
+    double best = 1e30;
+    for (const Cand& c : cands) {
+      const long tiles = (long)((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn);
+      const long rounds = (tiles + 255) / 256;
+      const double fetch_pen = 1.0 + 24.0 / (2.0 * c.bm * c.bn / (double)(c.bm + c.bn));   // 256x256 -> 1.19, 128x192 -> 1.31
+      const double cost = (double)rounds * c.bm * c.bn * fetch_pen;
+      if (cost < best) { best = cost; tile = c.id; }
+    }
+  }
+  switch (tile + flavour) {
+    case 1: return launch_nt8_cfg<Cfg256x256>(st, A, lda, B, ldb, M, N, K, ep);
+    case 2: return launch_nt8_cfg<Cfg256x192>(st, A, lda, B, ldb, M, N, K, ep);
+    case 3: return launch_nt8_cfg<Cfg256x128>(st, A, lda, B, ldb, M, N, K, ep);
+    case 4: return launch_nt8_cfg<Cfg128x192>(st, A, lda, B, ldb, M, N, K, ep);
+    case 11: return launch_nt8_cfg<Cfg256x256c>(st, A, lda, B, ldb, M, N, K, ep);
+    case 12: return launch_nt8_cfg<Cfg256x192c>(st, A, lda, B, ldb, M, N, K, ep);
+    case 13: return launch_nt8_cfg<Cfg256x128c>(st, A, lda, B, ldb, M, N, K, ep);
+    case 14: return launch_nt8_cfg<Cfg128x192c>(st, A, lda, B, ldb, M, N, K, ep);
+    case 21: return launch_nt8_cfg<Cfg256x256f>(st, A, lda, B, ldb, M, N, K, ep);
+    case 22: return launch_nt8_cfg<Cfg256x192f>(st, A, lda, B, ldb, M, N, K, ep);
+    case 23: return launch_nt8_cfg<Cfg256x128f>(st, A, lda, B, ldb, M, N, K, ep);
+    case 24: return launch_nt8_cfg<Cfg128x192f>(st, A, lda, B, ldb, M, N, K, ep);
+    default: return RL_ERR_ARG;
+  }
+}
+
+}  // namespace rl

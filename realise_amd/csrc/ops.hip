@@ -739,6 +739,22 @@ template <typename T> int segment_sum(hipStream_t st, const T* x, const int* inv
 template int segment_sum<bf16_t>(hipStream_t, const bf16_t*, const int*, int, int, float*, bf16_t*, const int*);
 template int segment_sum<float>(hipStream_t, const float*, const int*, int, int, float*, float*, const int*);
 
+// out[t, :] = x[inv[t], :]  (per-distinct-glyph rows back to per-token rows; the glyph-only entry point, BASELINE configs[3])
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ x, const int* __restrict__ inv, int T_, int C, T* __restrict__ out) {
+  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int t = blockIdx.y;
+  if (c >= C) return;
+  store4<T>(out + (int64_t)t * C + c, load4<T>(x + (int64_t)inv[t] * C + c));
+}
+template <typename T> int gather_rows(hipStream_t st, const T* x, const int* inv, int T_, int C, T* out) {
+  if (C & 3) return RL_ERR_ARG;
+  hipLaunchKernelGGL((gather_rows_kernel<T>), dim3((C / 4 + 63) / 64, T_), dim3(64), 0, st, x, inv, T_, C, out);
+  return RL_LAUNCH_CHECK();
+}
+template int gather_rows<bf16_t>(hipStream_t, const bf16_t*, const int*, int, int, bf16_t*);
+template int gather_rows<float>(hipStream_t, const float*, const int*, int, int, float*);
+
 // ---------------------------------------------------------------------------------------------
 // Row-wise argmax: one 256-thread workgroup per row, 16-byte loads, (value, index) pairs reduced with the
 // first-occurrence tie rule.

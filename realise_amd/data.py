@@ -59,3 +59,22 @@ def synthetic_batch(batch_size, seq_len, vocab_size=21128, seed=0, with_pho=True
         batch["pho_idx"] = torch.from_numpy(pho)
         batch["pho_lens"] = [int(x) for x in lens]
     return batch
+
+
+def synthetic_vocab(vocab_size=21128):
+    """A BERT-style Chinese vocabulary stand-in (``vocab.txt`` of chinese-roberta-wwm-ext is not in the tree): the special
+    tokens at their real ids ([PAD] 0, [UNK] 100, [CLS] 101, [SEP] 102, [MASK] 103), ``[unusedN]`` fillers, printable ASCII,
+    a few ``##`` word pieces, then consecutive CJK Unified Ideographs from U+4E00.  Deterministic; used by the glyph /
+    pinyin / trainer tests and their fixture generators."""
+    toks = []
+    special = {0: "[PAD]", 100: "[UNK]", 101: "[CLS]", 102: "[SEP]", 103: "[MASK]"}
+    for i in range(106):
+        toks.append(special.get(i, "[unused%d]" % i))
+    toks += [chr(c) for c in range(33, 127)]                   # single printable ASCII characters
+    toks += ["##%s" % chr(c) for c in range(97, 123)]          # word pieces: multi-character -> blank glyph, pinyin 'U'
+    toks += ["the", "##ing", "2019"]
+    cp = 0x4E00
+    while len(toks) < vocab_size:
+        toks.append(chr(cp))
+        cp += 1
+    return toks[:vocab_size]
