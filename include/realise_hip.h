@@ -206,6 +206,8 @@ int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, in
                   float beta2, float eps, float weight_decay, int64_t step, int correct_bias,
                   const float* grad_norm_sq, float max_grad_norm);
 int realise_fill_f32(void* stream, float* p, float value, int64_t n);
+/* widen a compute-dtype tensor to fp32 (the reference returns fp32 logits, src/models.py:859); 16-byte aligned pointers */
+int realise_cast_to_f32(void* stream, int dtype, const void* src, float* dst, int64_t n);
 
 /* Per-launch timing of the MFMA kernel families with HIP events on the launch stream (bench.py roofline).
  * family: 0 gemm_nt, 1 conv_nt (implicit im2col), 2 gemm_tn, 3 conv_tn, 4 attention fwd, 5 attention bwd.

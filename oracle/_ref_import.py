@@ -26,8 +26,15 @@ def _stub(name, **attrs):
     sys.modules[name] = m
 
 
+_CACHE = None
+
+
 def import_reference():
-    """Returns (models_module, BertConfig) of the upstream reference."""
+    """Returns (models_module, BertConfig) of the upstream reference (imported once per process: a second import would hand out
+    a BertConfig class the cached ``models`` module does not recognise)."""
+    global _CACHE
+    if _CACHE is not None:
+        return _CACHE
     if not reference_available():
         raise RuntimeError("reference tree not present at %s" % REFERENCE_ROOT)
     sys.dont_write_bytecode = True
@@ -47,4 +54,5 @@ def import_reference():
         del sys.modules[k]
     from transformers import BertConfig  # vendored 2.2.2
     import models
-    return models, BertConfig
+    _CACHE = (models, BertConfig)
+    return _CACHE

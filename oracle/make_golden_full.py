@@ -83,7 +83,7 @@ def case_resnet(models, BertConfig, name="resnet_b256s128", B=256, S=128, seed=9
     m = build_reference(models, BertConfig, cfg, "arch3", sd_np, True)
     ids = batch["src_idx"].view(-1)
     store = {"meta/B": np.int64(B), "meta/S": np.int64(S), "meta/seed": np.int64(seed)}
-    for mode in ("train", "eval"):
+    for mode in ("eval", "train"):        # eval first: it must see the INITIAL running statistics, the train pass updates them
         m.resnet.train(mode == "train")
         taps = {}
         hooks = [getattr(m.resnet, "res_block%d" % b).register_forward_hook(

@@ -89,6 +89,7 @@ SYMBOLS = {
     "realise_sumsq": (_I, [_P, _P, _L, _P]),
     "realise_adamw": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _I, _P, _F]),
     "realise_fill_f32": (_I, [_P, _P, _F, _L]),
+    "realise_cast_to_f32": (_I, [_P, _I, _P, _P, _L]),
     "realise_profile_enable": (_I, [_I]),
     "realise_profile_disable": (None, []),
     "realise_profile_pause": (None, [_I]),

@@ -241,6 +241,12 @@ int realise_profile_read(int kernel_family, long long* count, double* total_ms, 
   if (kernel_family < 0 || kernel_family >= PK_COUNT || !count || !total_ms || !total_work) return RL_ERR_ARG;
   return prof_read(kernel_family, count, total_ms, total_work);
 }
+int realise_cast_to_f32(void* stream, int dtype, const void* src, float* dst, int64_t n) {
+  if (!src || !dst) return RL_ERR_ARG;
+  if (dtype == REALISE_BF16) return cast_to_f32<bf16_t>((hipStream_t)stream, (const bf16_t*)src, dst, n);
+  if (dtype == REALISE_F32) return cast_to_f32<float>((hipStream_t)stream, (const float*)src, dst, n);
+  return RL_ERR_ARG;
+}
 int realise_fill_f32(void* stream, float* p, float value, int64_t n) { return fill_f32((hipStream_t)stream, p, value, n); }
 
 }  // extern "C"

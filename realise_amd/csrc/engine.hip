@@ -48,6 +48,7 @@ template <typename T> struct Engine : EngineBase {
   char* ws = nullptr;      // workspace
   int64_t ws_bytes = 0;
   int H, nh, I, V;
+  int Vp;                  // V rounded up to 64: row pitch of dlogits and of the classifier's W^T shadow (128-byte aligned rows)
 
   // ---------------------------------------------------------------- shadows (offsets in bytes)
   struct LayerSh { int64_t qkv_w, qkv_wT, ao_w, ao_wT, in_w, in_wT, out_w, out_wT; };
@@ -125,7 +126,7 @@ template <typename T> struct Engine : EngineBase {
 
   Engine(const realise_config& c, float* p, float* g, float* pu, float* fz, float* bf, int64_t* bi)
       : cfg(c), L(build_layout(c)), P(p), G(g), PU(pu), FZ(fz), BF(bf), BI(bi) {
-    H = c.hidden; nh = c.heads; I = c.intermediate; V = c.vocab;
+    H = c.hidden; nh = c.heads; I = c.intermediate; V = c.vocab; Vp = (V + 63) & ~63;
     plan_shadows();
   }
 
@@ -145,7 +146,7 @@ template <typename T> struct Engine : EngineBase {
     };
     plan_stack(sh_bert, cfg.bert_layers);
     sh_cls_w = b.take((int64_t)V * H * e);
-    sh_cls_wT = b.take((int64_t)V * H * e);
+    sh_cls_wT = b.take((int64_t)Vp * H * e);      // [H][Vp], columns >= V stay zero (the shadow arena is zero-initialised)
     if (cfg.model_type == 1) {
       plan_stack(sh_pho, cfg.pho_layers);
       plan_stack(sh_out, cfg.out_layers);
@@ -177,9 +178,9 @@ template <typename T> struct Engine : EngineBase {
       std::vector<CastDesc>& d = desc_host;       // member: stays alive while the async upload is in flight
       d.clear();
       int tiles = 0;
-      auto add = [&](int64_t src, int R, int C, int64_t dst, int64_t dstT) {
+      auto add = [&](int64_t src, int R, int C, int64_t dst, int64_t dstT, int ldT = 0) {
         CastDesc x;
-        x.src = pp(src); x.dst = sp<T>(dst); x.dstT = sp<T>(dstT); x.R = R; x.C = C;
+        x.src = pp(src); x.dst = sp<T>(dst); x.dstT = sp<T>(dstT); x.R = R; x.C = C; x.ldT = ldT > 0 ? ldT : R;
         x.tile_begin = tiles; x.tiles_c = (C + 63) / 64;
         tiles += x.tiles_c * ((R + 63) / 64);
         d.push_back(x);
@@ -194,7 +195,7 @@ template <typename T> struct Engine : EngineBase {
         }
       };
       add_stack(L.bert, sh_bert);
-      add(L.cls_w, V, H, sh_cls_w, sh_cls_wT);
+      add(L.cls_w, V, H, sh_cls_w, sh_cls_wT, Vp);
       if (cfg.model_type == 1) {
         add_stack(L.pho, sh_pho);
         add_stack(L.outb, sh_out);
@@ -253,11 +254,11 @@ template <typename T> struct Engine : EngineBase {
     if (!glyph_only) {
       plan_stack(p.bert, cfg.bert_layers, "bert");
       p.out_d = b.take(Tk * H * e);
-      p.dlogits = b.take(Tk * V * e);
-      tap("dlogits", p.dlogits, Tk * V);
+      p.dlogits = b.take(Tk * Vp * e);
+      tap("dlogits", p.dlogits, Tk * Vp);
     }
     p.count = b.take(256);
-    p.loss_internal = b.take(256);
+    p.loss_internal = b.take(Tk * 4 + 256);       // per-row loss terms (ordered fold: reproducible loss)
     // shared backward scratch
     p.gA = b.take(Tk * H * e); p.gB = b.take(Tk * H * e); p.gC = b.take(Tk * H * e); p.gE = b.take(Tk * H * e);
     const int64_t Tw = glyph_only ? 1 : Tk;               // the wide BERT scratch is not needed by the glyph-only plan
@@ -744,7 +745,7 @@ template <typename T> struct Engine : EngineBase {
     if (b.tgt_idx != nullptr) {
       if (!b.loss_masks || !b.loss_out) return RL_ERR_ARG;
       RL_TRY(ce_loss<T>(st, (const T*)b.logits_out, V, b.tgt_idx, b.loss_masks, Tk, V, b.loss_out, wp<float>(pl.count),
-                        b.want_dlogits ? wp<T>(pl.dlogits) : nullptr));
+                        b.want_dlogits ? wp<T>(pl.dlogits) : nullptr, wp<float>(pl.loss_internal), Vp));
     }
     have_fwd = b.training && b.tgt_idx != nullptr && b.want_dlogits;
     return RL_OK;
@@ -788,9 +789,9 @@ template <typename T> struct Engine : EngineBase {
     const DropParams dfin = site(5000, cfg.hidden_dropout);
     const T* top = cfg.model_type == 1 ? wp<T>(pl.outb.layers.back().y2) : wp<T>(pl.bert.layers.back().y2);
     const T* cls_in = dfin.thresh ? wp<T>(pl.out_d) : top;
-    { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(L.cls_b); te.out = gp(L.cls_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dl, V, cls_in, H, Tk, V, H, te)); }
+    { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(L.cls_b); te.out = gp(L.cls_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dl, Vp, cls_in, H, Tk, V, H, te)); }
     { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H;
-      RL_TRY(gemm_nt<T>(st, dl, V, sp<T>(sh_cls_wT), V, Tk, H, V, ep)); }
+      RL_TRY(gemm_nt<T>(st, dl, Vp, sp<T>(sh_cls_wT), Vp, Tk, H, Vp, ep)); }      // K = Vp: the padding columns are exact zeros on both sides
     if (dfin.thresh) RL_TRY(dropout_apply<T>(st, gA, gA, Tk, H, dfin));
     return RL_OK;
   }

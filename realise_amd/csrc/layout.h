@@ -155,7 +155,9 @@ inline Layout build_layout(const realise_config& c) {
     L.gru_b_ih = add(AR_TRAIN, "pho_gru.bias_ih_l0", {3 * H});
     L.pho_emb = add(AR_TRAIN, "pho_embeddings.weight", {c.pho_vocab, H});
     close_bucket(begin);
-    L.glyph = add(AR_FROZEN, "char_images_multifonts", {V, c.num_fonts, c.glyph_size, c.glyph_size});
+    // models.py:674-679: one font -> nn.Embedding "char_images.weight" [V, 1024]; several -> Parameter [V, F, 32, 32].  Same bytes.
+    if (c.num_fonts == 1) L.glyph = add(AR_FROZEN, "char_images.weight", {V, (int64_t)c.glyph_size * c.glyph_size});
+    else L.glyph = add(AR_FROZEN, "char_images_multifonts", {V, c.num_fonts, c.glyph_size, c.glyph_size});
   }
   // ---- bert layers in groups of <= 4 (one bucket each)
   {

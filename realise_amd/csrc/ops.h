@@ -69,10 +69,12 @@ template <typename T> int dropout_apply(hipStream_t st, const T* x, T* y, int ro
 
 // ---- masked cross-entropy (K13) ---------------------------------------------------------------
 // loss_out[0] = mean over rows with loss_mask==1 of CE(logits[row], labels[row]); dlogits (optional)
-// = d loss / d logits.  count_buf: 1 float scratch.
+// = d loss / d logits.  count_buf: 1 float scratch.  Rows whose label is -100 (CrossEntropyLoss's ignore_index) are skipped in
+// the mean; any other label outside [0, V) turns the loss into NaN.  row_loss (optional, `rows` floats): per-row terms folded in
+// a fixed order - the loss is then bitwise reproducible; nullptr: one float atomicAdd per row.
 template <typename T>
 int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask, int rows, int V,
-            float* loss_out, float* count_buf, T* dlogits);
+            float* loss_out, float* count_buf, T* dlogits, float* row_loss = nullptr, int64_t ld_dl = 0);   // ld_dl: row pitch of dlogits (0: ld)
 
 // ---- eval decode (run.py:262-263): ids[row] = argmax_v logits[row][v], first maximum wins (numpy / torch semantics), a NaN
 // counts as the maximum.  Only the ids leave the device (32 KB instead of the 692 MB fp32 logits of run.py:262).
@@ -168,11 +170,12 @@ template <typename T> int gather_rows(hipStream_t st, const T* x, const int* inv
 
 // ---- weight shadows (operand copies in the compute dtype) ----------------------------------------
 template <typename T> int cast_copy(hipStream_t st, const float* src, T* dst, int64_t n);
+template <typename T> int cast_to_f32(hipStream_t st, const T* src, float* dst, int64_t n);     // 16-byte aligned pointers
 // src fp32 [R][C] -> dst [R][C] (optional) and dstT [C][R] (optional)
 template <typename T> int cast_transpose(hipStream_t st, const float* src, int R, int C, T* dst, T* dstT);
 // many matrices in ONE launch (the per-step refresh of every Linear weight's W and W^T operand copies): `descs` is a
 // device array of n descriptors sorted by tile_begin, total_tiles 64x64 tiles overall
-struct CastDesc { const float* src; void* dst; void* dstT; int R, C; int tile_begin, tiles_c; };
+struct CastDesc { const float* src; void* dst; void* dstT; int R, C; int tile_begin, tiles_c; int ldT; };   // ldT: row pitch of dstT (>= R)
 template <typename T> int cast_transpose_multi(hipStream_t st, const CastDesc* descs, int n, int total_tiles);
 // conv weight [Co][Ci][KH][KW] fp32 -> fwd [Co][KH*KW][Cpad] and dgrad [Ci_rows][KH*KW][Co] (rows >= Ci zero)
 template <typename T>

@@ -402,9 +402,12 @@ template int dropout_apply<float>(hipStream_t, const float*, float*, int, int, D
 // ---------------------------------------------------------------------------------------------
 // Masked cross-entropy (models.py:862-869): one 256-thread workgroup per token row.
 // ---------------------------------------------------------------------------------------------
-__global__ void count_active_kernel(const int64_t* __restrict__ m, int n, float* out) {
+// rows that enter the loss: loss_mask == 1 (models.py:864) and label != -100 (CrossEntropyLoss's default ignore_index)
+#define RL_CE_IGNORE_INDEX (-100)
+__global__ void count_active_kernel(const int64_t* __restrict__ m, const int64_t* __restrict__ labels, int n, float* out) {
   float c = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += (m[i] == 1) ? 1.f : 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    c += (m[i] == 1 && labels[i] != RL_CE_IGNORE_INDEX) ? 1.f : 0.f;
   c = wave_sum(c);
   if ((threadIdx.x & 63) == 0 && c != 0.f) atomicAdd(out, c);
 }
@@ -423,13 +426,18 @@ __device__ __forceinline__ float block_reduce(float v, float* sm, bool is_max) {
 template <typename T>
 __global__ void __launch_bounds__(256)
 ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels, const int64_t* __restrict__ loss_mask,
-          int V, float* loss_out, const float* __restrict__ count, T* __restrict__ dlogits) {
+          int V, float* loss_out, const float* __restrict__ count, T* __restrict__ dlogits, float* __restrict__ row_loss, int64_t ld_dl) {
   __shared__ float sm[4];
   const int row = blockIdx.x;
   const T* x = logits + (int64_t)row * ld;
-  T* dx = dlogits ? dlogits + (int64_t)row * ld : nullptr;
-  const bool active = loss_mask[row] == 1;
+  T* dx = dlogits ? dlogits + (int64_t)row * ld_dl : nullptr;
+  // a padded gradient row (ld_dl > V: 128-byte aligned rows for the GEMMs that consume it) keeps exact zeros in its tail
+  if (dx != nullptr)
+    for (int c = V + threadIdx.x * 4; c < ld_dl; c += 1024) store4<T>(dx + c, floatx4{0.f, 0.f, 0.f, 0.f});
+  const int64_t lab64 = labels[row];
+  const bool active = loss_mask[row] == 1 && lab64 != RL_CE_IGNORE_INDEX;
   if (!active) {
+    if (row_loss != nullptr && threadIdx.x == 0) row_loss[row] = 0.f;
     if (dx != nullptr)
       for (int c = threadIdx.x * 4; c < V; c += 1024) store4<T>(dx + c, floatx4{0.f, 0.f, 0.f, 0.f});
     return;
@@ -447,9 +455,15 @@ ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ 
   }
   s = block_reduce(s, sm, false);
   const float inv_n = 1.0f / count[0];
-  const int lab = (int)labels[row];
+  // a label outside [0, V) is an error PyTorch raises on; here it poisons the loss (NaN) instead of reading out of bounds
+  const bool lab_ok = lab64 >= 0 && lab64 < V;
+  const int lab = lab_ok ? (int)lab64 : 0;
   const float lse = mx + logf(s);
-  if (threadIdx.x == 0) atomicAdd(loss_out, (lse - to_f<T>(x[lab])) * inv_n);
+  if (threadIdx.x == 0) {
+    const float l = lab_ok ? (lse - to_f<T>(x[lab])) * inv_n : __builtin_nanf("");
+    if (row_loss != nullptr) row_loss[row] = l;          // deterministic path: per-row terms, folded in a fixed order below
+    else atomicAdd(loss_out, l);
+  }
   if (dx != nullptr) {
     const float inv_s = 1.0f / s;
     for (int c = threadIdx.x * 4; c < V; c += 1024) {
@@ -461,18 +475,33 @@ ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ 
     }
   }
 }
+// loss = sum of the per-row terms in a fixed order (256 strided partial sums, then a fixed tree): bitwise reproducible
+__global__ void __launch_bounds__(256) ce_fold_kernel(const float* __restrict__ row_loss, int rows, float* loss_out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < rows; i += 256) s += row_loss[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss_out = red[0];
+}
 template <typename T>
 int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask, int rows, int V,
-            float* loss_out, float* count_buf, T* dlogits) {
-  if ((V & 3) || (ld & 3)) return RL_ERR_ARG;
+            float* loss_out, float* count_buf, T* dlogits, float* row_loss, int64_t ld_dl) {
+  if (ld_dl <= 0) ld_dl = ld;
+  if ((V & 3) || (ld & 3) || (ld_dl & 3) || ld_dl < V) return RL_ERR_ARG;
   (void)hipMemsetAsync(loss_out, 0, sizeof(float), st);
   (void)hipMemsetAsync(count_buf, 0, sizeof(float), st);
-  hipLaunchKernelGGL(count_active_kernel, dim3(64), dim3(256), 0, st, loss_mask, rows, count_buf);
-  hipLaunchKernelGGL((ce_kernel<T>), dim3(rows), dim3(256), 0, st, logits, ld, labels, loss_mask, V, loss_out, count_buf, dlogits);
+  hipLaunchKernelGGL(count_active_kernel, dim3(64), dim3(256), 0, st, loss_mask, labels, rows, count_buf);
+  hipLaunchKernelGGL((ce_kernel<T>), dim3(rows), dim3(256), 0, st, logits, ld, labels, loss_mask, V, loss_out, count_buf, dlogits, row_loss, ld_dl);
+  if (row_loss != nullptr) hipLaunchKernelGGL(ce_fold_kernel, dim3(1), dim3(256), 0, st, row_loss, rows, loss_out);
   return RL_LAUNCH_CHECK();
 }
-template int ce_loss<bf16_t>(hipStream_t, const bf16_t*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, bf16_t*);
-template int ce_loss<float>(hipStream_t, const float*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, float*);
+template int ce_loss<bf16_t>(hipStream_t, const bf16_t*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, bf16_t*, float*, int64_t);
+template int ce_loss<float>(hipStream_t, const float*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, float*, float*, int64_t);
 
 // ---------------------------------------------------------------------------------------------
 // Gate fusion (models.py:840-850).  The [T, 4H] concat is never materialised.

@@ -337,6 +337,28 @@ template <typename T> int cast_copy(hipStream_t st, const float* src, T* dst, in
 template int cast_copy<bf16_t>(hipStream_t, const float*, bf16_t*, int64_t);
 template int cast_copy<float>(hipStream_t, const float*, float*, int64_t);
 
+// T -> fp32 (the reference returns fp32 logits, models.py:859; the bf16 engine widens them on request), 8 elements per lane
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    floatx4 a, b;
+    load8<T>(src + i * 8, a, b);
+    *(floatx4*)(dst + i * 8) = a;
+    *(floatx4*)(dst + i * 8 + 4) = b;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n8 << 3) + threadIdx.x; i < n; i += blockDim.x) dst[i] = to_f<T>(src[i]);
+}
+template <typename T> int cast_to_f32(hipStream_t st, const T* src, float* dst, int64_t n) {
+  if (n <= 0) return RL_OK;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return RL_ERR_ARG;
+  hipLaunchKernelGGL((cast_to_f32_kernel<T>), dim3(ew_blocks(n / 8)), dim3(256), 0, st, src, dst, n);
+  return RL_LAUNCH_CHECK();
+}
+template int cast_to_f32<bf16_t>(hipStream_t, const bf16_t*, float*, int64_t);
+template int cast_to_f32<float>(hipStream_t, const float*, float*, int64_t);
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 cast_transpose_kernel(const float* __restrict__ src, int R, int C, T* __restrict__ dst, T* __restrict__ dstT) {
@@ -403,9 +425,9 @@ __global__ void __launch_bounds__(256) cast_transpose_multi_kernel(const CastDes
         floatx4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = tile[4 * q + j][y + 16 * k];
-        store4<T>(dstT + (int64_t)c * d.R + r, v);
+        store4<T>(dstT + (int64_t)c * d.ldT + r, v);
       } else {
-        for (int j = 0; j < 4 && r + j < d.R; ++j) dstT[(int64_t)c * d.R + r + j] = from_f<T>(tile[4 * q + j][y + 16 * k]);
+        for (int j = 0; j < 4 && r + j < d.R; ++j) dstT[(int64_t)c * d.ldT + r + j] = from_f<T>(tile[4 * q + j][y + 16 * k]);
       }
     }
   }

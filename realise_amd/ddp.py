@@ -14,37 +14,57 @@ from torch import nn
 
 
 class _GradSync:
-    def __init__(self, buckets, world, group, use_side_stream):
+    """grad_dtype "bf16": the buckets cross the wire as bf16 copies (half the bytes of the 679 MB fp32 exchange, SURVEY.md
+    section 5); the fp32 arena receives the reduced values back.  Pre-division by the world size happens in fp32 first."""
+
+    def __init__(self, buckets, world, group, use_side_stream, grad_dtype="fp32"):
+        if grad_dtype not in ("fp32", "bf16"):
+            raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
         self.buckets, self.world, self.group = buckets, world, group
         self.stream = torch.cuda.Stream() if use_side_stream else None
+        self.wire = [torch.empty_like(b, dtype=torch.bfloat16) for b in buckets] if grad_dtype == "bf16" else None
         self.works = []
 
-    def bucket_ready(self, i):
+    def _launch(self, i):
         buf = self.buckets[i]
+        buf.div_(self.world)                               # pre-divide: SUM of (g / W) == mean, overflow-safe
+        if self.wire is not None:
+            self.wire[i].copy_(buf)
+            self.works.append((i, dist.all_reduce(self.wire[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        else:
+            self.works.append((i, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+
+    def bucket_ready(self, i):
         if self.stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
-                buf.div_(self.world)                       # pre-divide: SUM of (g / W) == mean, overflow-safe
-                self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._launch(i)
         else:
-            buf.div_(self.world)
-            self.works.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._launch(i)
+
+    def _drain(self):
+        for i, w in self.works:
+            w.wait()
+            if self.wire is not None:
+                self.buckets[i].copy_(self.wire[i])
+        self.works = []
 
     def finish(self):
-        for w in self.works:
-            w.wait()
-        self.works = []
         if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self._drain()
             torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            self._drain()
 
 
 class DistributedDataParallel(nn.Module):
     """``DistributedDataParallel(model)`` for a RealiseModule (or any module exposing
     ``bucket_views()``, ``flat_parameters()``, ``flat_bn_buffers()`` and a ``grad_sync`` slot)."""
 
-    def __init__(self, module, process_group=None, broadcast_buffers=True):
+    def __init__(self, module, process_group=None, broadcast_buffers=True, grad_dtype="fp32"):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -57,7 +77,7 @@ class DistributedDataParallel(nn.Module):
                 if a.numel() > 1:
                     dist.broadcast(a, src=0, group=process_group)
             module.mark_parameters_updated()
-        module.grad_sync = _GradSync(module.bucket_views(), self.world, process_group, flat.is_cuda)
+        module.grad_sync = _GradSync(module.bucket_views(), self.world, process_group, flat.is_cuda, grad_dtype)
 
     def forward(self, *args, **kw):
         if self.broadcast_buffers and self.module.training:

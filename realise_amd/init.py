@@ -114,7 +114,10 @@ def tensor_specs(cfg, model_type="arch3"):
 
     if model_type == "arch3":
         F_ = cfg["num_fonts"]
-        specs.append(("char_images_multifonts", (V, F_, cfg["glyph_size"], cfg["glyph_size"]), "glyph"))
+        if F_ == 1:      # models.py:674-676: the single-font model keeps the table as an nn.Embedding [V, 1024]
+            specs.append(("char_images.weight", (V, cfg["glyph_size"] * cfg["glyph_size"]), "glyph"))
+        else:
+            specs.append(("char_images_multifonts", (V, F_, cfg["glyph_size"], cfg["glyph_size"]), "glyph"))
     bert("bert.", cfg["num_hidden_layers"])
     if model_type == "arch3":
         specs.append(("pho_embeddings.weight", (cfg["pho_vocab_size"], H), "normal"))
@@ -156,7 +159,7 @@ def init_state_dict_numpy(cfg, model_type="arch3", seed=0, scheme="reference", t
     for name, shape, kind in tensor_specs(cfg, model_type):
         if kind == "glyph":
             if glyph is None:
-                glyph = synth_glyph_table(shape[0], shape[1], shape[2], seed)
+                glyph = synth_glyph_table(shape[0], cfg["num_fonts"], cfg["glyph_size"], seed).reshape(shape)
             sd[name] = glyph
         else:
             sd[name] = tensor_init(name, shape, kind, cfg, seed, scheme)

@@ -34,11 +34,18 @@ class _EngineLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, loss_value, module):
         ctx.module = module
+        ctx.gen = module._fwd_gen
         return loss_value.clone()
 
     @staticmethod
     def backward(ctx, grad_out):
+        # the engine keeps the activations of ONE forward: a backward through an older loss (two forwards before one
+        # backward, micro-batch sums, a second backward of the same loss) would silently reuse the wrong activations
+        if ctx.gen != ctx.module._fwd_gen or ctx.module._bwd_done_gen == ctx.gen:
+            raise RuntimeError("realise_amd: backward() of a loss whose forward is no longer the engine's latest (run forward and "
+                               "backward in pairs; the workspace holds one batch's activations)")
         ctx.module._run_backward(grad_out)
+        ctx.module._bwd_done_gen = ctx.gen
         return None, None, None
 
 
@@ -49,7 +56,7 @@ class _Container(nn.Module):
 class RealiseModule(nn.Module):
     model_type = "arch3"
 
-    def __init__(self, config, compute_dtype=None, seed=0, init_scheme="reference", tie=True):
+    def __init__(self, config, compute_dtype=None, seed=0, init_scheme="reference", tie=True, logits_dtype=None):
         super().__init__()
         if not isinstance(config, RealiseConfig):
             config = RealiseConfig(**{k: getattr(config, k) for k in RealiseConfig.DEFAULTS if hasattr(config, k)})
@@ -60,6 +67,17 @@ class RealiseModule(nn.Module):
         if self.compute_dtype not in _DTYPES:
             raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
         self._tie = bool(tie)
+        # dtype of the returned logits.  "auto" (default): fp32 in eval mode - the reference contract, `logits.cpu().numpy()` in
+        # run.py:262 / test.py:140 needs it - and the compute dtype in training mode, where the trainer only reads the loss
+        # (run.py:191).  "fp32" / "bf16" force one dtype in both modes.
+        self.logits_dtype = logits_dtype or os.environ.get("REALISE_LOGITS_DTYPE") or "auto"
+        if self.logits_dtype not in ("auto", "bf16", "fp32"):
+            raise ValueError("logits_dtype must be 'auto', 'bf16' or 'fp32'")
+        if self.compute_dtype == "fp32" and self.logits_dtype == "bf16":
+            raise ValueError("bf16 logits need compute_dtype='bf16'")
+        self.static_weights = False         # serving: promise that parameters only change through tracked paths (see _ensure_engine)
+        self._fwd_gen = 0
+        self._bwd_done_gen = -1
         self._ccfg = _capi.make_config(config, self.model_type, _DTYPES[self.compute_dtype][0], tie=self._tie)
         self._entries, self._sizes, self._buckets = _capi.layout(self._ccfg)
         self._engine = None
@@ -170,7 +188,7 @@ class RealiseModule(nn.Module):
                     continue
                 arena, off, shp, param = self._views[name]
                 if kind == "glyph":
-                    val = synth_glyph_table(shape[0], shape[1], shape[2], seed)
+                    val = synth_glyph_table(shape[0], self.config.num_fonts, self.config.glyph_size, seed).reshape(shape)
                 else:
                     val = tensor_init(name, shape, kind, self.config, seed, scheme)
                 self._view(arena, off, shp).copy_(torch.from_numpy(np.asarray(val)).view(shp))
@@ -210,6 +228,8 @@ class RealiseModule(nn.Module):
         """transformers/modeling_utils.py:254-492: config.json + pytorch_model.bin."""
         if config is None:
             config = RealiseConfig.from_pretrained(path)
+        for k in ("cache_dir", "from_tf", "force_download", "proxies", "output_loading_info"):      # HF plumbing run.py passes along
+            kw.pop(k, None)
         model = cls(config, **kw)
         sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
         model.load_state_dict(sd, strict=False)
@@ -221,16 +241,53 @@ class RealiseModule(nn.Module):
         self.config.save_pretrained(d)
         torch.save({k: v.detach().cpu() for k, v in self.state_dict().items()}, os.path.join(d, "pytorch_model.bin"))
 
-    def build_glyce_embed_multifonts(self, table):
-        """src/models.py:737-795 renders fonts that are absent here (.MISSING_LARGE_BLOBS); accept a
-        pre-rendered [V, F, 32, 32] table instead."""
+    def _glyph_param(self):
+        name = "char_images.weight" if self.config.num_fonts == 1 else "char_images_multifonts"
+        if name not in self._views:
+            raise RuntimeError("this model has no glyph table (model_type %r)" % self.model_type)
+        return self._views[name][3]
+
+    def set_glyph_table(self, table):
+        """install a pre-rendered glyph table: [V, F, 32, 32] (or [V, 1024] for the single-font model)"""
+        p = self._glyph_param()
         with torch.no_grad():
-            self.char_images_multifonts.copy_(torch.as_tensor(table, dtype=torch.float32))
+            p.copy_(torch.as_tensor(np.asarray(table), dtype=torch.float32).reshape(p.shape))
         self._shadow_version = None
         self._frozen_version = None
 
+    def build_glyce_embed(self, vocab_dir, font_path, font_size=32):
+        """src/models.py:703-734 (single-font model, ``char_images.weight [V, 1024]``): render ``vocab.txt`` with one font,
+        blank unless the token is exactly one CJK character, standardise, install."""
+        from . import glyph
+        if self.config.num_fonts != 1:
+            raise RuntimeError("build_glyce_embed is the num_fonts == 1 path (run.py:433-435); use build_glyce_embed_multifonts")
+        vocab = glyph.read_vocab(vocab_dir)
+        if len(vocab) != self.vocab_size:
+            raise ValueError("vocab.txt has %d entries, the model %d" % (len(vocab), self.vocab_size))
+        self.set_glyph_table(glyph.render_font_table(vocab, font_path, font_size, cjk_only=True).reshape(len(vocab), -1))
+
+    def build_glyce_embed_multifonts(self, vocab_dir, num_fonts=None, use_traditional_font=False, font_size=32, font_paths=None,
+                                     to_traditional=None):
+        """src/models.py:737-758, called as ``model.build_glyce_embed_multifonts(vocab_dir, num_fonts, use_traditional_font)``
+        (run.py:436-440).  The reference opens ``simhei.ttf`` / ``xiaozhuan.ttf`` from the working directory and converts to
+        traditional forms with OpenCC; neither ships with the tree, so ``font_paths`` (list of paths, or (path, traditional)
+        pairs) and ``to_traditional`` (str -> str) can be given explicitly.  A pre-rendered table goes through
+        ``set_glyph_table``."""
+        from . import glyph
+        if not isinstance(vocab_dir, (str, bytes, os.PathLike)):
+            raise TypeError("build_glyce_embed_multifonts(vocab_dir, num_fonts, use_traditional_font): vocab_dir must be a path; "
+                            "install a pre-rendered table with set_glyph_table(table)")
+        nf = self.config.num_fonts if num_fonts is None else int(num_fonts)
+        if nf != self.config.num_fonts:
+            raise ValueError("num_fonts %d does not match config.num_fonts %d" % (nf, self.config.num_fonts))
+        vocab = glyph.read_vocab(vocab_dir)
+        if len(vocab) != self.vocab_size:
+            raise ValueError("vocab.txt has %d entries, the model %d" % (len(vocab), self.vocab_size))
+        self.set_glyph_table(glyph.render_multifont_table(vocab, nf, bool(use_traditional_font), font_size, font_paths, to_traditional))
+
     @staticmethod
     def build_batch(batch, tokenizer=None):
+        """SpellBert.build_batch (src/models.py:46-48): the BERT-only model needs nothing beyond make_features' tensors."""
         return batch
 
     def zero_grad(self, set_to_none=False):
@@ -262,7 +319,7 @@ class RealiseModule(nn.Module):
             if not self._engine:
                 raise _capi.RealiseHipError("realise_engine_create rejected the configuration")
             nbytes = lib.realise_engine_shadow_bytes(self._engine)
-            self._shadow = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._shadow = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)      # padded rows rely on zero fill
             self._ws = None
             self._frozen_version = None
         key = (B, S, Tp)
@@ -272,14 +329,18 @@ class RealiseModule(nn.Module):
             _capi.check(lib.realise_engine_bind(self._engine, self._shadow.data_ptr(), self._ws.data_ptr(), self._ws.numel()),
                         "realise_engine_bind")
         self._ws_key = key
-        # operand shadows: always re-derived in training (any optimizer may have stepped, including ones that
-        # write through `.data`, which torch's version counter does not see); in eval only when a tracked change
-        # happened (load_state_dict, in-place ops on parameters).
+        # Operand shadows (bf16 W / W^T copies): re-derived on EVERY forward, training or eval.  After `.to(device)` the
+        # parameters are views whose version counters are detached from the arena's, so no torch-side counter sees a stock
+        # optimizer, `p.data.copy_()`, an EMA swap or a manual re-init; one cast launch (~8 B / parameter) is cheaper than a
+        # silently stale weight.  Serving code that never touches the parameters can set `model.static_weights = True`: the
+        # refresh then only follows tracked changes (load_state_dict, FusedAdamW, mark_parameters_updated()).
+        # (The frozen glyph table - 65 M floats, requires_grad=False - keeps the tracked rule: its NHWC image is rebuilt after
+        # load_state_dict / build_glyce_embed* / set_glyph_table, or an in-place op the arena's version counter sees.)
         ver = (self._arenas[0]._version, self._arenas[2]._version)
         if getattr(self, "_frozen_version", None) != ver[1]:
             lib.realise_engine_invalidate_frozen(self._engine)
             self._frozen_version = ver[1]
-        if self.training or self._shadow_version != ver:
+        if self.training or not self.static_weights or self._shadow_version != ver:
             _capi.check(lib.realise_engine_refresh_shadows(self._engine, self._stream()), "realise_engine_refresh_shadows")
             self._shadow_version = ver
 
@@ -351,17 +412,49 @@ class RealiseModule(nn.Module):
             cb.n_alive = alive
         self._ensure_engine(B, S, cb.Tp)
         tdt = _DTYPES[self.compute_dtype][1]
+        self._fwd_gen += 1
         logits = torch.empty((B, S, self.vocab_size), dtype=tdt, device=self.device)
         loss = torch.zeros((), dtype=torch.float32, device=self.device) if tgt is not None else None
         cb.logits_out = logits.data_ptr()
         cb.loss_out = loss.data_ptr() if loss is not None else None
         _capi.check(_capi.load().realise_engine_forward(self._engine, self._stream(), C.byref(cb)), "realise_engine_forward")
         self._last = keep
+        want = self.logits_dtype if self.logits_dtype != "auto" else ("fp32" if not training else self.compute_dtype)
+        if want != self.compute_dtype:                        # reference contract: fp32 logits (models.py:859) from the bf16 engine
+            wide = torch.empty((B, S, self.vocab_size), dtype=torch.float32, device=self.device)
+            _capi.check(_capi.load().realise_cast_to_f32(self._stream(), _DTYPES[self.compute_dtype][0], logits.data_ptr(),
+                                                          wide.data_ptr(), logits.numel()), "realise_cast_to_f32")
+            logits = wide
         if tgt is None:
             return (logits,)
         if need_grad:
             loss = _EngineLoss.apply(self._anchor, loss, self)
         return (loss, logits)
+
+    def glyph_forward(self, src_idx, training=None):
+        """BASELINE configs[3]: the glyph ResNet alone - ``resnet(char_images_multifonts[src_idx])`` (src/models.py:829-836,
+        src/char_cnn.py:46-55) -> [B, S, 768] in the compute dtype, before ``resnet_layernorm``."""
+        if self.model_type != "arch3":
+            raise RuntimeError("glyph_forward needs the full model")
+        src = self._dev(src_idx)
+        B, S = src.shape
+        self._ensure_engine(B, S, -1)
+        training = bool(self.training if training is None else training)
+        out = torch.empty((B, S, self.config.hidden_size), dtype=_DTYPES[self.compute_dtype][1], device=self.device)
+        self._fwd_gen += 1
+        _capi.check(_capi.load().realise_engine_glyph_forward(self._engine, self._stream(), src.data_ptr(), B, S, 1 if training else 0,
+                                                              out.data_ptr()), "realise_engine_glyph_forward")
+        self._last = [src]
+        return out
+
+    def glyph_backward(self, d_res):
+        """accumulates the conv / BatchNorm parameter gradients of the last training ``glyph_forward`` for d_res [B, S, 768]"""
+        d = d_res.to(device=self.device, dtype=_DTYPES[self.compute_dtype][1]).contiguous()
+        sentinel = self._views["classifier.bias"][3]
+        if sentinel.grad is None:
+            self._grads.zero_()
+        _capi.check(_capi.load().realise_engine_glyph_backward(self._engine, self._stream(), d.data_ptr()), "realise_engine_glyph_backward")
+        self._attach_grads()
 
     def set_pinyin_table(self, table):
         """Enable the device-side ``build_batch``: ``table`` is a ``realise_amd.pinyin.PinyinTable`` of this vocabulary.
@@ -448,9 +541,38 @@ class RealiseModule(nn.Module):
         return self._arenas[3][:self._sizes[3]]
 
 
+_PINYIN_TABLES = {}      # id(tokenizer) -> (tokenizer, PinyinTable): the conversion is a pure function of the vocabulary
+
+
+def pinyin_table_for(tokenizer):
+    """The per-vocabulary pinyin table of a tokenizer, built once (Pinyin2.get_pinyin over every vocabulary entry,
+    src/utils.py:74-90) and cached for the tokenizer's lifetime."""
+    from .pinyin import PinyinTable
+    hit = _PINYIN_TABLES.get(id(tokenizer))
+    if hit is not None and hit[0] is tokenizer:
+        return hit[1]
+    n = getattr(tokenizer, "vocab_size", None) or len(tokenizer.vocab)
+    table = PinyinTable.build(tokenizer.convert_ids_to_tokens(list(range(int(n)))))
+    _PINYIN_TABLES[id(tokenizer)] = (tokenizer, table)
+    return table
+
+
 class SpellBertPho2ResArch3(RealiseModule):
     """src/models.py:652-870."""
     model_type = "arch3"
+
+    @staticmethod
+    def build_batch(batch, tokenizer):
+        """src/models.py:797-804: adds ``pho_idx`` [B*S, max pinyin length in the batch] (long) and the host list ``pho_lens``.
+        The reference runs pypinyin on every character of every batch; here the vocabulary's table is built once per tokenizer
+        and a batch is a gather.  (``model.set_pinyin_table(pinyin_table_for(tokenizer))`` moves the gather to the device.)"""
+        table = pinyin_table_for(tokenizer)
+        src = batch["src_idx"]
+        ids = src.detach().cpu().numpy() if torch.is_tensor(src) else np.asarray(src)
+        pho_idx, pho_lens = table.convert(ids)
+        batch["pho_idx"] = torch.from_numpy(np.ascontiguousarray(pho_idx))
+        batch["pho_lens"] = pho_lens
+        return batch
 
 
 class SpellBert(RealiseModule):

@@ -57,10 +57,11 @@ class FusedAdamW(torch.optim.Optimizer):
             norm_ptr, max_norm = self._norm_sq.data_ptr(), float(self.max_grad_norm)
         g0 = self.param_groups[0]
         uniform = all(g["lr"] == g0["lr"] and g["weight_decay"] == g0["weight_decay"] and g["eps"] == g0["eps"]
-                      and g["betas"] == g0["betas"] for g in self.param_groups)
-        covered = sum(n for rng in self._param_ranges() for _, n in rng)
-        n_train = sum(p.numel() for name, (a, o, s, p) in mod._views.items() if a == 0 and p is not None and name != "classifier.weight")
-        if uniform and covered >= n_train:
+                      and g["betas"] == g0["betas"] and g["correct_bias"] == g0["correct_bias"] for g in self.param_groups)
+        # the whole-arena launch is only valid when the groups hold EVERY trainable tensor of the arena exactly once
+        covered = sorted(r for rng in self._param_ranges() for r in rng)
+        wanted = sorted({(o, p.numel()) for name, (a, o, s, p) in mod._views.items() if a == 0 and p is not None})
+        if uniform and covered == wanted:
             _capi.check(lib.realise_adamw(st, flat_p.data_ptr(), flat_g.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
                                           flat_p.numel(), g0["lr"], g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"],
                                           self._step, 1 if g0["correct_bias"] else 0, norm_ptr, max_norm), "realise_adamw")
@@ -72,6 +73,23 @@ class FusedAdamW(torch.optim.Optimizer):
                                                   g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._step,
                                                   1 if g["correct_bias"] else 0, norm_ptr, max_norm), "realise_adamw")
         mod.mark_parameters_updated()
+
+    def state_dict(self):
+        """torch's param_groups plus the flat first / second moments and the step count (they live outside ``self.state``)"""
+        sd = super().state_dict()
+        sd["realise_flat"] = {"m": self._m.detach().clone(), "v": self._v.detach().clone(), "step": int(self._step)}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        flat = sd.pop("realise_flat", None)
+        super().load_state_dict(sd)
+        if flat is not None:
+            if flat["m"].numel() != self._m.numel():
+                raise ValueError("optimizer state belongs to a different model layout")
+            self._m.copy_(flat["m"].to(self._m.device))
+            self._v.copy_(flat["v"].to(self._v.device))
+            self._step = int(flat["step"])
 
     def grad_norm(self):
         """global L2 norm measured by the last step() (device tensor; reading it synchronises)"""

@@ -22,11 +22,14 @@ def pypinyin_tone3(c):
     return pypinyin.pinyin(c, style=pypinyin.Style.TONE3, neutral_tone_with_five=True, errors=lambda x: ["U" for _ in x])[0][0]
 
 
-def token_pinyin(token, tone3=pypinyin_tone3):
+DEFAULT_TONE3 = pypinyin_tone3      # hosts without pypinyin (and tests) may point this at another str -> TONE3 function
+
+
+def token_pinyin(token, tone3=None):
     """Pinyin2.get_pinyin (utils.py:74-90): 'U' for multi-character tokens and unknown characters, else tone-first."""
     if len(token) > 1:
         return "U"
-    s = tone3(token)
+    s = (tone3 or DEFAULT_TONE3)(token)
     if s == "U":
         return s
     if not isinstance(s, str) or s[-1] not in "12345":
@@ -44,7 +47,7 @@ class PinyinTable:
             raise ValueError("inconsistent pinyin table")
 
     @classmethod
-    def build(cls, tokens, tone3=pypinyin_tone3):
+    def build(cls, tokens, tone3=None):
         """tokens: the vocabulary in id order (``tokenizer.convert_ids_to_tokens(range(V))``)."""
         table = np.zeros((len(tokens), MAX_LEN), np.int64)
         lens = np.zeros(len(tokens), np.int32)

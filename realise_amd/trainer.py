@@ -12,19 +12,22 @@ from .optim import FusedAdamW, get_linear_schedule_with_warmup
 
 
 def make_features(examples, max_seq_length):
-    """run.py:68-101: pad to max_seq_length; masks = 1 on [CLS] chars [SEP]; loss_masks = 1 on chars only."""
+    """run.py:68-101: truncate / pad ``src_idx`` and ``tgt_idx`` to max_seq_length; ``masks`` = 1 on the kept tokens
+    ([CLS] chars [SEP]); ``loss_masks`` = 1 on positions 1 .. min(lengths, max_seq_length - 1) (the characters only)."""
     batch = {k: [] for k in ("id", "src", "tgt", "tokens_size", "lengths", "src_idx", "tgt_idx", "masks", "loss_masks")}
     for e in examples:
-        n = len(e["src_idx"])
-        if n > max_seq_length:
-            raise ValueError("sequence longer than max_seq_length")
-        pad = max_seq_length - n
         for k in ("id", "src", "tgt", "tokens_size", "lengths"):
             batch[k].append(e.get(k))
-        batch["src_idx"].append(list(e["src_idx"]) + [0] * pad)
-        batch["tgt_idx"].append(list(e["tgt_idx"]) + [0] * pad)
-        batch["masks"].append([1] * n + [0] * pad)
-        batch["loss_masks"].append([0] + [1] * e["lengths"] + [0] * (max_seq_length - 1 - e["lengths"]))
+        for k in ("src_idx", "tgt_idx"):
+            seq = list(e[k])[:max_seq_length]
+            pad = max_seq_length - len(seq)
+            batch[k].append(seq + [0] * pad)
+            if k == "src_idx":
+                batch["masks"].append([1] * len(seq) + [0] * pad)
+        loss_mask = [0] * max_seq_length
+        for i in range(1, min(1 + e["lengths"], max_seq_length)):
+            loss_mask[i] = 1
+        batch["loss_masks"].append(loss_mask)
     for k in ("src_idx", "tgt_idx", "masks", "loss_masks"):
         batch[k] = torch.tensor(batch[k], dtype=torch.long)
     return batch
@@ -51,6 +54,9 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
     """the hot loop of run.py:125-237 with the fused optimizer; returns the mean loss."""
     build_batch = build_batch or type(model).build_batch
     model.to(device)
+    if distributed:                    # run.py:130-137: every rank trains on its own strided shard
+        import torch.distributed as dist
+        items = shard(list(items), dist.get_rank(), dist.get_world_size())
     wrapped = DistributedDataParallel(model) if distributed else model
     no_decay = ["bias", "LayerNorm.weight"]
     groups = [{"params": [p for n, p in model.named_parameters() if p.requires_grad and not any(nd in n for nd in no_decay)],
@@ -58,7 +64,7 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
               {"params": [p for n, p in model.named_parameters() if p.requires_grad and any(nd in n for nd in no_decay)],
                "weight_decay": 0.0}]
     opt = FusedAdamW(model, groups, lr=lr, eps=adam_epsilon, max_grad_norm=max_grad_norm)
-    steps_total = max(1, (len(items) + batch_size - 1) // batch_size * epochs)
+    steps_total = max(1, len(items) // batch_size * epochs)          # t_total of run.py:142-144 (floor)
     sched = get_linear_schedule_with_warmup(opt, warmup_steps, steps_total)
     tr_loss = torch.zeros((), device=device)
     step = 0

@@ -20,7 +20,7 @@ from realise_amd.modeling import SpellBert, SpellBertPho2ResArch3
 pytestmark = pytest.mark.gpu
 
 FP32_LOGIT_TOL = 1e-3
-BF16_LOGIT_TOL = 6e-2
+BF16_LOGIT_TOL = 4e-2       # the reference itself under bf16 autocast: 2.5e-2 max
 
 
 def build(model_type, cfg, sd_np, dtype, train=False):
@@ -61,7 +61,7 @@ def test_eval_forward_bf16_within_band(golden_dir, name, model_type):
     m = build(model_type, cfg, sd_np, "bf16")
     with torch.no_grad():
         loss, logits = m(batch)
-    assert logits.dtype == torch.bfloat16
+    assert logits.dtype == torch.float32          # eval mode: the reference's fp32 logits (logits_dtype='auto')
     check_summary(g, "logits", logits.float(), BF16_LOGIT_TOL)
     assert abs(loss.item() - float(g["loss"])) < 5e-2
     am = logits.float().argmax(-1).cpu().numpy().astype(np.int32)
@@ -69,7 +69,7 @@ def test_eval_forward_bf16_within_band(golden_dir, name, model_type):
     real = batch["masks"].numpy() == 1
     assert np.array_equal(am[decided & real], g["argmax"][decided & real])
     agree = (am == g["argmax"])[real].mean()
-    assert agree > 0.85, agree
+    assert agree > 0.92, agree
 
 
 def _oracle_train(model_type, cfg, sd_np, batch, taps=None):
@@ -168,7 +168,7 @@ def test_train_step_bf16_grads_close_to_oracle(golden_dir):
         c = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         cos.append((c, pname))
     cos.sort()
-    assert cos[0][0] > 0.97, cos[:8]          # direction of every gradient tensor agrees with fp32
+    assert cos[0][0] > 0.99, cos[:8]          # direction of every gradient tensor agrees with fp32
 
 
 def test_gradient_accumulation_and_zero_grad(golden_dir):
