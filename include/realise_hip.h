@@ -150,7 +150,8 @@ realise_engine* realise_engine_create(const realise_config* cfg, float* params, 
 void realise_engine_destroy(realise_engine* e);
 int64_t realise_engine_shadow_bytes(const realise_engine* e);
 int64_t realise_engine_workspace_bytes(const realise_engine* e, int B, int S, int Tp);   /* Tp = -1: glyph-only plan */
-/* hand the engine its operand-shadow arena and its activation workspace (caller-allocated) */
+/* hand the engine its operand-shadow arena and its activation workspace (caller-allocated).  The shadow arena must be
+ * ZERO-FILLED by the caller: padded operand rows (the classifier's W^T copy is pitched to 64 columns) rely on it. */
 int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_t workspace_bytes);
 /* re-derive the compute-dtype operand copies from the fp32 masters (after any parameter update) */
 int realise_engine_refresh_shadows(realise_engine* e, void* stream);
