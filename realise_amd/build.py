@@ -63,6 +63,10 @@ def build(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        # an instantiation the compiler silently dropped shows up only at dlopen time (undefined symbol): check it here
+        chk = subprocess.run([sys.executable, "-c", "import ctypes, sys; ctypes.CDLL(sys.argv[1])", LIB], capture_output=True, text=True)
+        if chk.returncode != 0:
+            raise RuntimeError("librealise_hip.so does not load:\n%s" % chk.stderr[-2000:])
     return LIB
 
 

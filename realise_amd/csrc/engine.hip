@@ -76,7 +76,7 @@ template <typename T> struct Engine : EngineBase {
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
     int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
     int64_t bn_sums, bn_slots;
-    int64_t gu_first, gu_flag, gu_ids, gu_counts, gu_inv, gu_bounds, seg_acc;   // glyph dedup
+    int64_t gu_first, gu_flag, gu_ids, gu_counts, gu_inv, gu_bounds, seg_acc, gu_dense;   // glyph dedup
     // backward scratch
     int64_t gA, gB, gC, gE, gD, gF, rowdot, X1, X2, X3, dz, tn_slab, ln_slots;
     int64_t wC1[2], wC2[2], wD[2], wF[2], tn_slab2;      // per-parity dY copies + second slab: weight gradients on the side stream
@@ -300,6 +300,7 @@ template <typename T> struct Engine : EngineBase {
       p.bn_slots = b.take((int64_t)COL_SLOT_FLOATS * 4);
       p.gu_first = b.take((int64_t)V * 4); p.gu_flag = b.take(Tk * 4); p.gu_ids = b.take(Tk * 8); p.gu_counts = b.take(Tk * 4);
       p.gu_inv = b.take(Tk * 4); p.gu_bounds = b.take(64); p.seg_acc = b.take(Tk * H * 4);
+      p.gu_dense = b.take(Tk * (int64_t)cfg.glyph_size * cfg.glyph_size * 8 * e);      // the distinct glyph images, contiguous (NHWC, 8 channels)
       tap("glyph.bounds", p.gu_bounds, 64 / (int64_t)sizeof(T)); tap("glyph.inv", p.gu_inv, Tk * 4 / (int64_t)sizeof(T));
       tap("glyph.counts", p.gu_counts, Tk * 4 / (int64_t)sizeof(T)); tap("glyph.ids", p.gu_ids, Tk * 8 / (int64_t)sizeof(T));
       p.res_xhat = b.take(Tk * H * e); p.res_rstd = b.take(Tk * 4); p.res_h = b.take(Tk * H * e);
@@ -552,8 +553,10 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(glyph_unique(st, ids, pl.B * pl.S, V, wp<int>(pl.gu_first), wp<int>(pl.gu_flag), wp<int64_t>(pl.gu_ids),
                           wp<float>(pl.gu_counts), wp<int>(pl.gu_inv), wp<int>(pl.gu_bounds), hw));
     }
-    const T* x = sp<T>(sh_glyph);
-    const int64_t* index = wp<int64_t>(pl.gu_ids);
+    RL_TRY(gather_images<T>(st, sp<T>(sh_glyph), wp<int64_t>(pl.gu_ids), wp<int>(pl.gu_bounds), pl.B * pl.S,
+                            (int64_t)cfg.glyph_size * cfg.glyph_size * 8, wp<T>(pl.gu_dense)));
+    const T* x = wp<T>(pl.gu_dense);
+    const int64_t* index = nullptr;
     for (int k = 0; k < 5; ++k) {
       const BlockOff& o = L.blocks[k];
       const BlockSh& s = sh_blk[k];
@@ -592,8 +595,8 @@ template <typename T> struct Engine : EngineBase {
       BlockAct& a = pl.blk[k];
       const int Co = o.cout, Cin = s.cin_pad, Pn = a.Pout;
       const RowBound rb = rbound(k);
-      const T* x_in = k > 0 ? wp<T>(pl.blk[k - 1].out) : sp<T>(sh_glyph);
-      const int64_t* index = k > 0 ? nullptr : wp<int64_t>(pl.gu_ids);
+      const T* x_in = k > 0 ? wp<T>(pl.blk[k - 1].out) : wp<T>(pl.gu_dense);
+      const int64_t* index = nullptr;
       T* dc2 = wp<T>(pl.r_dc2); T* dcs = wp<T>(pl.r_dcs); T* dh1 = wp<T>(pl.r_dh1); T* dc1 = wp<T>(pl.r_dc1);
       // out = relu(bn2(c2) + bns(cs))
       RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));

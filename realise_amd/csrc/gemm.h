@@ -100,6 +100,74 @@ template <typename T> struct ConvLoader {
     q.k += dk; q.ch += dk;
     while (q.ch >= C) { q.ch -= C; if (++q.kw == KW) { q.kw = 0; ++q.kh; } }
   }
+  // ---- 32-bit addressing for raw-buffer LDS-DMA fetches (one VGPR offset per fetch, the descriptor in SGPRs).  A row keeps the
+  // byte offset of its ANCHOR pixel (the tap-(0,0) source pixel, possibly inside the zero padding; arithmetic is mod 2^32) and the
+  // anchor's coordinates; a lane keeps its current tap (kh, kw, channel) and the tap's byte offset relative to the anchor.  Per
+  // fetch: two adds, two unsigned compares, one select - instead of a 64-bit address recomputed from (n, y, x, kh, kw) each time.
+  // A fetch that must read zeros (padding, row / K tails, stride-2 parity misses) gets an offset beyond num_records: the buffer
+  // range check returns zeros.
+  static constexpr uint32_t OOB = 0xFFFFFF00u;          // with num_records = RECORDS below
+  static constexpr uint32_t RECORDS = 0xFFFFFE00u;
+  struct Row32 { uint32_t off; int y0, x0; };
+  struct Tap32 { int kh, kw, ch, k; uint32_t toff; };
+  __device__ __forceinline__ Row32 prepare32(int row) const {
+    Row32 r; r.off = 0u; r.y0 = -(1 << 24); r.x0 = -(1 << 24);          // out of range: every tap fails the bounds test
+    if (row < rows) {
+      int n, rem, y, x;
+      if (hw_shift >= 0) {
+        n = row >> hw_shift; rem = row & ((1 << hw_shift) - 1);
+        y = rem >> w_shift; x = rem & ((1 << w_shift) - 1);
+      } else {
+        const int hw = Hr * Wr;
+        n = row / hw; rem = row - n * hw;
+        y = rem / Wr; x = rem - y * Wr;
+      }
+      const int64_t ns = img_index ? img_index[n] : (int64_t)n;
+      const int64_t img = ns * Hs * Ws;
+      if (mode == 0) { r.y0 = y * stride - pad; r.x0 = x * stride - pad; }
+      else { r.y0 = y + pad; r.x0 = x + pad; }
+      if (mode == 0 || stride == 1) r.off = (uint32_t)((img + (int64_t)r.y0 * Ws + r.x0) * C * (int64_t)sizeof(T));
+      else r.off = (uint32_t)(img * C * (int64_t)sizeof(T));
+    }
+    return r;
+  }
+  __device__ __forceinline__ void tap_offset(Tap32& q) const {
+    if (mode == 0) q.toff = (uint32_t)(((q.kh * Ws + q.kw) * C + q.ch) * (int)sizeof(T));
+    else if (stride == 1) q.toff = (uint32_t)((q.ch - (q.kh * Ws + q.kw) * C) * (int)sizeof(T));
+    else q.toff = (uint32_t)(q.ch * (int)sizeof(T));
+  }
+  __device__ __forceinline__ Tap32 tap32(int k) const {
+    Tap32 q; q.k = k;
+    const int tap = k / C;
+    q.ch = k - tap * C; q.kh = tap / KW; q.kw = tap - q.kh * KW;
+    tap_offset(q);
+    return q;
+  }
+  __device__ __forceinline__ void advance32(Tap32& q, int dk) const {
+    q.k += dk; q.ch += dk;
+    while (q.ch >= C) { q.ch -= C; if (++q.kw == KW) { q.kw = 0; ++q.kh; } }
+    tap_offset(q);
+  }
+  __device__ __forceinline__ uint32_t voff32(const Row32& r, const Tap32& q) const {
+    if (q.k >= K) return OOB;
+    if (mode == 0) {
+      const bool ok = (unsigned)(r.y0 + q.kh) < (unsigned)Hs && (unsigned)(r.x0 + q.kw) < (unsigned)Ws;
+      return ok ? r.off + q.toff : OOB;
+    }
+    const int ty = r.y0 - q.kh, tx = r.x0 - q.kw;
+    if (stride == 1) {
+      const bool ok = (unsigned)ty < (unsigned)Hs && (unsigned)tx < (unsigned)Ws;
+      return ok ? r.off + q.toff : OOB;
+    }
+    if (stride == 2) {
+      const int sy = ty >> 1, sx = tx >> 1;
+      const bool ok = ((ty | tx) >= 0) && (((ty | tx) & 1) == 0) && sy < Hs && sx < Ws;
+      return ok ? r.off + (uint32_t)((sy * Ws + sx) * C * (int)sizeof(T)) + q.toff : OOB;
+    }
+    const int sy = ty / stride, sx = tx / stride;
+    const bool ok = ty >= 0 && tx >= 0 && sy * stride == ty && sx * stride == tx && sy < Hs && sx < Ws;
+    return ok ? r.off + (uint32_t)((sy * Ws + sx) * C * (int)sizeof(T)) + q.toff : OOB;
+  }
   __device__ __forceinline__ const void* addr(const Ctx& c, const KPos& q, const void* zero) const {
     if (c.img == nullptr || q.k >= K) return zero;
     int sy, sx;

@@ -23,6 +23,30 @@ namespace rl {
 // K-tile = one 128-byte LDS row per operand row (64 bf16 / 32 f32), chunk c of row r stored at chunk
 // (c ^ (r & 7)) (KTile): conflict-free ds_read_b128 operand reads.
 // =================================================================================================
+// Per-wave state of a gathered A operand: NA 8-row pieces per K-tile, one Row32 per piece, one Tap32 per lane.
+template <typename L, int NA> struct ConvRows {
+  __device__ __forceinline__ void init(const L&, int, int) {}
+  __device__ __forceinline__ void issue(const L&, char*) {}
+};
+template <typename T, int NA> struct ConvRows<ConvLoader<T>, NA> {
+  typename ConvLoader<T>::Row32 r[NA];
+  typename ConvLoader<T>::Tap32 q;
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ void init(const ConvLoader<T>& la, int row0, int kchunk) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) r[j] = la.prepare32(row0 + j * 8);
+    q = la.tap32(kchunk);
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)la.src, 0, (int)ConvLoader<T>::RECORDS, 0x00020000);
+  }
+  __device__ __forceinline__ void issue(const ConvLoader<T>& la, char* lds_wave_base) {      // fetch this K-tile's pieces, step to the next
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds_wave_base + j * 1024), 16,
+                                               la.voff32(r[j], q), 0, 0, 0);
+    la.advance32(q, Geo<T>::BK);
+  }
+};
+
 template <typename T, typename ALoader, int WM, int WN, int NSTAGE, int NF, bool SPREAD>
 __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 && NSTAGE == 2) ? 2 : 1)
 gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, int ntiles, EpiParams<T> ep) {
@@ -48,20 +72,25 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
   const int lrow = lane >> 3;                        // row inside the 8-row group written by one instruction
   const int kchunk = ((lane & 7) ^ lrow) * G::VEC;   // logical K offset of the chunk this lane fetches
 
-  typename ALoader::Ctx actx[NA];
+  constexpr bool kDenseA = sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
+  typename ALoader::Ctx actx[kDenseA ? NA : 1];
   typename DenseLoader<T>::Ctx bctx[NB];
   const int m0f = ep.probe == 1 ? 0 : m0, n0f = ep.probe == 1 ? 0 : n0;
+  if constexpr (kDenseA) {
 #pragma unroll
-  for (int j = 0; j < NA; ++j) actx[j] = la.prepare(m0f + (wave * NA + j) * 8 + lrow);
+    for (int j = 0; j < NA; ++j) actx[j] = la.prepare(m0f + (wave * NA + j) * 8 + lrow);
+  }
 #pragma unroll
   for (int j = 0; j < NB; ++j) bctx[j] = lb.prepare(n0f + (wave * NB + j) * 8 + lrow);
   typename ALoader::KPos aq = la.kpos(kchunk);
   typename DenseLoader<T>::KPos bq = lb.kpos(kchunk);
+  // gathered (implicit-im2col) A operand: 32-bit buffer addressing, see ConvLoader::Row32 / Tap32
+  ConvRows<ALoader, NA> crow;
+  if constexpr (!kDenseA) crow.init(la, m0f + wave * NA * 8 + lrow, kchunk);
   const int nk = (K + G::BK - 1) / G::BK;
   // Fast addressing for the K-tiles that lie completely inside K: each lane keeps one 64-bit source pointer per
   // wave-instruction and just adds the K-tile stride (0 for lanes parked on the zero page).  A ragged last tile
   // (K % BK != 0, e.g. the classifier's data gradient with K = 21128) falls back to checked addressing for that tile only.
-  constexpr bool kDenseA = sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
   const int nfast = K / G::BK;
   const bool fast = nfast > 0, fast_all = (K % G::BK) == 0;
   int kt_issue = 0;
@@ -93,11 +122,13 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
     if (ep.probe == 2) return;
     char* base = smem + stage * STAGE;
     const bool f = kt_issue < nfast;                 // this tile is addressed by pointer stepping
-    if (kDenseA && f) {
+    if constexpr (!kDenseA) {
+      crow.issue(la, base + wave * NA * 1024);
+    } else if (f) {
 #pragma unroll
       for (int j = 0; j < NA; ++j) { glds16(pa[j], base + (wave * NA + j) * 1024); pa[j] += inca[j]; }
     } else {
-      if (kDenseA && fast && kt_issue == nfast) aq = la.kpos(kchunk + nfast * G::BK);
+      if (fast && kt_issue == nfast) aq = la.kpos(kchunk + nfast * G::BK);
 #pragma unroll
       for (int j = 0; j < NA; ++j) glds16(la.addr(actx[j], aq, zero), base + (wave * NA + j) * 1024);
       la.advance(aq, G::BK);
@@ -431,6 +462,13 @@ int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la_, const T* B, int64_t l
   if (la.K != K) return RL_ERR_ARG;
   return launch_nt<T, ConvLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }
+// hipcc (ROCm 7.2) drops the implicit instantiation of the default-tile conv kernel once the kernel body holds the ConvRows
+// helper (the host object keeps an undefined reference): instantiate the gathered-operand kernels explicitly.
+#define RL_INST_NT_CONV(T, WM, WN, NS, NF) \
+  template __global__ void gemm_nt_kernel<T, ConvLoader<T>, WM, WN, NS, NF, false>(ConvLoader<T>, DenseLoader<T>, int, int, int, int, int, EpiParams<T>);
+RL_INST_NT_CONV(bf16_t, 2, 2, 2, 4) RL_INST_NT_CONV(bf16_t, 2, 2, 2, 3) RL_INST_NT_CONV(bf16_t, 4, 1, 2, 4)
+RL_INST_NT_CONV(float, 2, 2, 2, 4) RL_INST_NT_CONV(float, 2, 2, 2, 3) RL_INST_NT_CONV(float, 4, 1, 2, 4)
+#undef RL_INST_NT_CONV
 template int gemm_nt<bf16_t>(hipStream_t, const bf16_t*, int64_t, const bf16_t*, int64_t, int, int, int, const EpiParams<bf16_t>&, const int*);
 template int gemm_nt<float>(hipStream_t, const float*, int64_t, const float*, int64_t, int, int, int, const EpiParams<float>&, const int*);
 template int gemm_nt_conv<bf16_t>(hipStream_t, const ConvLoader<bf16_t>&, const bf16_t*, int64_t, int, int, int, const EpiParams<bf16_t>&);
@@ -487,6 +525,31 @@ __device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int ks, int c
 
 enum TnOut { TN_OUT_DIRECT = 0, TN_OUT_SLAB = 1, TN_OUT_ATOMIC = 2 };
 
+// Per-wave state of a gathered B operand of the TN kernel: NB pieces per reduction tile, the lane's (tap, channel) per piece is
+// fixed for the whole kernel, only the reduction row p moves.
+template <typename L, int NB> struct ConvTaps {
+  __device__ __forceinline__ void set(const L&, int, int) {}
+  __device__ __forceinline__ void init(const L&) {}
+  __device__ __forceinline__ void fetch(const L&, int, int, bool, char*) {}
+};
+template <typename T, int NB> struct ConvTaps<ConvLoader<T>, NB> {
+  typename ConvLoader<T>::Tap32 t[NB];
+  __amdgpu_buffer_rsrc_t rs;
+  __device__ __forceinline__ void set(const ConvLoader<T>& lb, int q, int col) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) if (i == q) t[i] = lb.tap32(col);
+  }
+  __device__ __forceinline__ void init(const ConvLoader<T>& lb) {
+    rs = __builtin_amdgcn_make_buffer_rsrc((void*)lb.src, 0, (int)ConvLoader<T>::RECORDS, 0x00020000);
+  }
+  __device__ __forceinline__ void fetch(const ConvLoader<T>& lb, int q, int p, bool live, char* lds_wave_piece) {
+    uint32_t voff = ConvLoader<T>::OOB;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) if (i == q && live) voff = lb.voff32(lb.prepare32(p), t[i]);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_piece, 16, voff, 0, 0, 0);
+  }
+};
+
 __device__ __forceinline__ int64_t tn_out_index(const TnEpi& ep, int i, int j) {   // -1: padding column
   if (ep.mode == TN_PLAIN) return (int64_t)i * ep.ldo + j;
   const int tap = j / ep.Cpad, ci = j - tap * ep.Cpad;
@@ -542,10 +605,12 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
   const void* zero = (const void*)g_zero16;
 
   // per-lane chunk coordinates are the same for every reduction tile: only the row base moves
+  constexpr bool kDenseB = sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
   int apl[NA], bpl[NB];
   const T* acol[NA];
   typename BLoader::KPos bq[NB];
   bool bok[NB];
+  ConvTaps<BLoader, NB> ctap;          // gathered B operand: the lane's tap per piece is fixed, the row moves (32-bit buffer addressing)
 #pragma unroll
   for (int q = 0; q < NA; ++q) {
     const int off = (wave * NA + q) * 1024 + lane * 16;
@@ -560,7 +625,9 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
     const int col = j0 + ((off % RPB) ^ tn_swz<T, RPB>(bpl[q])) / (int)sizeof(T);
     bok[q] = col < J;
     bq[q] = lb.kpos(bok[q] ? col : 0);
+    if constexpr (!kDenseB) ctap.set(lb, q, bok[q] ? col : 0);
   }
+  if constexpr (!kDenseB) ctap.init(lb);
 
   floatx4 acc[4][4];
 #pragma unroll
@@ -583,7 +650,6 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
 
   // Fast addressing for full reduction tiles: one 64-bit source pointer per wave-instruction, advanced by a
   // constant (0 for lanes parked on the zero page); the checked path handles a ragged last tile.
-  constexpr bool kDenseB = sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
   const char* pa[NA];
   const char* pb[NB];
   int64_t inca[NA], incb[NB];
@@ -624,10 +690,8 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
         pb[q] += incb[q];
       } else {
         const int p = pt + bpl[q];
-        if (p < p_end && bok[q]) {
-          const typename BLoader::Ctx c = lb.prepare(p);
-          src = lb.addr(c, bq[q], zero);
-        }
+        ctap.fetch(lb, q, p, p < p_end && bok[q], base + A_BYTES + (wave * NB + q) * 1024);
+        continue;
       }
       glds16(src, base + A_BYTES + (wave * NB + q) * 1024);
     }

@@ -165,6 +165,8 @@ int glyph_unique(hipStream_t st, const int64_t* ids, int T_, int V, int* first_s
                  float* counts, int* inv, int* bounds, HwList hw);
 // out[u][c] = sum over tokens t with inv[t] == u of x[t][c]   (fp32 scratch `acc` of T*C floats, out rows >= U untouched)
 template <typename T> int segment_sum(hipStream_t st, const T* x, const int* inv, int T_, int C, float* acc, T* out, const int* nuniq_dev);
+// dense[u] = table[ids[u]], u < *nuniq (images of `elems` elements)
+template <typename T> int gather_images(hipStream_t st, const T* table, const int64_t* ids, const int* nuniq, int max_images, int64_t elems, T* dense);
 // out[t][:] = x[inv[t]][:]
 template <typename T> int gather_rows(hipStream_t st, const T* x, const int* inv, int T_, int C, T* out);
 

@@ -768,6 +768,26 @@ template <typename T> int segment_sum(hipStream_t st, const T* x, const int* inv
 template int segment_sum<bf16_t>(hipStream_t, const bf16_t*, const int*, int, int, float*, bf16_t*, const int*);
 template int segment_sum<float>(hipStream_t, const float*, const int*, int, int, float*, float*, const int*);
 
+// dense[u] = table[ids[u]] for the U distinct glyphs of the batch (one contiguous NHWC image each): the block-1 convolutions and
+// their weight gradients then address images by slot, without the id indirection in their gather loops
+template <typename T>
+__global__ void __launch_bounds__(256) gather_images_kernel(const T* __restrict__ table, const int64_t* __restrict__ ids,
+                                                            const int* __restrict__ nuniq, int64_t elems, T* __restrict__ dense) {
+  const int u = blockIdx.x;
+  if (u >= *nuniq) return;
+  const uint4* s = (const uint4*)(table + ids[u] * elems);
+  uint4* d = (uint4*)(dense + (int64_t)u * elems);
+  const int n16 = (int)(elems * sizeof(T) / 16);
+  for (int i = threadIdx.x; i < n16; i += 256) d[i] = s[i];
+}
+template <typename T> int gather_images(hipStream_t st, const T* table, const int64_t* ids, const int* nuniq, int max_images, int64_t elems, T* dense) {
+  if ((elems * sizeof(T)) & 15) return RL_ERR_ARG;
+  hipLaunchKernelGGL((gather_images_kernel<T>), dim3(max_images), dim3(256), 0, st, table, ids, nuniq, elems, dense);
+  return RL_LAUNCH_CHECK();
+}
+template int gather_images<bf16_t>(hipStream_t, const bf16_t*, const int64_t*, const int*, int, int64_t, bf16_t*);
+template int gather_images<float>(hipStream_t, const float*, const int64_t*, const int*, int, int64_t, float*);
+
 // out[t, :] = x[inv[t], :]  (per-distinct-glyph rows back to per-token rows; the glyph-only entry point, BASELINE configs[3])
 template <typename T>
 __global__ void gather_rows_kernel(const T* __restrict__ x, const int* __restrict__ inv, int T_, int C, T* __restrict__ out) {
