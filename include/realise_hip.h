@@ -92,6 +92,11 @@ void realise_set_glyph_dedup(int on);
  * data-gradient chain on the caller's stream (joined before realise_engine_backward returns); 0 (default) everything in
  * order on the caller's stream.  Identical results; +1 % throughput measured, per-kernel timings become overlap-dependent. */
 void realise_set_wgrad_overlap(int on);
+/* 1 (default): the three branches of SpellBertPho2ResArch3.forward that are independent between the inputs and the gate
+ * (src/models.py:816 bert | :818-827 pinyin GRU + pho_model | :829-838 glyph ResNet), and their backward passes behind the
+ * gate, run on three HIP streams (the caller's + two engine-owned), forked / joined with events inside the engine call; the
+ * caller's stream owns every result when the call returns.  0: everything in order on the caller's stream.  Identical results. */
+void realise_set_branch_overlap(int on);
 
 /* BertSelfAttention core (modeling_bert.py:239-260): softmax(QK^T/8 + mask_add) -> dropout -> .V
  * q/k/v: [B*S][ldq] token-major, head h at columns 64h..64h+63; ctx [B*S][ldc]; lse [B][nh][S]. */

@@ -80,6 +80,7 @@ void realise_set_tn_split(int n) { set_tn_split(n); }
 void realise_set_nt_wide_epilogue(int on) { set_nt_wide_epilogue(on); }
 void realise_set_glyph_dedup(int on) { set_glyph_dedup(on); }
 void realise_set_wgrad_overlap(int on) { set_wgrad_overlap(on); }
+void realise_set_branch_overlap(int on) { set_branch_overlap(on); }
 
 int realise_attention_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ldq, const float* mask_add,
                           void* ctx, int64_t ldc, float* lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh,

@@ -5,7 +5,8 @@
 #include "../../include/realise_hip.h"
 
 namespace rl {
-void set_wgrad_overlap(int on);   // weight-gradient GEMMs of the BERT layers on an engine-owned side stream (default off)
+void set_wgrad_overlap(int on);
+void set_branch_overlap(int on);  // bert | pho | glyph branches on three streams inside forward / whole-pass backward (default on)   // weight-gradient GEMMs of the BERT layers on an engine-owned side stream (default off)
 
 struct EngineBase {
   virtual ~EngineBase() {}

@@ -22,6 +22,14 @@ namespace rl {
 // time-share CUs) while making per-kernel durations - and with them the roofline accounting - overlap-dependent.
 static int g_wgrad_overlap = 0;
 void set_wgrad_overlap(int on) { g_wgrad_overlap = on; }
+// Branch overlap (default on): the three branches of SpellBertPho2ResArch3 that are independent between the inputs and the gate
+// (models.py:816 bert, :818-827 pinyin GRU + pho_model, :829-838 glyph ResNet) - and their backward passes after the gate -
+// run on three HIP streams (the caller's + two engine-owned ones), forked and joined with events inside one engine call.  The
+// HBM-bound glyph kernels (BatchNorm passes, 64-channel convolutions) then fill the launch gaps / epilogue tails of the
+// MFMA-bound BERT GEMMs and co-reside on the CUs next to them (tools/overlap_probe.py: -25 % of the glyph branch's time).
+// Results are identical to the serial order (the branches touch disjoint tensors and scratch).
+static int g_branch_overlap = 1;
+void set_branch_overlap(int on) { g_branch_overlap = on; }
 
 #define RL_TRY(expr) do { const int _rc = (expr); if (_rc != RL_OK) { fprintf(stderr, "[realise_hip] %s failed (%d) at %s:%d\n", #expr, _rc, __FILE__, __LINE__); return _rc; } } while (0)
 
@@ -80,6 +88,8 @@ template <typename T> struct Engine : EngineBase {
     // backward scratch
     int64_t gA, gB, gC, gE, gD, gF, rowdot, X1, X2, X3, dz, tn_slab, ln_slots;
     int64_t wC1[2], wC2[2], wD[2], wF[2], tn_slab2;      // per-parity dY copies + second slab: weight gradients on the side stream
+    // backward scratch of the three concurrent branches: 0 = bert (the fields above), 1 = pho_model + GRU, 2 = glyph ResNet
+    struct Scratch { int64_t gB, gE, rowdot, tn_slab, tn_slab2, ln_slots, wC1[2], wC2[2], wD[2], wF[2]; } sc[3];
     int64_t gru_dh, gru_dgi, gru_dgh, gru_onehot, gru_dtable;
     int64_t r_dout, r_dc2, r_dcs, r_dh1, r_dc1, r_dx;
   } pl;
@@ -110,11 +120,37 @@ template <typename T> struct Engine : EngineBase {
     return RL_OK;
   }
   ~Engine() override {
+    if (bst[0] != nullptr) {
+      for (int k = 0; k < 2; ++k) { (void)hipStreamSynchronize(bst[k]); (void)hipStreamDestroy(bst[k]); (void)hipEventDestroy(ev_join[k]); }
+      (void)hipEventDestroy(ev_fork);
+    }
     if (side != nullptr) {
       (void)hipStreamSynchronize(side);
       for (int p = 0; p < 2; ++p) { for (int k = 0; k < 4; ++k) (void)hipEventDestroy(ev_ready[p][k]); (void)hipEventDestroy(ev_done[p]); }
       (void)hipStreamDestroy(side);
     }
+  }
+  // branch overlap: two engine-owned streams next to the caller's, fork / join events
+  hipStream_t bst[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  int cs = 0;                              // scratch set the backward helpers currently enqueue with (pl.sc[cs])
+  bool branches_ok() {
+    if (bst[0] != nullptr) return true;
+    for (int k = 0; k < 2; ++k)
+      if (hipStreamCreateWithFlags(&bst[k], hipStreamNonBlocking) != hipSuccess) { bst[0] = bst[1] = nullptr; return false; }
+    (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+    for (int k = 0; k < 2; ++k) (void)hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming);
+    return true;
+  }
+  int fork(hipStream_t st) {
+    if (hipEventRecord(ev_fork, st) != hipSuccess) return RL_ERR_LAUNCH;
+    for (int k = 0; k < 2; ++k) if (hipStreamWaitEvent(bst[k], ev_fork, 0) != hipSuccess) return RL_ERR_LAUNCH;
+    return RL_OK;
+  }
+  int join(hipStream_t st) {
+    for (int k = 0; k < 2; ++k)
+      if (hipEventRecord(ev_join[k], bst[k]) != hipSuccess || hipStreamWaitEvent(st, ev_join[k], 0) != hipSuccess) return RL_ERR_LAUNCH;
+    return RL_OK;
   }
   const int32_t* alive_dev = nullptr;      // device-side n_alive[Tp] of the last batch (nullptr: host counts)
   bool have_fwd = false;
@@ -271,6 +307,23 @@ template <typename T> struct Engine : EngineBase {
     p.tn_slab = b.take(TN_SLAB_ELEMS * 4);
     p.ln_slots = b.take(32 * 2 * 1024 * 4);
     tap("d_x0", p.gB, Tk * H);
+    {
+      typename Plan::Scratch& s0 = p.sc[0];
+      s0.gB = p.gB; s0.gE = p.gE; s0.rowdot = p.rowdot; s0.tn_slab = p.tn_slab; s0.tn_slab2 = p.tn_slab2; s0.ln_slots = p.ln_slots;
+      for (int k = 0; k < 2; ++k) { s0.wC1[k] = p.wC1[k]; s0.wC2[k] = p.wC2[k]; s0.wD[k] = p.wD[k]; s0.wF[k] = p.wF[k]; }
+      p.sc[1] = s0; p.sc[2] = s0;
+      if (cfg.model_type == 1) {
+        if (!glyph_only) {          // pho branch: a full private set (its layers run next to the bert layers)
+          typename Plan::Scratch& s1 = p.sc[1];
+          s1.gB = b.take(Tk * H * e); s1.gE = b.take(Tk * H * e); s1.rowdot = b.take((int64_t)B * nh * S * 4);
+          s1.tn_slab = b.take(TN_SLAB_ELEMS * 4); s1.tn_slab2 = s1.tn_slab; s1.ln_slots = b.take(32 * 2 * 1024 * 4);
+          s1.wC1[0] = b.take(Tk * H * e); s1.wC2[0] = b.take(Tk * H * e); s1.wD[0] = b.take(Tk * I * e); s1.wF[0] = b.take(Tk * 3 * H * e);
+          s1.wC1[1] = s1.wC1[0]; s1.wC2[1] = s1.wC2[0]; s1.wD[1] = s1.wD[0]; s1.wF[1] = s1.wF[0];
+        }
+        typename Plan::Scratch& s2 = p.sc[2];   // glyph branch: LayerNorm-backward output, slabs of the conv weight gradients
+        s2.gE = b.take(Tk * H * e); s2.tn_slab = b.take(TN_SLAB_ELEMS * 4); s2.ln_slots = b.take(32 * 2 * 1024 * 4);
+      }
+    }
     if (cfg.model_type == 1) {
       if (!glyph_only) {
         plan_stack(p.pho, cfg.pho_layers, "pho_model");
@@ -422,8 +475,9 @@ template <typename T> struct Engine : EngineBase {
   int layers_backward(hipStream_t st, int sid, const StackOff& so, const std::vector<LayerSh>& shs, StackAct& a, int hi, int lo,
                       T* gA) {
     const int B = pl.B, S = pl.S, Tk = B * S;
-    T* gB = wp<T>(pl.gB); T* gE = wp<T>(pl.gE);
-    const bool ov = g_wgrad_overlap && side_ok();
+    const typename Plan::Scratch& sc = pl.sc[cs];
+    T* gB = wp<T>(sc.gB); T* gE = wp<T>(sc.gE);
+    const bool ov = g_wgrad_overlap && !branch_mode && side_ok();
     for (int l = hi; l >= lo; --l) {
       const LayerOff& o = so.layers[l];
       const LayerSh& w = shs[l];
@@ -436,22 +490,22 @@ template <typename T> struct Engine : EngineBase {
       // run the four weight-gradient GEMMs on them; the caller's stream only waits before it re-uses that set (two layers
       // later).  Without overlap everything stays on `st` and set 0 is the plain scratch.
       const int p = ov ? (bw_layers++ & 1) : 0;
-      T* gC1 = wp<T>(pl.wC1[p]); T* gC2 = wp<T>(pl.wC2[p]); T* gD = wp<T>(pl.wD[p]); T* gF = wp<T>(pl.wF[p]);
+      T* gC1 = wp<T>(sc.wC1[p]); T* gC2 = wp<T>(sc.wC2[p]); T* gD = wp<T>(sc.wD[p]); T* gF = wp<T>(sc.wF[p]);
       if (ov && done_pending[p]) {
         if (hipStreamWaitEvent(st, ev_done[p], 0) != hipSuccess) return RL_ERR_LAUNCH;
         done_pending[p] = false;
       }
       auto wgrad = [&](int k, const T* dy, int64_t ldy, const T* x, int64_t ldx, int Iw, int Jw, float* bias_g, float* w_g) -> int {
         hipStream_t ws_ = st;
-        TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = bias_g; te.out = w_g; te.ldo = Jw;
+        TnEpi te; te.slab = wp<float>(sc.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = bias_g; te.out = w_g; te.ldo = Jw;
         if (ov) {
           if (hipEventRecord(ev_ready[p][k], st) != hipSuccess || hipStreamWaitEvent(side, ev_ready[p][k], 0) != hipSuccess) return RL_ERR_LAUNCH;
-          ws_ = side; te.slab = wp<float>(pl.tn_slab2);
+          ws_ = side; te.slab = wp<float>(sc.tn_slab2);
         }
         return gemm_tn<T>(ws_, dy, ldy, x, ldx, Tk, Iw, Jw, te);
       };
       {  // output LayerNorm: gA = d y2 -> gB = d s2 (residual part of d y1), gC1 = d(dense out) = d s2 * dropmask
-        LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
+        LnBwdArgs<T> ln; ln.slots = wp<float>(sc.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
         ln.gamma = pp(o.out_ln_g); ln.dx = gB; ln.dx_drop = (d3.thresh || ov) ? gC1 : nullptr; ln.out_drop = d3;
         ln.dgamma = gp(o.out_ln_g); ln.dbeta = gp(o.out_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
@@ -468,7 +522,7 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(gemm_nt<T>(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
       }
       {  // attention-output LayerNorm: gB = d y1 -> gA = d s1, gC2 = d(dense out)
-        LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
+        LnBwdArgs<T> ln; ln.slots = wp<float>(sc.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
         ln.gamma = pp(o.ao_ln_g); ln.dx = gA; ln.dx_drop = (d2.thresh || ov) ? gC2 : nullptr; ln.out_drop = d2;
         ln.dgamma = gp(o.ao_ln_g); ln.dbeta = gp(o.ao_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
@@ -482,7 +536,7 @@ template <typename T> struct Engine : EngineBase {
       {
         const T* q = wp<T>(t.qkv);
         RL_TRY(attn_bwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), gE, H, wp<float>(t.lse),
-                           wp<float>(pl.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale));
+                           wp<float>(sc.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale));
       }
       RL_TRY(wgrad(3, gF, 3 * H, x_in, H, 3 * H, H, gp(o.qkv_b), gp(o.qkv_w)));
       {  // d x_in = d s1 + d qkv . W_qkv
@@ -500,7 +554,7 @@ template <typename T> struct Engine : EngineBase {
   // embeddings backward: gA = d(embedding output) -> dx (T*, d of the pre-LayerNorm sum) ; scatters table grads
   int emb_backward(hipStream_t st, int sid, const StackOff& so, StackAct& a, const int64_t* ids, int pos_zero, const T* gA, T* dx) {
     const int B = pl.B, S = pl.S, Tk = B * S;
-    LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.in_drop = site(sid * 1000 + 900, cfg.hidden_dropout);
+    LnBwdArgs<T> ln; ln.slots = wp<float>(pl.sc[cs].ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.in_drop = site(sid * 1000 + 900, cfg.hidden_dropout);
     ln.xhat = wp<T>(a.emb_xhat); ln.rstd = wp<float>(a.emb_rstd); ln.gamma = pp(so.ln_g); ln.dx = dx;
     ln.dgamma = gp(so.ln_g); ln.dbeta = gp(so.ln_b);
     RL_TRY(ln_bwd<T>(st, ln));
@@ -608,7 +662,7 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), pp(o.bns.g), sums,
                              Pn, Co, dcs, gp(o.bns.g), gp(o.bns.b), rb, Pn));
       // conv2 (3x3 s1): weight grad and data grad
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w2); te.Cin = Co; te.Cpad = Co; te.KHW = 9;
+      { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w2); te.Cin = Co; te.Cpad = Co; te.KHW = 9;
         RL_TRY(gemm_tn_conv<T>(st, dc2, Co, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0, rb.rows_dev), Pn, Co, 9 * Co, te)); }
       { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = dh1; ep.ldo = Co;
         RL_TRY(gemm_nt_conv<T>(st, geom(dc2, nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 1, rb.rows_dev), sp<T>(s.w2d), 9 * Co, Pn, Co, 9 * Co, ep)); }
@@ -618,9 +672,9 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(bn_bwd_apply<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), pp(o.bn1.g), sums,
                              Pn, Co, dc1, gp(o.bn1.g), gp(o.bn1.b), rb, Pn));
       // conv1 (3x3 s2) and shortcut (1x1 s2) weight grads
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w1); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 9;
+      { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w1); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 9;
         RL_TRY(gemm_tn_conv<T>(st, dc1, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 3, 2, 1, 0, rb.rows_dev), Pn, Co, 9 * Cin, te)); }
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.ws); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 1;
+      { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.ws); te.Cin = o.cin; te.Cpad = Cin; te.KHW = 1;
         RL_TRY(gemm_tn_conv<T>(st, dcs, Co, geom(x_in, index, Pn, a.Hout, a.Hin, Cin, 1, 2, 0, 0, rb.rows_dev), Pn, Co, Cin, te)); }
       if (k > 0) {   // d x_in = dgrad(conv1) + dgrad(shortcut); the glyph table itself is frozen
         const int Pin = pl.blk[k - 1].Pout;
@@ -678,10 +732,10 @@ template <typename T> struct Engine : EngineBase {
       a.rzn = wp<T>(pl.gru_rzn) + (int64_t)t * N * 3 * H; a.dout = dout; a.dh = wp<T>(pl.gru_dh); a.dgi = wp<T>(pl.gru_dgi);
       a.dgh = wp<T>(pl.gru_dgh); a.onehot = wp<T>(pl.gru_onehot);
       RL_TRY(gru_step_bwd<T>(st, a));
-      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = dtable; te.ldo = 3 * H; RL_TRY(gemm_tn<T>(st, a.onehot, 64, a.dgi, 3 * H, n, 64, 3 * H, te, nd)); }
+      { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = dtable; te.ldo = 3 * H; RL_TRY(gemm_tn<T>(st, a.onehot, 64, a.dgi, 3 * H, n, 64, 3 * H, te, nd)); }
       RL_TRY(bias_grad<T>(st, a.dgh, 3 * H, n, 3 * H, gp(L.gru_b_hh), nd));
       if (t > 0) {
-        { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(L.gru_w_hh); te.ldo = H; RL_TRY(gemm_tn<T>(st, a.dgh, 3 * H, hs_prev, H, n, 3 * H, H, te, nd)); }
+        { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(L.gru_w_hh); te.ldo = H; RL_TRY(gemm_tn<T>(st, a.dgh, 3 * H, hs_prev, H, n, 3 * H, H, te, nd)); }
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = a.dh; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, a.dgh, 3 * H, sp<T>(sh_gru_hhT), 3 * H, n, H, 3 * H, ep, nd));
       }
@@ -721,20 +775,24 @@ template <typename T> struct Engine : EngineBase {
     const int Tk = b.B * b.S;
     RL_TRY(mask_to_additive(st, b.masks, wp<float>(pl.mask_add), Tk));
     const T* bert_h = nullptr;
+    const bool ovl = cfg.model_type == 1 && g_branch_overlap && branches_ok();
+    hipStream_t s_pho = ovl ? bst[0] : st, s_glyph = ovl ? bst[1] : st;
+    if (ovl) RL_TRY(fork(st));                                    // bert | pinyin GRU + pho_model | glyph ResNet
     RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, b.src_idx, nullptr, 0, &bert_h));
     const T* top = bert_h;
     if (cfg.model_type == 1) {
-      RL_TRY(gru_forward(st));
+      RL_TRY(gru_forward(s_pho));
       const T* pho_h = nullptr;
-      RL_TRY(stack_forward(st, 1, L.pho, sh_pho, pl.pho, nullptr, wp<T>(pl.gru_out), 0, &pho_h));
+      RL_TRY(stack_forward(s_pho, 1, L.pho, sh_pho, pl.pho, nullptr, wp<T>(pl.gru_out), 0, &pho_h));
       const T* res = nullptr;
-      RL_TRY(resnet_forward(st, b.src_idx, &res));
+      RL_TRY(resnet_forward(s_glyph, b.src_idx, &res));
       {
         LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = res; ln.row_index = wp<int>(pl.gu_inv);      // token t reads its glyph's row
         ln.gamma = pp(L.res_ln_g); ln.beta = pp(L.res_ln_b); ln.eps = cfg.ln_eps;
         ln.y = wp<T>(pl.res_h); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
-        RL_TRY(ln_fwd<T>(st, ln));
+        RL_TRY(ln_fwd<T>(s_glyph, ln));
       }
+      if (ovl) RL_TRY(join(st));
       RL_TRY(gate_fwd<T>(st, gate_args()));
       RL_TRY(stack_forward(st, 2, L.outb, sh_out, pl.outb, nullptr, wp<T>(pl.fused), 1, &top));
     }
@@ -811,54 +869,78 @@ template <typename T> struct Engine : EngineBase {
         int lo = hi - 3 > 0 ? hi - 3 : 0;
         RL_TRY(layers_backward(st, 0, L.bert, sh_bert, pl.bert, hi, lo, gA));
       } else {
-        RL_TRY(emb_backward(st, 0, L.bert, pl.bert, last.src_idx, 0, gA, wp<T>(pl.gB)));
+        RL_TRY(emb_backward(st, 0, L.bert, pl.bert, last.src_idx, 0, gA, wp<T>(pl.sc[0].gB)));
       }
       return RL_OK;
     }
     switch (s) {
-      case 0: {   // head + output_block
-        RL_TRY(stage_head(st));
-        RL_TRY(layers_backward(st, 2, L.outb, sh_out, pl.outb, cfg.out_layers - 1, 0, gA));
-        RL_TRY(emb_backward(st, 2, L.outb, pl.outb, nullptr, 1, gA, wp<T>(pl.gB)));      // gB = d fused
-      } break;
-      case 1: {   // gate, resnet LayerNorm, glyph ResNet
-        GateArgs<T> g = gate_args();
-        g.dfused = wp<T>(pl.gB); g.dbert = wp<T>(pl.X1); g.dpho = wp<T>(pl.X2); g.dres = wp<T>(pl.X3); g.dz = wp<float>(pl.dz);
-        g.dW = gp(L.gate_w); g.dbias = gp(L.gate_b);
-        RL_TRY(gate_bwd<T>(st, g));
-        LnBwdArgs<T> ln; ln.slots = wp<float>(pl.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = wp<T>(pl.X3); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
-        ln.gamma = pp(L.res_ln_g); ln.dx = wp<T>(pl.gE); ln.dgamma = gp(L.res_ln_g); ln.dbeta = gp(L.res_ln_b);
-        RL_TRY(ln_bwd<T>(st, ln));
-        // per-token gradient -> per-distinct-glyph gradient (sum over the tokens that share the glyph)
-        RL_TRY(segment_sum<T>(st, wp<T>(pl.gE), wp<int>(pl.gu_inv), Tk, H, wp<float>(pl.seg_acc), wp<T>(pl.r_dout), wp<int>(pl.gu_bounds)));
-        RL_TRY(resnet_backward(st, wp<T>(pl.r_dout)));
-      } break;
-      case 2: {   // pho_model + GRU
-        T* g2 = wp<T>(pl.X2);
-        RL_TRY(layers_backward(st, 1, L.pho, sh_pho, pl.pho, cfg.pho_layers - 1, 0, g2));
-        RL_TRY(emb_backward(st, 1, L.pho, pl.pho, nullptr, 0, g2, wp<T>(pl.gE)));       // gE = d gru_out (original order)
-        RL_TRY(gru_backward(st, wp<T>(pl.gE)));
-      } break;
-      default: {
-        const int g = s - 3;
-        T* g1 = wp<T>(pl.X1);
-        if (g < L.bert_groups) {
-          int hi = cfg.bert_layers - 1 - 4 * g;
-          int lo = hi - 3 > 0 ? hi - 3 : 0;
-          RL_TRY(layers_backward(st, 0, L.bert, sh_bert, pl.bert, hi, lo, g1));
-        } else {
-          RL_TRY(emb_backward(st, 0, L.bert, pl.bert, last.src_idx, 0, g1, wp<T>(pl.gB)));
-        }
-      } break;
+      case 0: RL_TRY(stage_out_block(st)); break;
+      case 1: RL_TRY(stage_gate(st)); RL_TRY(stage_glyph(st)); break;
+      case 2: RL_TRY(stage_pho(st)); break;
+      default: RL_TRY(stage_bert(st, s - 3)); break;
     }
     return RL_OK;
   }
+  int stage_out_block(hipStream_t st) {      // head + output_block; leaves d fused in gB (set 0)
+    T* gA = wp<T>(pl.gA);
+    RL_TRY(stage_head(st));
+    RL_TRY(layers_backward(st, 2, L.outb, sh_out, pl.outb, cfg.out_layers - 1, 0, gA));
+    RL_TRY(emb_backward(st, 2, L.outb, pl.outb, nullptr, 1, gA, wp<T>(pl.sc[0].gB)));
+    return RL_OK;
+  }
+  int stage_gate(hipStream_t st) {           // d fused -> X1 (d bert), X2 (d pho), X3 (d res) + gate_net gradients
+    GateArgs<T> g = gate_args();
+    g.dfused = wp<T>(pl.sc[0].gB); g.dbert = wp<T>(pl.X1); g.dpho = wp<T>(pl.X2); g.dres = wp<T>(pl.X3); g.dz = wp<float>(pl.dz);
+    g.dW = gp(L.gate_w); g.dbias = gp(L.gate_b);
+    return gate_bwd<T>(st, g);
+  }
+  int stage_glyph(hipStream_t st) {          // resnet LayerNorm, segment sum over the tokens of a glyph, glyph ResNet
+    const int Tk = pl.B * pl.S;
+    const typename Plan::Scratch& sc = pl.sc[cs];
+    LnBwdArgs<T> ln; ln.slots = wp<float>(sc.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = wp<T>(pl.X3); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
+    ln.gamma = pp(L.res_ln_g); ln.dx = wp<T>(sc.gE); ln.dgamma = gp(L.res_ln_g); ln.dbeta = gp(L.res_ln_b);
+    RL_TRY(ln_bwd<T>(st, ln));
+    RL_TRY(segment_sum<T>(st, wp<T>(sc.gE), wp<int>(pl.gu_inv), Tk, H, wp<float>(pl.seg_acc), wp<T>(pl.r_dout), wp<int>(pl.gu_bounds)));
+    return resnet_backward(st, wp<T>(pl.r_dout));
+  }
+  int stage_pho(hipStream_t st) {            // pho_model + GRU
+    T* g2 = wp<T>(pl.X2);
+    T* gE = wp<T>(pl.sc[cs].gE);
+    RL_TRY(layers_backward(st, 1, L.pho, sh_pho, pl.pho, cfg.pho_layers - 1, 0, g2));
+    RL_TRY(emb_backward(st, 1, L.pho, pl.pho, nullptr, 0, g2, gE));       // gE = d gru_out (original order)
+    return gru_backward(st, gE);
+  }
+  int stage_bert(hipStream_t st, int g) {    // bert layer group g, or (g == groups) its embeddings
+    T* g1 = wp<T>(pl.X1);
+    if (g < L.bert_groups) {
+      int hi = cfg.bert_layers - 1 - 4 * g;
+      int lo = hi - 3 > 0 ? hi - 3 : 0;
+      return layers_backward(st, 0, L.bert, sh_bert, pl.bert, hi, lo, g1);
+    }
+    return emb_backward(st, 0, L.bert, pl.bert, last.src_idx, 0, g1, wp<T>(pl.sc[0].gB));
+  }
 
+  bool branch_mode = false;
   int backward(hipStream_t st, int first, int last_stage) override {
     if (!have_fwd) { fprintf(stderr, "[realise_hip] backward without a training forward (tgt_idx + want_dlogits)\n"); return RL_ERR_ARG; }
     const int n = n_stages();
     if (last_stage < 0) last_stage = n - 1;
     if (first < 0 || last_stage >= n || first > last_stage) return RL_ERR_ARG;
+    cs = 0;
+    // whole pass in one call (no per-bucket gradient exchange in between): the three branches behind the gate run concurrently
+    if (cfg.model_type == 1 && first == 0 && last_stage == n - 1 && g_branch_overlap && !g_wgrad_overlap && branches_ok()) {
+      branch_mode = true;
+      int rc = stage_out_block(st);
+      if (rc == RL_OK) rc = stage_gate(st);
+      if (rc == RL_OK) rc = fork(st);
+      if (rc == RL_OK) { cs = 2; rc = stage_glyph(bst[1]); }
+      if (rc == RL_OK) { cs = 1; rc = stage_pho(bst[0]); }
+      cs = 0;
+      for (int g = 0; rc == RL_OK && g <= L.bert_groups; ++g) rc = stage_bert(st, g);
+      const int rj = join(st);
+      branch_mode = false;
+      return rc != RL_OK ? rc : rj;
+    }
     for (int s = first; s <= last_stage; ++s) RL_TRY(run_stage(st, s));
     return join_side(st);          // the caller's stream owns every gradient of these stages once this returns
   }
