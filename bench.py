@@ -283,6 +283,7 @@ def main():
 
     overlap = 0 if args.no_overlap else 1
     lib.realise_set_branch_overlap(overlap)
+    lib.realise_set_wgrad_overlap(overlap)
 
     def prof_step(i):
         if profile:                                          # bracket launches on every 10th timed step only
@@ -291,11 +292,13 @@ def main():
             # per-launch durations are only meaningful when a kernel has the chip to itself: the sampled steps run the three
             # model branches serially (the other steps overlap them on three streams)
             lib.realise_set_branch_overlap(0 if on else overlap)
+            lib.realise_set_wgrad_overlap(0 if on else overlap)
             sampled[0] += on
         step()
 
     elapsed = timed_loop(prof_step, args.steps, world, dev)
     lib.realise_set_branch_overlap(overlap)
+    lib.realise_set_wgrad_overlap(overlap)
     final_loss = float(tr_loss.item()) / max(1, args.steps + args.warmup)
     fams = {}
     if profile:

@@ -88,9 +88,9 @@ void realise_set_nt_wide_epilogue(int on);
 /* A/B knob: 1 (default) run the glyph ResNet once per distinct token id with multiplicity-weighted BatchNorm;
  * 0 run it densely over all B*S tokens like the reference (identical results) */
 void realise_set_glyph_dedup(int on);
-/* A/B knob: 1 = the four weight-gradient GEMMs of each BERT layer run on an engine-owned side stream, overlapped with the
- * data-gradient chain on the caller's stream (joined before realise_engine_backward returns); 0 (default) everything in
- * order on the caller's stream.  Identical results; +1 % throughput measured, per-kernel timings become overlap-dependent. */
+/* A/B knob: 1 (default) = the four weight-gradient GEMMs of each BERT layer run on an engine-owned side stream, overlapped with the
+ * data-gradient chain on the caller's stream (joined before realise_engine_backward returns); 0 everything in order on the
+ * caller's stream.  Identical results; +2 % throughput measured, per-kernel timings become overlap-dependent. */
 void realise_set_wgrad_overlap(int on);
 /* 1 (default): the three branches of SpellBertPho2ResArch3.forward that are independent between the inputs and the gate
  * (src/models.py:816 bert | :818-827 pinyin GRU + pho_model | :829-838 glyph ResNet), and their backward passes behind the

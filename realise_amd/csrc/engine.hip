@@ -18,9 +18,11 @@
 
 namespace rl {
 
-// Off by default: measured +1.1 % step throughput on MI355X (the GEMMs already fill the chip, so the two streams mostly
-// time-share CUs) while making per-kernel durations - and with them the roofline accounting - overlap-dependent.
-static int g_wgrad_overlap = 0;
+// Weight-gradient overlap (default on): the four wgrad GEMMs of a BERT layer run on an engine-owned side stream while the caller's
+// stream continues with the data-gradient chain (two dY buffer sets, by layer parity).  +2.3 % step throughput on top of the branch
+// overlap below (bench.py: 23.6 -> 23.1 ms); identical results.  Per-kernel durations become overlap-dependent, so bench.py
+// switches both overlaps off on the steps whose launches it brackets with events.
+static int g_wgrad_overlap = 1;
 void set_wgrad_overlap(int on) { g_wgrad_overlap = on; }
 // Branch overlap (default on): the three branches of SpellBertPho2ResArch3 that are independent between the inputs and the gate
 // (models.py:816 bert, :818-827 pinyin GRU + pho_model, :829-838 glyph ResNet) - and their backward passes after the gate -
@@ -477,7 +479,7 @@ template <typename T> struct Engine : EngineBase {
     const int B = pl.B, S = pl.S, Tk = B * S;
     const typename Plan::Scratch& sc = pl.sc[cs];
     T* gB = wp<T>(sc.gB); T* gE = wp<T>(sc.gE);
-    const bool ov = g_wgrad_overlap && !branch_mode && side_ok();
+    const bool ov = g_wgrad_overlap && (!branch_mode || cs == 0) && side_ok();      // under branch overlap only the bert branch owns two dY sets
     for (int l = hi; l >= lo; --l) {
       const LayerOff& o = so.layers[l];
       const LayerSh& w = shs[l];
@@ -928,7 +930,7 @@ template <typename T> struct Engine : EngineBase {
     if (first < 0 || last_stage >= n || first > last_stage) return RL_ERR_ARG;
     cs = 0;
     // whole pass in one call (no per-bucket gradient exchange in between): the three branches behind the gate run concurrently
-    if (cfg.model_type == 1 && first == 0 && last_stage == n - 1 && g_branch_overlap && !g_wgrad_overlap && branches_ok()) {
+    if (cfg.model_type == 1 && first == 0 && last_stage == n - 1 && g_branch_overlap && branches_ok()) {
       branch_mode = true;
       int rc = stage_out_block(st);
       if (rc == RL_OK) rc = stage_gate(st);
@@ -938,8 +940,9 @@ template <typename T> struct Engine : EngineBase {
       cs = 0;
       for (int g = 0; rc == RL_OK && g <= L.bert_groups; ++g) rc = stage_bert(st, g);
       const int rj = join(st);
+      const int rs = join_side(st);
       branch_mode = false;
-      return rc != RL_OK ? rc : rj;
+      return rc != RL_OK ? rc : (rj != RL_OK ? rj : rs);
     }
     for (int s = first; s <= last_stage; ++s) RL_TRY(run_stage(st, s));
     return join_side(st);          // the caller's stream owns every gradient of these stages once this returns

@@ -411,7 +411,7 @@ def test_wgrad_side_stream_overlap_gives_the_same_gradients(golden_dir):
             torch.cuda.synchronize()
             out.append((loss.item(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
     finally:
-        lib.realise_set_wgrad_overlap(0)
+        lib.realise_set_wgrad_overlap(1)
     assert abs(out[0][0] - out[1][0]) < 1e-5                 # the loss sum itself uses fp32 atomics
     for n, g0 in out[0][1].items():
         g1 = out[1][1][n]
