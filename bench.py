@@ -246,7 +246,7 @@ def main():
         return glyph_workload(args, model, dev, lib, world, rank)
     B = args.batch or 64
     sd_cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
         sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(dev)
     model.train()

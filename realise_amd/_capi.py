@@ -56,6 +56,7 @@ SYMBOLS = {
     "realise_set_nt_variant": (None, [_I]),
     "realise_set_tn_probe": (None, [_I]),
     "realise_set_tn_split": (None, [_I]),
+    "realise_set_tn_variant": (None, [_I]),
     "realise_set_attn_probe": (None, [_I]),
     "realise_set_branch_overlap": (None, [_I]),
     "realise_set_nt_wide_epilogue": (None, [_I]),

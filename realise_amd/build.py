@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "librealise_hip.so")
-SOURCES = ["gemm.hip", "gemm_nt8.hip", "attention.hip", "ops.hip", "ops2.hip", "engine.hip", "capi.hip", "prof.hip"]
+SOURCES = ["gemm.hip", "gemm_nt8.hip", "gemm_tn8.hip", "attention.hip", "ops.hip", "ops2.hip", "engine.hip", "capi.hip", "prof.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc"]
 
 
@@ -64,7 +64,7 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
         # an instantiation the compiler silently dropped shows up only at dlopen time (undefined symbol): check it here
-        chk = subprocess.run([sys.executable, "-c", "import ctypes, sys; ctypes.CDLL(sys.argv[1])", LIB], capture_output=True, text=True)
+        chk = subprocess.run([sys.executable, "-c", "import ctypes, os, sys; ctypes.CDLL(sys.argv[1], mode=os.RTLD_NOW)", LIB], capture_output=True, text=True)
         if chk.returncode != 0:
             raise RuntimeError("librealise_hip.so does not load:\n%s" % chk.stderr[-2000:])
     return LIB

@@ -77,6 +77,7 @@ void realise_set_nt_variant(int v) { set_nt_variant(v); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }
 void realise_set_tn_split(int n) { set_tn_split(n); }
+void realise_set_tn_variant(int v) { set_tn_variant(v); }
 void realise_set_nt_wide_epilogue(int on) { set_nt_wide_epilogue(on); }
 void realise_set_glyph_dedup(int on) { set_glyph_dedup(on); }
 void realise_set_wgrad_overlap(int on) { set_wgrad_overlap(on); }

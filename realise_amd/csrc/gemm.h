@@ -228,6 +228,12 @@ int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int6
              const EpiParams<bf16_t>& ep, int tile);
 void set_nt8_probe(int mode);             // 2 no fetches, 3 no MFMA / fragment reads (results wrong)
 
+// Ping-pong 8-wave weight-gradient kernel (gemm_tn8.hip): bf16, dense operands, 256 x 128 output tiles, split reduction + fold
+bool tn8_supported(int64_t lda, int64_t ldb, int P, int I, int J, const TnEpi& ep);
+int gemm_tn8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int P, int I, int J, const TnEpi& ep, int force_split);
+void tn_fold_launch(hipStream_t st, const TnEpi& ep, int nsplit, int I, int J);     // out += alpha * sum of the split slabs, fixed order
+void set_tn_variant(int v);               // 0 production, 9 force the 4-wave TN kernel
+
 void set_tn_transpose_read(int use_tr);
 void set_nt_wide_epilogue(int on);        // A/B knob: LDS-staged 16-B-per-lane epilogue (default on)
 void set_tn_probe(int mode);

@@ -420,7 +420,7 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
   if constexpr (sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos) && sizeof(T) == 2) {
     // Production path for the big dense GEMMs: the ping-pong 8-wave kernel (gemm_nt8.hip), tile by chip fill.  Variants 10..34
     // force one of its tiles / issue flavours, variant 9 forces the 4-wave kernel below (tools/nt8_probe.cpp).
-    if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 34))) {
+    if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 44))) {
       if (nt8_supported(M, N, K, ep, la.ld, ldb)) return gemm_nt8(st, la.base, la.ld, B, ldb, M, N, K, ep, g_nt_variant >= 10 ? g_nt_variant - 10 : 0);
     }
     switch (g_nt_variant) {       // experimental tile shapes (tools/nt_probe.cpp)
@@ -482,48 +482,6 @@ template int gemm_nt_conv<float>(hipStream_t, const ConvLoader<float>&, const fl
 // slabs that a second kernel folds into the gradient (no atomics; a single split accumulates in
 // place).  WI x WJ waves: (2,2) -> 128x128 outputs; (1,4) -> 64x256 for the 64-channel glyph convs.
 // =================================================================================================
-template <typename T> struct TnGeo;
-template <> struct TnGeo<bf16_t> { static constexpr int BP = 64, KSTEPS = 2, VEC = 8; };
-template <> struct TnGeo<float> { static constexpr int BP = 32, KSTEPS = 8, VEC = 4; };
-
-// Byte XOR applied to the column offset of reduction row p (keeps 16-byte chunks intact).  bf16: one
-// ds_read_b64_tr_b16 half-wave touches rows {p0..p0+3} and {p0+8..p0+11} at the same 32-byte column block;
-// the XOR spreads those 8 rows over 8 distinct 32-byte slots of the 256-byte bank row (4 slots when the
-// tile row is only 128 bytes).  fp32: lanes 0-31 read rows p, p+1 -> two 64-byte halves.
-template <typename T, int RP> __device__ __forceinline__ int tn_swz(int p) {
-  if constexpr (sizeof(T) == 2) return (((p & 3) | (((p >> 3) & 1) << 2)) << 5) & (RP - 1);
-  else return ((p & 1) << 6) & (RP - 1);
-}
-
-template <bool TR, int RP>
-__device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int ks, int col0, int l15, int g) {
-  if constexpr (TR) {
-    // 16-lane group g reads the [4 p][16 col] blocks at rows 8g+4h .. +3; lane q of the group points at
-    // row (q >> 2), columns 4*(q & 3) .. +3 and receives column q, 4 consecutive p.
-    typedef short4_t __attribute__((address_space(3))) * lds_s4;
-    short4_t h[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int p = ks * 32 + 8 * g + 4 * hh + (l15 >> 2);
-      const int colb = ((col0 + 4 * (l15 & 3)) * 2) ^ tn_swz<bf16_t, RP>(p);
-      h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + p * RP + colb));
-    }
-    typedef __attribute__((ext_vector_type(8))) short short8_t;
-    short8_t r = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
-    return __builtin_bit_cast(bf16x8_t, r);
-  } else {
-    typedef __attribute__((ext_vector_type(8))) unsigned short ushort8_t;
-    ushort8_t r;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int p = ks * 32 + 8 * g + e;
-      r[e] = *(const unsigned short*)(tile + p * RP + (((col0 + l15) * 2) ^ tn_swz<bf16_t, RP>(p)));
-    }
-    return __builtin_bit_cast(bf16x8_t, r);
-  }
-}
-
-enum TnOut { TN_OUT_DIRECT = 0, TN_OUT_SLAB = 1, TN_OUT_ATOMIC = 2 };
 
 // Per-wave state of a gathered B operand of the TN kernel: NB pieces per reduction tile, the lane's (tap, channel) per piece is
 // fixed for the whole kernel, only the reduction row p moves.
@@ -549,33 +507,6 @@ template <typename T, int NB> struct ConvTaps<ConvLoader<T>, NB> {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_piece, 16, voff, 0, 0, 0);
   }
 };
-
-__device__ __forceinline__ int64_t tn_out_index(const TnEpi& ep, int i, int j) {   // -1: padding column
-  if (ep.mode == TN_PLAIN) return (int64_t)i * ep.ldo + j;
-  const int tap = j / ep.Cpad, ci = j - tap * ep.Cpad;
-  return ci < ep.Cin ? ((int64_t)i * ep.Cin + ci) * ep.KHW + tap : -1;
-}
-
-__device__ __forceinline__ void tn_epilogue4(const TnEpi& ep, int how, int split, int I, int J, int i, int j, floatx4 v) {
-  if (i >= I || j >= J) return;
-  if (how == TN_OUT_SLAB) {                       // dense [split][I][J]; J % 4 == 0
-    *(floatx4*)(ep.slab + ((int64_t)split * I + i) * J + j) = v;
-    return;
-  }
-  v *= ep.alpha;
-  if (how == TN_OUT_DIRECT && ep.mode == TN_PLAIN && (ep.ldo & 3) == 0) {
-    floatx4* o = (floatx4*)(ep.out + (int64_t)i * ep.ldo + j);
-    *o = *o + v;
-    return;
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int64_t idx = tn_out_index(ep, i, j + r);
-    if (idx < 0) continue;
-    if (how == TN_OUT_DIRECT) ep.out[idx] += v[r];
-    else atomicAdd(ep.out + idx, v[r]);
-  }
-}
 
 template <typename T, typename BLoader, bool TR, int WI, int WJ>
 __global__ void __launch_bounds__(256, 2)
@@ -768,6 +699,13 @@ __global__ void __launch_bounds__(256) tn_fold_kernel(TnEpi ep, int nsplit, int 
   }
 }
 
+void tn_fold_launch(hipStream_t st, const TnEpi& ep, int nsplit, int I, int J) {
+  const int64_t n4 = (int64_t)I * J / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(tn_fold_kernel, dim3(blocks), dim3(256), 0, st, ep, nsplit, I, J);
+}
+
 static int g_tn_tr = 1;   // ds_read_b64_tr_b16 verified on MI355X (tests/test_kernels_gpu.py::test_gemm_tn)
 void set_tn_transpose_read(int use_tr) { g_tn_tr = use_tr; }
 
@@ -813,12 +751,7 @@ static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader
       if (!a2) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, false, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
       hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, false, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
     }
-    if (how == TN_OUT_SLAB && ep.probe != 4) {
-      const int64_t n4 = (int64_t)I * J / 4;
-      int blocks = (int)((n4 + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      hipLaunchKernelGGL(tn_fold_kernel, dim3(blocks), dim3(256), 0, st, ep, nsplit, I, J);
-    }
+    if (how == TN_OUT_SLAB && ep.probe != 4) tn_fold_launch(st, ep, nsplit, I, J);
   }
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
@@ -832,10 +765,17 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb,
   return launch_tn_tile<T, BLoader, 2, 2>(st, A, lda, lb, P, I, J, ep);
 }
 
+static int g_tn_variant = 0;      // 0 production (the 4-wave kernel), 8 the experimental 8-wave ping-pong kernel (gemm_tn8.hip: correct, 7-16 % slower)
+void set_tn_variant(int v) { g_tn_variant = v; }
+
 template <typename T>
 int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep,
             const int* rows_dev) {
   if (ldb % TnGeo<T>::VEC) return RL_ERR_ARG;
+  if constexpr (sizeof(T) == 2) {
+    if (rows_dev == nullptr && g_tn_variant == 8 && g_tn_probe == 0 && tn8_supported(lda, ldb, P, I, J, ep))
+      return gemm_tn8(st, A, lda, B, ldb, P, I, J, ep, g_tn_split);
+  }
   DenseLoader<T> lb{B, ldb, P, J};
   lb.rows_dev = rows_dev;
   return launch_tn<T, DenseLoader<T>>(st, A, lda, lb, P, I, J, ep);

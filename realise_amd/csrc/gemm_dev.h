@@ -95,4 +95,76 @@ __device__ __forceinline__ void epilogue8(const EpiParams<T>& ep, int M, int N, 
 }
 
 
+// ---- TN (weight-gradient) device helpers shared by gemm.hip and gemm_tn8.hip ---------------------------------------------
+template <typename T> struct TnGeo;
+template <> struct TnGeo<bf16_t> { static constexpr int BP = 64, KSTEPS = 2, VEC = 8; };
+template <> struct TnGeo<float> { static constexpr int BP = 32, KSTEPS = 8, VEC = 4; };
+
+// Byte XOR applied to the column offset of reduction row p (keeps 16-byte chunks intact).  bf16: one
+// ds_read_b64_tr_b16 half-wave touches rows {p0..p0+3} and {p0+8..p0+11} at the same 32-byte column block;
+// the XOR spreads those 8 rows over 8 distinct 32-byte slots of the 256-byte bank row (4 slots when the
+// tile row is only 128 bytes).  fp32: lanes 0-31 read rows p, p+1 -> two 64-byte halves.
+template <typename T, int RP> __device__ __forceinline__ int tn_swz(int p) {
+  if constexpr (sizeof(T) == 2) return (((p & 3) | (((p >> 3) & 1) << 2)) << 5) & (RP - 1);
+  else return ((p & 1) << 6) & (RP - 1);
+}
+
+template <bool TR, int RP>
+__device__ __forceinline__ bf16x8_t tn_frag_bf16(const char* tile, int ks, int col0, int l15, int g) {
+  if constexpr (TR) {
+    // 16-lane group g reads the [4 p][16 col] blocks at rows 8g+4h .. +3; lane q of the group points at
+    // row (q >> 2), columns 4*(q & 3) .. +3 and receives column q, 4 consecutive p.
+    typedef short4_t __attribute__((address_space(3))) * lds_s4;
+    short4_t h[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int p = ks * 32 + 8 * g + 4 * hh + (l15 >> 2);
+      const int colb = ((col0 + 4 * (l15 & 3)) * 2) ^ tn_swz<bf16_t, RP>(p);
+      h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + p * RP + colb));
+    }
+    typedef __attribute__((ext_vector_type(8))) short short8_t;
+    short8_t r = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+    return __builtin_bit_cast(bf16x8_t, r);
+  } else {
+    typedef __attribute__((ext_vector_type(8))) unsigned short ushort8_t;
+    ushort8_t r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int p = ks * 32 + 8 * g + e;
+      r[e] = *(const unsigned short*)(tile + p * RP + (((col0 + l15) * 2) ^ tn_swz<bf16_t, RP>(p)));
+    }
+    return __builtin_bit_cast(bf16x8_t, r);
+  }
+}
+
+enum TnOut { TN_OUT_DIRECT = 0, TN_OUT_SLAB = 1, TN_OUT_ATOMIC = 2 };
+
+__device__ __forceinline__ int64_t tn_out_index(const TnEpi& ep, int i, int j) {   // -1: padding column
+  if (ep.mode == TN_PLAIN) return (int64_t)i * ep.ldo + j;
+  const int tap = j / ep.Cpad, ci = j - tap * ep.Cpad;
+  return ci < ep.Cin ? ((int64_t)i * ep.Cin + ci) * ep.KHW + tap : -1;
+}
+
+__device__ __forceinline__ void tn_epilogue4(const TnEpi& ep, int how, int split, int I, int J, int i, int j, floatx4 v) {
+  if (i >= I || j >= J) return;
+  if (how == TN_OUT_SLAB) {                       // dense [split][I][J]; J % 4 == 0
+    *(floatx4*)(ep.slab + ((int64_t)split * I + i) * J + j) = v;
+    return;
+  }
+  v *= ep.alpha;
+  if (how == TN_OUT_DIRECT && ep.mode == TN_PLAIN && (ep.ldo & 3) == 0) {
+    floatx4* o = (floatx4*)(ep.out + (int64_t)i * ep.ldo + j);
+    *o = *o + v;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t idx = tn_out_index(ep, i, j + r);
+    if (idx < 0) continue;
+    if (how == TN_OUT_DIRECT) ep.out[idx] += v[r];
+    else atomicAdd(ep.out + idx, v[r]);
+  }
+}
+
+
 }  // namespace rl

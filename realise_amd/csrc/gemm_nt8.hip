@@ -30,8 +30,10 @@ template <int... Is> struct SeqGen<0, Is...> {
 };
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { SeqGen<N>::run(f); }
 
-template <int BM_, int BN_, int WM_, int WN_, bool HOLD_B_, int SQ_, int NS_, int LEAD_, int ISSUE_AT_ = 0>
+template <int BM_, int BN_, int WM_, int WN_, bool HOLD_B_, int SQ_, int NS_, int LEAD_, int ISSUE_AT_ = 0, int FW_ = 8, int WGS_ = 1>
 struct Nt8Cfg {
+  static constexpr int WGS = WGS_;               // workgroups meant to share a CU (2: <= 80 KB of LDS and <= 128 VGPRs each)
+  static constexpr int FW = FW_;                 // waves that issue the fetches: all 8 (they also multiply), or 4 dedicated loader waves
   // where a phase issues its fetches: 0 end of the memory segment (after the fragment reads), 1 between the MFMAs, 2 head of the
   // memory segment (the texture-address unit serialises the 4 waves' 1-KiB requests, ~29 clk each: issuing them FIRST lets that
   // queueing run under the fragment reads instead of after them)
@@ -42,15 +44,16 @@ struct Nt8Cfg {
   static constexpr int RM = BM / WM, RN = BN / WN, MT = RM / 16, NT = RN / 16;        // per-wave tile, in rows / 16x16 tiles
   static constexpr int HT = HOLD_B ? NT : MT, ST = HOLD_B ? MT : NT, NPH = ST / SQ;   // held / streamed tiles, phases per K-tile
   static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-  static constexpr int NP = (BM + BN) / 8, NPW = NP / 8;                               // 1-KiB pieces per K-tile, per wave
-  static constexpr int HP = (HOLD_B ? BN : BM) / 8, HPW = HP / 8;                      // pieces of the held operand
+  static constexpr int NP = (BM + BN) / 8, NPW = NP / FW;                              // 1-KiB pieces per K-tile, per fetching wave
+  static constexpr int HP = (HOLD_B ? BN : BM) / 8, HPW = HP / FW;                     // pieces of the held operand
   static constexpr int SW = HOLD_B ? WM : WN, SR = HOLD_B ? RM : RN;                   // wave slices of the streamed operand
-  static constexpr int GP = SW * SQ * 2, GPW = GP / 8;                                 // pieces of one streamed group
+  static constexpr int GP = SW * SQ * 2, GPW = GP / FW;                                // pieces of one streamed group
   static_assert(WM * WN == 8, "8 waves");
   static_assert(RM % 16 == 0 && RN % 16 == 0 && ST % SQ == 0, "wave tile");
-  static_assert((BM + BN) % 64 == 0 && HP % 8 == 0 && GP % 8 == 0, "pieces must split evenly over the 8 waves");
+  static_assert(NP % FW == 0 && HP % FW == 0 && GP % FW == 0, "pieces must split evenly over the fetching waves");
   static_assert(HPW + NPH * GPW == NPW, "piece census");
-  static_assert(NS * STAGE <= 160 * 1024, "LDS");
+  static constexpr int LDS_CAP = 160 * 1024 / WGS;
+  static_assert(NS * STAGE <= LDS_CAP, "LDS");
   // local issue slot of a wave's s-th piece of a tile, the phase that first reads it, the last piece phase q needs
   static constexpr int cum(int q) { return (q * NPW + NPH - 1) / NPH; }
   static constexpr int qissue(int s) { int q = 0; while (cum(q + 1) <= s) ++q; return q; }
@@ -85,14 +88,17 @@ struct Nt8Cfg {
   static_assert(VM_PRO >= 0, "prologue");
   // epilogue: per-wave fp32 transpose tile of ER rows x (RN + 4) floats inside the ring
   static constexpr int RS = RN + 4;
-  static constexpr int er_fit() { int er = RM; while (er > 16 && 8 * er * RS * 4 > 160 * 1024) er >>= 1; return er; }
+  static constexpr int er_fit() { int er = RM; while (er > 16 && 8 * er * RS * 4 > LDS_CAP) er >>= 1; return er; }
   static constexpr int ER = er_fit();
   static_assert((ER * RN / 8) % 64 == 0, "epilogue items per wave");
   static constexpr int LDS = (NS * STAGE > 8 * ER * RS * 4) ? NS * STAGE : 8 * ER * RS * 4;
 };
 
+static int g_nt8_probe = 0;
+void set_nt8_probe(int mode) { g_nt8_probe = mode; }
+
 template <typename C, int PROBE, bool KTAIL = false>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512, 2 * C::WGS)
 gemm_nt8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int M, int N, int K, int tiles_n,
                 int ntiles, EpiParams<bf16_t> ep) {
   typedef bf16_t T;
@@ -264,8 +270,6 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
   }
 }
 
-static int g_nt8_probe = 0;
-void set_nt8_probe(int mode) { g_nt8_probe = mode; }
 
 template <typename C, bool KTAIL = false>
 static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
@@ -289,6 +293,227 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
+
+// =================================================================================================
+// Warp-specialised form: 8 consumer waves + 4 LOADER waves (768 threads, 3 waves per SIMD, <= 168 VGPRs).
+// tools/clock_probe.cpp measured why: a wave that both fetches and multiplies serialises the two in its in-order stream (LDS-DMA
+// issue back-pressure and the vmcnt waits sit between its MFMAs; the 8-wave kernel's K-tile time is the SUM of its fetch-only and
+// MFMA-only times), while MFMA waves next to dedicated fetch waves run both at once: 1510 TF + 45 B/clk/CU of fill on the same
+// CUs against 1675 TF / 43 B/clk alone.  The consumers keep the two-group ping-pong (fragment reads of one group under the MFMAs of
+// the other); the loaders walk the same phase sequence as group 0 with nothing but the phase's fetches and the counted wait in it,
+// so the RAW / WAR phase rules of the schedule above hold unchanged (the loader's wait + barrier precede every read).
+// =================================================================================================
+// The loader role of the warp-specialised kernel (a separate __device__ function: as in-kernel generic lambdas next to the consumer's
+// the host pass of hipcc 7.2 silently failed to instantiate the kernel stub).
+template <typename C, int PROBE>
+__device__ __forceinline__ void nt8ws_loader(char* smem, const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb,
+                                             int M, int N, int K, int m0, int n0, int nk, int lw, int lane) {
+  constexpr int NPW = C::NPW, NPH = C::NPH, NS = C::NS, LEAD = C::LEAD, SQ = C::SQ;
+  const int lrow = lane >> 3;
+  const int kchunk_b = (((lane & 7) ^ lrow) << 4);
+  int lo[NPW];
+  uint32_t go[NPW];
+#pragma unroll
+  for (int s = 0; s < NPW; ++s) {
+    const int p = s * 4 + lw;
+    int row, is_b;
+    if (s < C::HPW) { row = p * 8; is_b = C::HOLD_B ? 1 : 0; }
+    else {
+      const int pp = p - C::HP, q = pp / C::GP, rem = pp - q * C::GP, slice = rem / (SQ * 2), j = rem - slice * (SQ * 2);
+      row = slice * C::SR + q * SQ * 16 + j * 8; is_b = C::HOLD_B ? 0 : 1;
+    }
+    lo[s] = (is_b ? C::A_BYTES : 0) + row * 128;
+    const int grow = is_b ? min(n0 + row + lrow, N - 1) : min(m0 + row + lrow, M - 1);
+    go[s] = (uint32_t)((int64_t)grow * (is_b ? ldb : lda) * 2 + kchunk_b);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((int64_t)(M - 1) * lda + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(((int64_t)(N - 1) * ldb + K) * 2), 0x00020000);
+  auto issue = [&](auto s_c, int stage, int ktile) {
+    constexpr int s = decltype(s_c)::value;
+    if constexpr (PROBE == 2) return;
+    constexpr bool is_b = (s < C::HPW) ? C::HOLD_B : !C::HOLD_B;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_b ? rsB : rsA, (__attribute__((address_space(3))) void*)(smem + stage * C::STAGE + lo[s]), 16,
+                                             go[s], ktile * 128, 0, 0);
+  };
+  static_for<C::PRO_TILES>([&](auto dt_c) {
+    constexpr int dt = decltype(dt_c)::value;
+    if (dt < nk) {
+      static_for<NPW>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        if constexpr (C::in_prologue(dt, s)) issue(s_c, dt % NS, dt);
+      });
+    }
+  });
+  if (nk >= C::PRO_TILES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::VM_PRO) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  auto lphase = [&](auto par_c, auto q_c, int t) {
+    constexpr int PAR = decltype(par_c)::value, q = decltype(q_c)::value;
+    constexpr int dt2 = (q + LEAD) / NPH, q2 = (q + LEAD) % NPH;
+    if (t + dt2 < nk) {
+      static_for<NPW>([&](auto s_c) {
+        constexpr int s = decltype(s_c)::value;
+        if constexpr (s >= C::cum(q2) && s < C::cum(q2 + 1)) issue(s_c, (PAR + dt2) % NS, t + dt2);
+      });
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::vm(q)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  for (int tb = 0; tb < nk; tb += NS) {
+    static_for<NS>([&](auto par_c) {
+      constexpr int PAR = decltype(par_c)::value;
+      if (tb + PAR < nk) static_for<NPH>([&](auto q_c) { lphase(par_c, q_c, tb + PAR); });
+    });
+  }
+  __builtin_amdgcn_s_barrier();            // barrier census of consumer group 0
+}
+
+template <typename C, int PROBE>
+__global__ void __launch_bounds__(768)
+gemm_nt8ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int M, int N, int K, int tiles_n,
+                  int ntiles, EpiParams<bf16_t> ep) {
+  typedef bf16_t T;
+  typedef MmaBF16 Mma;
+  static_assert(C::FW == 4 && C::ISSUE_AT == 0, "loader-wave configuration");
+  constexpr int NPW = C::NPW, NPH = C::NPH, NS = C::NS, LEAD = C::LEAD, SQ = C::SQ, HT = C::HT, MT = C::MT, NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * C::BM, n0 = tn * C::BN;
+  const int nk = K >> 6;
+
+  if (wave >= 8) {          // loader wave
+    nt8ws_loader<C, PROBE>(smem, A, lda, B, ldb, M, N, K, m0, n0, nk, wave - 8, lane);
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------- consumer wave
+  const int g = lane >> 4, l15 = lane & 15;
+  const int grp = wave >> 2;
+  const int wm = wave / C::WN, wn = wave - wm * C::WN;
+  int fa[2], fb[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int lane_sw = l15 * 128 + ((((ks << 2) + g) ^ (l15 & 7)) << 4);
+    fa[ks] = wm * C::RM * 128 + lane_sw;
+    fb[ks] = C::A_BYTES + wn * C::RN * 128 + lane_sw;
+  }
+  floatx4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t hf[HT][2], sf[SQ][2];
+  if constexpr (PROBE == 4) {                // fetch + MFMA without the fragment reads: registers hold zeros
+#pragma unroll
+    for (int h = 0; h < HT; ++h) { hf[h][0] = bf16x8_t{}; hf[h][1] = bf16x8_t{}; }
+#pragma unroll
+    for (int i = 0; i < SQ; ++i) { sf[i][0] = bf16x8_t{}; sf[i][1] = bf16x8_t{}; }
+  }
+  __builtin_amdgcn_s_barrier();              // tile 0 landed (the loaders waited for it)
+  asm volatile("" ::: "memory");
+  if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }     // group 1 runs half a phase behind
+
+  auto phase = [&](auto par_c, auto q_c) {
+    constexpr int PAR = decltype(par_c)::value, q = decltype(q_c)::value, SBASE = PAR * C::STAGE;
+    if constexpr (PROBE != 3 && PROBE != 4) {
+      if constexpr (q == 0) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+            hf[h][ks] = *(const bf16x8_t*)(smem + SBASE + h * 2048 + (C::HOLD_B ? fb[ks] : fa[ks]));
+      }
+#pragma unroll
+      for (int i = 0; i < SQ; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          sf[i][ks] = *(const bf16x8_t*)(smem + SBASE + (q * SQ + i) * 2048 + (C::HOLD_B ? fa[ks] : fb[ks]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PROBE == 5) {                // fetch + fragment reads without the MFMAs
+#pragma unroll
+      for (int i = 0; i < SQ; ++i) { asm volatile("" ::"v"(sf[i][0]), "v"(sf[i][1])); }
+      if constexpr (q == 0) {
+#pragma unroll
+        for (int h = 0; h < HT; ++h) asm volatile("" ::"v"(hf[h][0]), "v"(hf[h][1]));
+      }
+    }
+    if constexpr (PROBE != 3 && PROBE != 5) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < SQ; ++i)
+#pragma unroll
+          for (int h = 0; h < HT; ++h) {
+            if constexpr (C::HOLD_B) acc[q * SQ + i][h] = Mma::mma(hf[h][ks], sf[i][ks], acc[q * SQ + i][h]);
+            else acc[h][q * SQ + i] = Mma::mma(sf[i][ks], hf[h][ks], acc[h][q * SQ + i]);
+          }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int tb = 0; tb < nk; tb += NS) {
+    static_for<NS>([&](auto par_c) {
+      constexpr int PAR = decltype(par_c)::value;
+      if (tb + PAR < nk) static_for<NPH>([&](auto q_c) { phase(par_c, q_c); });
+    });
+  }
+  if (grp == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+
+  constexpr int RS = C::RS, ER = C::ER, ITEMS = C::RN / 8, NIT = ER * ITEMS / 64;
+  float* et = (float*)smem + wave * (ER * RS);
+  const int row_w = m0 + wm * C::RM, col_w = n0 + wn * C::RN;
+#pragma unroll
+  for (int c = 0; c < C::RM / ER; ++c) {
+#pragma unroll
+    for (int i = 0; i < ER / 16; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) *(floatx4*)(et + (i * 16 + l15) * RS + j * 16 + 4 * g) = acc[c * (ER / 16) + i][j];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = lane + 64 * it, r = e / ITEMS, c8 = e - r * ITEMS;
+      const floatx4 v0 = *(const floatx4*)(et + r * RS + c8 * 8), v1 = *(const floatx4*)(et + r * RS + c8 * 8 + 4);
+      epilogue8<T>(ep, M, N, row_w + c * ER + r, col_w + c8 * 8, v0, v1);
+    }
+  }
+}
+
+template <typename C>
+static int launch_nt8ws_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
+                            const EpiParams<bf16_t>& ep) {
+  const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (N + C::BN - 1) / C::BN, ntiles = tiles_m * tiles_n;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt8ws_kernel<C, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt8ws_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt8ws_kernel<C, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt8ws_kernel<C, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt8ws_kernel<C, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    attr_set = true;
+  }
+  ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
+  if (g_nt8_probe == 2) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 2>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
+  else if (g_nt8_probe == 3) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 3>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
+  else if (g_nt8_probe == 4) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 4>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
+  else if (g_nt8_probe == 5) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 5>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
+  else hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 0>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
+  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+}
+
 //             BM   BN  WM WN hold_B SQ NS LEAD issue_in_MFMA_segment
 typedef Nt8Cfg<256, 256, 2, 4, true, 2, 2, 5> Cfg256x256;      // wave 128 x 64, 4 phases of 16 MFMAs
 typedef Nt8Cfg<256, 192, 4, 2, false, 2, 2, 4> Cfg256x192;     // wave  64 x 96, 3 phases of 16 MFMAs
@@ -302,6 +527,11 @@ typedef Nt8Cfg<256, 256, 2, 4, true, 2, 2, 5, 2> Cfg256x256f;
 typedef Nt8Cfg<256, 192, 4, 2, false, 2, 2, 4, 2> Cfg256x192f;
 typedef Nt8Cfg<256, 128, 4, 2, true, 2, 3, 4, 2> Cfg256x128f;
 typedef Nt8Cfg<128, 192, 2, 4, true, 2, 3, 4, 2> Cfg128x192f;
+typedef Nt8Cfg<128, 192, 2, 4, true, 2, 2, 2, 0, 8, 2> Cfg128x192p;       // two workgroups per CU (80 KB each): one's epilogue and fetch
+typedef Nt8Cfg<128, 192, 4, 2, false, 2, 2, 4, 0, 8, 2> Cfg128x192q;      //   waits run under the other's MFMAs
+typedef Nt8Cfg<256, 192, 4, 2, false, 2, 2, 4, 0, 4> Cfg256x192w;     // 8 consumer + 4 loader waves
+typedef Nt8Cfg<256, 128, 4, 2, true, 2, 3, 4, 0, 4> Cfg256x128w;
+typedef Nt8Cfg<128, 192, 2, 4, true, 2, 3, 4, 0, 4> Cfg128x192w;
 
 bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb) {
   return (K % 8) == 0 && K >= 64 && (N % 8) == 0 && (ep.ldo % 8) == 0 && (ep.aux == nullptr || (ep.ldaux % 8) == 0) &&
@@ -309,16 +539,25 @@ bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda
          (int64_t)M * lda * 2 < 0xFFFFFF00ll && (int64_t)N * ldb * 2 < 0xFFFFFF00ll;
 }
 
-// tile: 0 = heuristic, 1 = 256x256, 2 = 256x192, 3 = 256x128, 4 = 128x192; +10: fetches issued inside the MFMA segments
+// tile: 0 = heuristic, 1 = 256x256, 2 = 256x192, 3 = 256x128, 4 = 128x192, 5 / 6 = 128x192 two workgroups per CU;
+// +10: fetches issued inside the MFMA segments; 32..34: loader-wave kernels
 int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
              const EpiParams<bf16_t>& ep, int tile) {
   if (!nt8_supported(M, N, K, ep, lda, ldb)) return RL_ERR_ARG;
   if (K % 64) return launch_nt8_cfg<Cfg128x192, true>(st, A, lda, B, ldb, M, N, K, ep);     // ragged K: one tile shape carries the tail code
   const int flavour = (tile / 10) * 10;      // 10..14: fetches issued between the MFMAs; 20..24: at the head of the memory segment
   tile -= flavour;
+  if (tile == 0 && N < 4096) {
+    // outputs up to a few thousand columns: the two-workgroups-per-CU shape.  Its smaller tile fetches 43 % more bytes per flop
+    // than 256x192, but the second workgroup's MFMAs run under the first one's output write (a third of a K = 768 GEMM's time with
+    // one workgroup per CU) and under its fetch waits: qkv 39.6 -> 35.0 us, ffn1+GELU 56.1 -> 51.3, attn-out 14.6 -> 14.3, the
+    // K = 2304 / 3072 shapes equal (tools/nt8_probe.cpp ws, profiles/round2_nt8_probe.log)
+    tile = 6;
+  }
   if (tile == 0) {
     // chip fill: rounds of 256 one-per-CU workgroups; among the shapes pick the least (rounds x MFMA time of one tile), ties to
-    // the larger tile (fewer fetched bytes per flop)
+    // the larger tile (fewer fetched bytes per flop).  The classifier (N = 21128) lands on 256x192: 303 us against 340 for the
+    // two-per-CU shape, which is fetch-bound there.
     struct Cand { int id, bm, bn; } cands[4] = {{1, 256, 256}, {2, 256, 192}, {3, 256, 128}, {4, 128, 192}};
     double best = 1e30;
     for (const Cand& c : cands) {
@@ -342,6 +581,11 @@ int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int6
     case 22: return launch_nt8_cfg<Cfg256x192f>(st, A, lda, B, ldb, M, N, K, ep);
     case 23: return launch_nt8_cfg<Cfg256x128f>(st, A, lda, B, ldb, M, N, K, ep);
     case 24: return launch_nt8_cfg<Cfg128x192f>(st, A, lda, B, ldb, M, N, K, ep);
+    case 5: return launch_nt8_cfg<Cfg128x192p>(st, A, lda, B, ldb, M, N, K, ep);
+    case 6: return launch_nt8_cfg<Cfg128x192q>(st, A, lda, B, ldb, M, N, K, ep);
+    case 32: return launch_nt8ws_cfg<Cfg256x192w>(st, A, lda, B, ldb, M, N, K, ep);
+    case 33: return launch_nt8ws_cfg<Cfg256x128w>(st, A, lda, B, ldb, M, N, K, ep);
+    case 34: return launch_nt8ws_cfg<Cfg128x192w>(st, A, lda, B, ldb, M, N, K, ep);
     default: return RL_ERR_ARG;
   }
 }

@@ -76,7 +76,9 @@ int main(int argc, char** argv) {
     return bad;
   };
   size_t total_bad = 0;
-  const int vars[] = {11, 12, 13, 14};
+  const bool ws = argc > 3 && !strcmp(argv[3], "ws");
+  std::vector<int> vars = {11, 12, 13, 14};
+  if (ws) vars = {15, 16};
   for (int v : vars) {
     for (const Shape& sh : odd) total_bad += compare(sh, 0, v);
     total_bad += compare(shapes[2], 0, v);
@@ -93,15 +95,16 @@ int main(int argc, char** argv) {
   printf("TOTAL mismatches: %zu\n", total_bad);
   fflush(stdout);
 
-  const int tv[] = {9, 0, 11, 12, 13, 14};
+  std::vector<int> tv = {9, 0, 11, 12, 13, 14};
+  if (ws) tv = {12, 14, 15, 16};
   for (const Shape& sh : shapes) {
     for (int v : tv) {
       if (quick && v > 10) continue;
-      if (sh.N > 3072 && (v % 10 == 3 || v % 10 == 4)) continue;
+      if (sh.N > 3072 && (v % 10 == 3 || v % 10 == 4) && !ws) continue;
       variant(v);
       printf("v%-2d %5d x %5d x %5d %-22s", v, sh.M, sh.N, sh.K, sh.what);
       const int reps = sh.N > 3072 || sh.K > 3072 ? 5 : 20;
-      for (int mode : {0, 2, 3}) {
+      for (int mode : (ws && v >= 40) ? std::vector<int>{0, 2, 3, 4, 5} : std::vector<int>{0, 2, 3}) {
         probe(mode);
         const double us = time_us(sh, 0, reps);
         printf(" | m%d %7.1f us %5.0f TF", mode, us, 2.0 * sh.M * sh.N * sh.K / us * 1e-6);
@@ -116,7 +119,7 @@ int main(int argc, char** argv) {
     }
   }
   probe(0);
-  for (int v : {9, 0}) {   // sustained: the four forward GEMMs of a layer, cycling through 19 weight sets
+  for (int v : ws ? std::vector<int>{0, 15, 16} : std::vector<int>{9, 0}) {   // sustained: the four forward GEMMs of a layer, cycling through 19 weight sets
     variant(v);
     uint16_t* W; const size_t wl = (size_t)(2304 + 768 + 3072 + 3072) * 768;
     hipMalloc(&W, wl * 19 * 2); hipMemcpy(W, B, wl * 2, hipMemcpyDeviceToDevice);
