@@ -64,6 +64,19 @@ int realise_conv_nt(void* stream, int dtype, const realise_conv_geom* a, const v
 int realise_gemm_tn(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
                     int P, int I, int J, float* out, int64_t ldo, float* scratch, int64_t scratch_elems,
                     float* colsum_out /* nullable: colsum_out[i] += sum_p A[p,i], the matching bias gradient */);
+/* Up to 4 Linear weight gradients that share the token count P in ONE launch (the four Linear layers of a transformer
+ * layer: BertSelfAttention q/k/v packed, BertSelfOutput.dense, BertIntermediate.dense, BertOutput.dense,
+ * modeling_bert.py:221-232,273,326,339 under loss.backward(), run.py:200): every workgroup owns one 128x128 tile of one
+ * problem over the whole reduction, so there is no reduction split, no scratch and no fold pass.
+ * out_k[I_k, J_k] += A_k^T B_k, colsum_k[i] += sum_p A_k[p,i] (nullable).  ldo % 4 == 0. */
+typedef struct realise_tn_problem {
+  const void* A; int64_t lda;      /* dY [P, I] */
+  const void* B; int64_t ldb;      /* X  [P, J] */
+  int32_t I, J;
+  float* out; int64_t ldo;
+  float* colsum;
+} realise_tn_problem;
+int realise_gemm_tn_grouped(void* stream, int dtype, int n, const realise_tn_problem* problems, int P);
 /* Conv2d weight gradient into the reference's [Co][Ci][KH][KW] layout. */
 int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const realise_conv_geom* b,
                     int P, int Co, int Ci, float* out, float* scratch, int64_t scratch_elems);
@@ -98,6 +111,7 @@ void realise_set_wgrad_overlap(int on);
  * (src/models.py:816 bert | :818-827 pinyin GRU + pho_model | :829-838 glyph ResNet), and their backward passes behind the
  * gate, run on three HIP streams (the caller's + two engine-owned), forked / joined with events inside the engine call; the
  * caller's stream owns every result when the call returns.  0: everything in order on the caller's stream.  Identical results. */
+void realise_set_wgrad_group(int on);      /* 1 (default): the four weight gradients of a transformer layer as one grouped launch */
 void realise_set_branch_overlap(int on);
 
 /* BertSelfAttention core (modeling_bert.py:239-260): softmax(QK^T/8 + mask_add) -> dropout -> .V

@@ -25,6 +25,11 @@ class ConvGeom(C.Structure):
                [(n, C.c_int32) for n in ("rows", "Hr", "Wr", "Hs", "Ws", "C", "KH", "KW", "stride", "pad", "mode")]
 
 
+class TnProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("I", C.c_int32), ("J", C.c_int32),
+                ("out", C.c_void_p), ("ldo", C.c_int64), ("colsum", C.c_void_p)]
+
+
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("model_type", "dtype", "hidden", "heads", "intermediate", "vocab", "max_pos",
                                          "type_vocab", "bert_layers", "pho_layers", "out_layers", "num_fonts",
@@ -49,6 +54,7 @@ SYMBOLS = {
     "realise_gemm_nt": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
     "realise_conv_nt": (_I, [_P, _I, C.POINTER(ConvGeom), _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
     "realise_gemm_tn": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, _P, _L, _P, _L, _P]),
+    "realise_gemm_tn_grouped": (_I, [_P, _I, _I, C.POINTER(TnProblem), _I]),
     "realise_conv_tn": (_I, [_P, _I, _P, _L, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _L]),
     "realise_set_tn_transpose_read": (None, [_I]),
     "realise_set_nt_allow_n96": (None, [_I]),
@@ -62,6 +68,7 @@ SYMBOLS = {
     "realise_set_nt_wide_epilogue": (None, [_I]),
     "realise_set_glyph_dedup": (None, [_I]),
     "realise_set_wgrad_overlap": (None, [_I]),
+    "realise_set_wgrad_group": (None, [_I]),
     "realise_attention_fwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _U, _U, _F]),
     "realise_attention_bwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _U, _U, _F]),
     "realise_mask_to_additive": (_I, [_P, _P, _P, _I]),
@@ -124,7 +131,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # A/B knobs for measurements (defaults are the production settings)
-    for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup),
+    for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_WGRAD_GROUP", lib.realise_set_wgrad_group), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup),
                     ("REALISE_NT_VARIANT", lib.realise_set_nt_variant)):
         if os.environ.get(env) is not None:
             fn(int(os.environ[env]))

@@ -31,6 +31,17 @@ template <typename T> ConvLoader<T> to_geom(const realise_conv_geom* g) {
 }
 }  // namespace
 
+template <typename T>
+static int tn_grouped(hipStream_t st, int n, const realise_tn_problem* pr, int P) {
+  if (n < 1 || n > TN_GROUP_MAX || pr == nullptr) return RL_ERR_ARG;
+  TnGroupProblem<T> g[TN_GROUP_MAX];
+  for (int k = 0; k < n; ++k) {
+    g[k].A = (const T*)pr[k].A; g[k].lda = pr[k].lda; g[k].B = (const T*)pr[k].B; g[k].ldb = pr[k].ldb;
+    g[k].I = pr[k].I; g[k].J = pr[k].J; g[k].out = pr[k].out; g[k].ldo = pr[k].ldo; g[k].colsum = pr[k].colsum;
+  }
+  return gemm_tn_group<T>(st, n, g, P);
+}
+
 extern "C" {
 
 const char* realise_version(void) { return "realise_hip 0.1 (gfx950)"; }
@@ -59,6 +70,12 @@ int realise_gemm_tn(void* stream, int dtype, const void* A, int64_t lda, const v
   if (dtype == REALISE_F32) return gemm_tn<float>(st, (const float*)A, lda, (const float*)B, ldb, P, I, J, te);
   return RL_ERR_ARG;
 }
+int realise_gemm_tn_grouped(void* stream, int dtype, int n, const realise_tn_problem* problems, int P) {
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == REALISE_BF16) return tn_grouped<bf16_t>(st, n, problems, P);
+  if (dtype == REALISE_F32) return tn_grouped<float>(st, n, problems, P);
+  return RL_ERR_ARG;
+}
 int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const realise_conv_geom* b, int P, int Co, int Ci,
                     float* out, float* scratch, int64_t scratch_elems) {
   hipStream_t st = (hipStream_t)stream;
@@ -77,6 +94,7 @@ void realise_set_nt_variant(int v) { set_nt_variant(v); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }
 void realise_set_tn_split(int n) { set_tn_split(n); }
+void realise_set_wgrad_group(int on) { set_wgrad_group(on); }
 void realise_set_tn_variant(int v) { set_tn_variant(v); }
 void realise_set_nt_wide_epilogue(int on) { set_nt_wide_epilogue(on); }
 void realise_set_glyph_dedup(int on) { set_glyph_dedup(on); }

@@ -24,6 +24,11 @@ namespace rl {
 // switches both overlaps off on the steps whose launches it brackets with events.
 static int g_wgrad_overlap = 1;
 void set_wgrad_overlap(int on) { g_wgrad_overlap = on; }
+// Grouped weight gradients (default on): the four wgrad GEMMs of a transformer layer go out as ONE launch of 432 tiles with no
+// reduction split (gemm_tn_group) once the layer's last dY exists, instead of four launches that each split the reduction 3-4 ways
+// and fold the slabs afterwards.
+static int g_wgrad_group = 1;
+void set_wgrad_group(int on) { g_wgrad_group = on; }
 // Branch overlap (default on): the three branches of SpellBertPho2ResArch3 that are independent between the inputs and the gate
 // (models.py:816 bert, :818-827 pinyin GRU + pho_model, :829-838 glyph ResNet) - and their backward passes after the gate -
 // run on three HIP streams (the caller's + two engine-owned ones), forked and joined with events inside one engine call.  The
@@ -497,7 +502,14 @@ template <typename T> struct Engine : EngineBase {
         if (hipStreamWaitEvent(st, ev_done[p], 0) != hipSuccess) return RL_ERR_LAUNCH;
         done_pending[p] = false;
       }
+      const bool grouped = g_wgrad_group != 0;
+      TnGroupProblem<T> gp4[4];
       auto wgrad = [&](int k, const T* dy, int64_t ldy, const T* x, int64_t ldx, int Iw, int Jw, float* bias_g, float* w_g) -> int {
+        if (grouped) {        // collected; launched once after the attention backward produced the last dY
+          gp4[k].A = dy; gp4[k].lda = ldy; gp4[k].B = x; gp4[k].ldb = ldx; gp4[k].I = Iw; gp4[k].J = Jw; gp4[k].out = w_g; gp4[k].ldo = Jw;
+          gp4[k].colsum = bias_g;
+          return RL_OK;
+        }
         hipStream_t ws_ = st;
         TnEpi te; te.slab = wp<float>(sc.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = bias_g; te.out = w_g; te.ldo = Jw;
         if (ov) {
@@ -506,13 +518,14 @@ template <typename T> struct Engine : EngineBase {
         }
         return gemm_tn<T>(ws_, dy, ldy, x, ldx, Tk, Iw, Jw, te);
       };
+      const bool keep_dy = ov || grouped;      // the dense-output gradients must outlive the in-place updates of gA / gB
       {  // output LayerNorm: gA = d y2 -> gB = d s2 (residual part of d y1), gC1 = d(dense out) = d s2 * dropmask
         LnBwdArgs<T> ln; ln.slots = wp<float>(sc.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
-        ln.gamma = pp(o.out_ln_g); ln.dx = gB; ln.dx_drop = (d3.thresh || ov) ? gC1 : nullptr; ln.out_drop = d3;
+        ln.gamma = pp(o.out_ln_g); ln.dx = gB; ln.dx_drop = (d3.thresh || keep_dy) ? gC1 : nullptr; ln.out_drop = d3;
         ln.dgamma = gp(o.out_ln_g); ln.dbeta = gp(o.out_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
       }
-      const T* dso = (d3.thresh || ov) ? gC1 : gB;
+      const T* dso = (d3.thresh || keep_dy) ? gC1 : gB;
       RL_TRY(wgrad(0, dso, H, wp<T>(t.post), I, H, I, gp(o.out_b), gp(o.out_w)));
       {  // d pre = (d s2' . W_out) * gelu'(pre)
         EpiParams<T> ep; ep.mode = EPI_GELU_BWD; ep.out = gD; ep.ldo = I; ep.aux = wp<T>(t.pre); ep.ldaux = I;
@@ -525,11 +538,11 @@ template <typename T> struct Engine : EngineBase {
       }
       {  // attention-output LayerNorm: gB = d y1 -> gA = d s1, gC2 = d(dense out)
         LnBwdArgs<T> ln; ln.slots = wp<float>(sc.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
-        ln.gamma = pp(o.ao_ln_g); ln.dx = gA; ln.dx_drop = (d2.thresh || ov) ? gC2 : nullptr; ln.out_drop = d2;
+        ln.gamma = pp(o.ao_ln_g); ln.dx = gA; ln.dx_drop = (d2.thresh || keep_dy) ? gC2 : nullptr; ln.out_drop = d2;
         ln.dgamma = gp(o.ao_ln_g); ln.dbeta = gp(o.ao_ln_b);
         RL_TRY(ln_bwd<T>(st, ln));
       }
-      const T* dsa = (d2.thresh || ov) ? gC2 : gA;
+      const T* dsa = (d2.thresh || keep_dy) ? gC2 : gA;
       RL_TRY(wgrad(2, dsa, H, wp<T>(t.ctx), H, H, H, gp(o.ao_b), gp(o.ao_w)));
       {  // d ctx = d s1' . W_ao
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gE; ep.ldo = H;
@@ -541,6 +554,14 @@ template <typename T> struct Engine : EngineBase {
                            wp<float>(sc.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale));
       }
       RL_TRY(wgrad(3, gF, 3 * H, x_in, H, 3 * H, H, gp(o.qkv_b), gp(o.qkv_w)));
+      if (grouped) {
+        hipStream_t ws_ = st;
+        if (ov) {
+          if (hipEventRecord(ev_ready[p][3], st) != hipSuccess || hipStreamWaitEvent(side, ev_ready[p][3], 0) != hipSuccess) return RL_ERR_LAUNCH;
+          ws_ = side;
+        }
+        RL_TRY(gemm_tn_group<T>(ws_, 4, gp4, Tk));
+      }
       {  // d x_in = d s1 + d qkv . W_qkv
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, gF, 3 * H, sp<T>(w.qkv_wT), 3 * H, Tk, H, 3 * H, ep));

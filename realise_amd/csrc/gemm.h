@@ -207,6 +207,24 @@ struct TnEpi {
   int probe = 0;            // diagnostics (tools/nt_probe.cpp): 2 no fetches, 3 no MFMA, 4 no fold pass
 };
 
+// Grouped TN (weight-gradient) launch: problems sharing the reduction length P, one 128x128 tile per workgroup, no reduction split.
+constexpr int TN_GROUP_MAX = 4;
+template <typename T> struct TnGroupProblem {
+  const T* A = nullptr; int64_t lda = 0;        // dY [P, I]
+  const T* B = nullptr; int64_t ldb = 0;        // X  [P, J]
+  int I = 0, J = 0;
+  float* out = nullptr; int64_t ldo = 0;        // fp32 [I, ldo], accumulated; ldo % 4 == 0
+  float* colsum = nullptr;                      // nullable: += column sums of A (bias gradient)
+  int tiles_j = 0, ntiles = 0, tile_begin = 0;  // filled by gemm_tn_group
+};
+template <typename T> struct TnGroup {
+  TnGroupProblem<T> p[TN_GROUP_MAX];
+  int n = 0, total_tiles = 0, probe = 0;
+  float alpha = 1.0f;
+};
+template <typename T>
+int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha = 1.0f);
+
 // C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)
 template <typename T>
 int gemm_nt(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K,

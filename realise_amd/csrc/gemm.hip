@@ -508,10 +508,10 @@ template <typename T, int NB> struct ConvTaps<ConvLoader<T>, NB> {
   }
 };
 
+// One (split, tile) of a TN problem; `logical` = split * ntiles + tile.
 template <typename T, typename BLoader, bool TR, int WI, int WJ>
-__global__ void __launch_bounds__(256, 2)
-gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, int J, int tiles_j, int ntiles,
-               int nsplit, int pchunk, int how, TnEpi ep) {
+__device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, int J, int tiles_j, int ntiles,
+                                             int nsplit, int pchunk, int how, TnEpi ep, int logical) {
   typedef typename MmaOf<T>::type Mma;
   typedef TnGeo<T> G;
   constexpr int BI = 64 * WI, BJ = 64 * WJ;
@@ -522,9 +522,6 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave / WJ, wj = wave - wi * WJ;
-  // 1-D grid of (split, tile) pairs: the XCD remap hands each XCD a contiguous run of them, so the tiles of one
-  // reduction split (which share A / B row panels) sit behind one L2.
-  const int logical = xcd_remap(blockIdx.x, ntiles * nsplit);
   const int split = logical / ntiles, tile = logical - split * ntiles;
   const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
   const int i0 = ti * BI, j0 = tj * BJ;
@@ -677,6 +674,34 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
   }
 }
 
+template <typename T, typename BLoader, bool TR, int WI, int WJ>
+__global__ void __launch_bounds__(256, 2)
+gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, int J, int tiles_j, int ntiles,
+               int nsplit, int pchunk, int how, TnEpi ep) {
+  // 1-D grid of (split, tile) pairs: the XCD remap hands each XCD a contiguous run of them, so the tiles of one
+  // reduction split (which share A / B row panels) sit behind one L2.
+  tn_tile_body<T, BLoader, TR, WI, WJ>(A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep, xcd_remap(blockIdx.x, ntiles * nsplit));
+}
+
+// Grouped form: up to TN_GROUP_MAX dense problems that share the reduction length P in ONE launch, each workgroup owning one
+// 128x128 tile of one problem over the whole reduction (no split: nothing to fold).  The four weight gradients of a transformer
+// layer are 432 such tiles - one round of the chip's 512 workgroup slots - where launched one by one each needs a 3-4 way
+// reduction split (slab write + fold pass) to fill the chip: 8 launches and ~75 MB of slab traffic per layer become 1 launch.
+template <typename T, bool TR>
+__global__ void __launch_bounds__(256, 2)
+gemm_tn_group_kernel(TnGroup<T> grp, int P, int pchunk) {
+  const int logical = xcd_remap(blockIdx.x, grp.total_tiles);
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < TN_GROUP_MAX; ++i) if (i < grp.n && logical >= grp.p[i].tile_begin) k = i;
+  const TnGroupProblem<T>& pr = grp.p[k];
+  DenseLoader<T> lb{pr.B, pr.ldb, P, pr.J};
+  TnEpi ep;
+  ep.out = pr.out; ep.ldo = pr.ldo; ep.colsum = pr.colsum; ep.alpha = grp.alpha; ep.probe = grp.probe;
+  tn_tile_body<T, DenseLoader<T>, TR, 2, 2>(pr.A, pr.lda, lb, P, pr.I, pr.J, pr.tiles_j, pr.ntiles, 1, pchunk, TN_OUT_DIRECT, ep,
+                                            logical - pr.tile_begin);
+}
+
 // out(mapped) += alpha * sum_s slab[s][i][j]
 __global__ void __launch_bounds__(256) tn_fold_kernel(TnEpi ep, int nsplit, int I, int J) {
   const int64_t n4 = (int64_t)I * J / 4;
@@ -767,6 +792,42 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb,
 
 static int g_tn_variant = 0;      // 0 production (the 4-wave kernel), 8 the experimental 8-wave ping-pong kernel (gemm_tn8.hip: correct, 7-16 % slower)
 void set_tn_variant(int v) { g_tn_variant = v; }
+
+template <typename T>
+int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha) {
+  typedef TnGeo<T> G;
+  if (n < 1 || n > TN_GROUP_MAX || P <= 0) return RL_ERR_ARG;
+  TnGroup<T> grp;
+  grp.n = n; grp.alpha = alpha; grp.probe = g_tn_probe;
+  int total = 0;
+  double flops = 0.0;
+  for (int k = 0; k < n; ++k) {
+    TnGroupProblem<T> pr = probs[k];
+    if (pr.I <= 0 || pr.J <= 0 || (pr.lda % G::VEC) || (pr.ldb % G::VEC) || (pr.I % G::VEC) || (pr.J % G::VEC) || (pr.ldo & 3)) return RL_ERR_ARG;
+    pr.tiles_j = (pr.J + 127) / 128;
+    pr.ntiles = ((pr.I + 127) / 128) * pr.tiles_j;
+    pr.tile_begin = total;
+    total += pr.ntiles;
+    flops += 2.0 * P * pr.I * pr.J;
+    grp.p[k] = pr;
+  }
+  grp.total_tiles = total;
+  const int pchunk = ((P + G::BP - 1) / G::BP) * G::BP;
+  const size_t lds = 2 * (size_t)G::BP * 256 * sizeof(T);
+  ProfScope ps(st, PK_GEMM_TN, flops);
+  if (sizeof(T) == 2 && g_tn_tr) {
+    static bool a1 = false;
+    if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
+    hipLaunchKernelGGL((gemm_tn_group_kernel<T, true>), dim3(total), dim3(256), lds, st, grp, P, pchunk);
+  } else {
+    static bool a2 = false;
+    if (!a2) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
+    hipLaunchKernelGGL((gemm_tn_group_kernel<T, false>), dim3(total), dim3(256), lds, st, grp, P, pchunk);
+  }
+  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+}
+template int gemm_tn_group<bf16_t>(hipStream_t, int, const TnGroupProblem<bf16_t>*, int, float);
+template int gemm_tn_group<float>(hipStream_t, int, const TnGroupProblem<float>*, int, float);
 
 template <typename T>
 int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep,

@@ -160,6 +160,35 @@ def test_gemm_tn(dt, tr, Pn, I, J, scratch):
         lib.realise_set_tn_transpose_read(1)
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("Pn,shapes", [(1024, [(768, 3072), (3072, 768), (768, 768), (2304, 768)]), (300, [(136, 200), (64, 128)]), (8192, [(768, 768)])])
+def test_gemm_tn_grouped(dt, Pn, shapes):
+    """the one-launch form of a transformer layer's weight gradients equals the per-problem launches and torch"""
+    lib = _capi.load()
+    code, tdt, tol = DT[dt]
+    probs = (_capi.TnProblem * len(shapes))()
+    keep, outs, refs, css = [], [], [], []
+    for k, (I, J) in enumerate(shapes):
+        a = rnd((Pn, I), 31 + k).to(dev()).to(tdt)
+        b = rnd((Pn, J), 41 + k).to(dev()).to(tdt)
+        base = rnd((I, J), 51 + k).to(dev())
+        out = base.clone()
+        cs = torch.full((I,), 0.25, device=dev()) if k != 1 else None
+        keep += [a, b]
+        outs.append(out); css.append((cs, a))
+        refs.append(a.float().t() @ b.float() + base)
+        probs[k].A, probs[k].lda, probs[k].B, probs[k].ldb = a.data_ptr(), I, b.data_ptr(), J
+        probs[k].I, probs[k].J, probs[k].out, probs[k].ldo = I, J, out.data_ptr(), J
+        probs[k].colsum = cs.data_ptr() if cs is not None else None
+    _capi.check(lib.realise_gemm_tn_grouped(stream(), code, len(shapes), probs, Pn), "gemm_tn_grouped")
+    for k in range(len(shapes)):
+        close(outs[k], refs[k], 3e-3 if dt == "bf16" else 2e-4, "grouped problem %d" % k)
+        cs, a = css[k]
+        if cs is not None:
+            close(cs, a.float().sum(0) + 0.25, 3e-3 if dt == "bf16" else 2e-4, "grouped column sums %d" % k)
+    assert lib.realise_gemm_tn_grouped(stream(), code, 5, probs, Pn) != 0          # more than 4 problems is an argument error
+
+
 # ------------------------------------------------------------------------------------------ conv
 def _geom(src, index, rows, Hr, Hs, Cc, k, stride, pad, mode):
     g = _capi.ConvGeom()
