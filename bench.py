@@ -176,6 +176,19 @@ def read_families(lib, sampled):
     return fams
 
 
+def dump_launches(lib, sampled, path):
+    out = {}
+    ms = (C.c_float * 8192)()
+    work = (C.c_double * 8192)()
+    for i, name in enumerate(FAMILIES):
+        n = lib.realise_profile_dump(i, 8192, ms, work)
+        per = n // max(1, sampled)
+        out[name] = [{"us": round(ms[k] * 1e3, 2), "gflop": round(work[k] * 1e-9, 3),
+                      "tflops": round(work[k] / (ms[k] * 1e-3) * 1e-12, 1) if ms[k] > 0 else 0.0} for k in range(per)]
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+
+
 def timed_loop(fn, steps, world, dev):
     if world > 1:
         dist.barrier()
@@ -208,6 +221,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write the per-launch durations of the first sampled step to this JSON file")
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only measurements")
     ap.add_argument("--no-overlap", action="store_true", help="run the bert / pho / glyph branches serially on one stream")
     args = ap.parse_args()
@@ -303,6 +317,8 @@ def main():
     fams = {}
     if profile:
         fams = read_families(lib, sampled[0])
+        if args.dump_launches:
+            dump_launches(lib, sampled[0], args.dump_launches)
         lib.realise_profile_disable()
 
     # live glyph rows: distinct token ids of the batch / tokens (device-side dedup bookkeeping of the last step)

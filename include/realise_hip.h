@@ -240,6 +240,8 @@ void realise_profile_disable(void);
  * bench.py samples every 10th timed step instead of all of them) */
 void realise_profile_pause(int paused);
 int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work);
+/* per-launch records of one family in launch order (host arrays of max_records entries); returns the number written */
+int realise_profile_dump(int kernel_family, int max_records, float* ms_out, double* work_out);
 
 const char* realise_version(void);
 

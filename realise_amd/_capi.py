@@ -102,6 +102,7 @@ SYMBOLS = {
     "realise_profile_enable": (_I, [_I]),
     "realise_profile_disable": (None, []),
     "realise_profile_pause": (None, [_I]),
+    "realise_profile_dump": (_I, [_I, _I, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "realise_profile_read": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

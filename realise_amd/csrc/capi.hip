@@ -257,6 +257,7 @@ int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, in
 int realise_profile_enable(int max_launches) { return prof_enable(max_launches); }
 void realise_profile_pause(int paused) { prof_pause(paused); }
 void realise_profile_disable(void) { prof_disable(); }
+int realise_profile_dump(int kernel_family, int max_records, float* ms_out, double* work_out) { return prof_dump(kernel_family, max_records, ms_out, work_out); }
 int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work) {
   if (kernel_family < 0 || kernel_family >= PK_COUNT || !count || !total_ms || !total_work) return RL_ERR_ARG;
   return prof_read(kernel_family, count, total_ms, total_work);

@@ -702,33 +702,99 @@ gemm_tn_group_kernel(TnGroup<T> grp, int P, int pchunk) {
                                             logical - pr.tile_begin);
 }
 
-// out(mapped) += alpha * sum_s slab[s][i][j]
-__global__ void __launch_bounds__(256) tn_fold_kernel(TnEpi ep, int nsplit, int I, int J) {
-  const int64_t n4 = (int64_t)I * J / 4;
-  const int64_t plane = (int64_t)I * J;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
-    floatx4 s = *(const floatx4*)(ep.slab + e * 4);
-    for (int k = 1; k < nsplit; ++k) s += *(const floatx4*)(ep.slab + k * plane + e * 4);
-    s *= ep.alpha;
-    const int i = (int)((e * 4) / J), j = (int)((e * 4) - (int64_t)i * J);
-    if (ep.mode == TN_PLAIN && (ep.ldo & 3) == 0) {
-      floatx4* o = (floatx4*)(ep.out + (int64_t)i * ep.ldo + j);
-      *o = *o + s;
-    } else {
+// out(mapped) += alpha * sum_s slab[s][i][j], in a fixed order (bitwise reproducible).
+// A block is EB items x SB split lanes (EB * SB = 256): lane group s sums the splits s, s + SB, ... of its item, the partial sums meet
+// in LDS and lane group 0 adds them in order.  SB > 1 is what keeps the pass short when a small gradient was split hundreds of ways
+// to fill the chip (the 64-channel glyph convolutions: 4608 outputs x 512 splits took 120 us with one thread per output walking all
+// the slabs; tools/conv_tn_probe.py).
+// PLAIN: an item is one float4 of a row.  CONVW: an item is one (output channel, input channel) pair, all KH*KW taps - the slab is
+// read along ci (coalesced) per tap and the [Co][Ci][KH][KW] gradient is written as KH*KW consecutive floats per thread.
+template <int SB>
+__global__ void __launch_bounds__(256) tn_fold_plain_kernel(TnEpi ep, int nsplit, int I, int J) {
+  constexpr int EB = 256 / SB;
+  __shared__ floatx4 part[SB > 1 ? SB : 1][EB];
+  const int64_t n4 = (int64_t)I * J / 4, plane = (int64_t)I * J;
+  const int le = threadIdx.x % EB, ls = threadIdx.x / EB;
+  for (int64_t e0 = (int64_t)blockIdx.x * EB; e0 < n4; e0 += (int64_t)gridDim.x * EB) {
+    const int64_t e = e0 + le;
+    floatx4 s = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (e < n4)
+      for (int k = ls; k < nsplit; k += SB) s += *(const floatx4*)(ep.slab + k * plane + e * 4);
+    if constexpr (SB > 1) {
+      part[ls][le] = s;
+      __syncthreads();
+      if (ls == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t idx = tn_out_index(ep, i, j + r);
-        if (idx >= 0) ep.out[idx] += s[r];
+        for (int k = 1; k < SB; ++k) s += part[k][le];
       }
+    }
+    if (ls == 0 && e < n4) {
+      s *= ep.alpha;
+      const int i = (int)((e * 4) / J), j = (int)((e * 4) - (int64_t)i * J);
+      if (ep.mode == TN_PLAIN && (ep.ldo & 3) == 0) {
+        floatx4* o = (floatx4*)(ep.out + (int64_t)i * ep.ldo + j);
+        *o = *o + s;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t idx = tn_out_index(ep, i, j + r);
+          if (idx >= 0) ep.out[idx] += s[r];
+        }
+      }
+    }
+    if constexpr (SB > 1) __syncthreads();
+  }
+}
+
+template <int SB>
+__global__ void __launch_bounds__(256) tn_fold_convw_kernel(TnEpi ep, int nsplit, int I, int J) {
+  constexpr int EB = 256 / SB;
+  __shared__ float part[SB > 1 ? SB : 1][EB];
+  const int64_t items = (int64_t)I * ep.Cin, plane = (int64_t)I * J;
+  const int le = threadIdx.x % EB, ls = threadIdx.x / EB;
+  for (int64_t e0 = (int64_t)blockIdx.x * EB; e0 < items; e0 += (int64_t)gridDim.x * EB) {
+    const int64_t e = e0 + le;
+    const int i = (int)(e / ep.Cin), ci = (int)(e - (int64_t)i * ep.Cin);
+    for (int tap = 0; tap < ep.KHW; ++tap) {
+      float s = 0.f;
+      if (e < items) {
+        const float* src = ep.slab + (int64_t)i * J + tap * ep.Cpad + ci;
+        for (int k = ls; k < nsplit; k += SB) s += src[k * plane];
+      }
+      if constexpr (SB > 1) {
+        part[ls][le] = s;
+        __syncthreads();
+        if (ls == 0) {
+#pragma unroll
+          for (int k = 1; k < SB; ++k) s += part[k][le];
+        }
+        __syncthreads();
+      }
+      if (ls == 0 && e < items) ep.out[e * ep.KHW + tap] += s * ep.alpha;
     }
   }
 }
 
 void tn_fold_launch(hipStream_t st, const TnEpi& ep, int nsplit, int I, int J) {
-  const int64_t n4 = (int64_t)I * J / 4;
-  int blocks = (int)((n4 + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(tn_fold_kernel, dim3(blocks), dim3(256), 0, st, ep, nsplit, I, J);
+  // the per-(co, ci) form pays off once there are enough pairs to fill blocks; tiny gradients (64 x 3 x 9) go through the float4 form
+  const bool convw = ep.mode != TN_PLAIN && (int64_t)I * ep.Cin >= 16384;
+  const int64_t items = convw ? (int64_t)I * ep.Cin : (int64_t)I * J / 4;
+  // split lanes: as many as keep >= ~1024 blocks' worth of items busy, at most 16 and at most the split count
+  int sb = 1;
+  while (sb < 16 && sb * 2 <= nsplit && items * sb < 256 * 1024) sb *= 2;
+  int blocks = (int)((items + 256 / sb - 1) / (256 / sb));
+  if (blocks > 4096) blocks = 4096;
+#define RL_FOLD(SBV) \
+  if (convw) hipLaunchKernelGGL(tn_fold_convw_kernel<SBV>, dim3(blocks), dim3(256), 0, st, ep, nsplit, I, J); \
+  else hipLaunchKernelGGL(tn_fold_plain_kernel<SBV>, dim3(blocks), dim3(256), 0, st, ep, nsplit, I, J);
+  switch (sb) {
+    case 1: RL_FOLD(1) break;
+    case 2: RL_FOLD(2) break;
+    case 4: RL_FOLD(4) break;
+    case 8: RL_FOLD(8) break;
+    default: RL_FOLD(16) break;
+  }
+#undef RL_FOLD
 }
 
 static int g_tn_tr = 1;   // ds_read_b64_tr_b16 verified on MI355X (tests/test_kernels_gpu.py::test_gemm_tn)

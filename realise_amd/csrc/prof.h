@@ -11,6 +11,7 @@ int prof_enable(int max_launches);
 void prof_disable();
 void prof_pause(int paused);      // keep the collected records, stop / resume bracketing launches (sampled steps)
 int prof_read(int kid, long long* count, double* total_ms, double* total_work);
+int prof_dump(int kid, int max, float* ms_out, double* work_out);   // per-launch records of one family, in launch order
 struct ProfScope {
   hipStream_t st;
   ProfScope(hipStream_t s, int kid, double work) : st(s) { prof_begin(s, kid, work); }

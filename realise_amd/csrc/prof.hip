@@ -58,4 +58,16 @@ int prof_read(int kid, long long* count, double* total_ms, double* total_work) {
   }
   return 0;
 }
+int prof_dump(int kid, int max, float* ms_out, double* work_out) {
+  if (!g_on) return 0;
+  if (g_used >= 2) (void)hipEventSynchronize(g_ev[g_used - 1]);
+  int n = 0;
+  for (const Rec& r : g_recs) {
+    if (r.kid != kid || r.e0 + 2 > g_used || n >= max) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_ev[r.e0], g_ev[r.e0 + 1]) != hipSuccess) continue;
+    ms_out[n] = ms; work_out[n] = r.work; ++n;
+  }
+  return n;
+}
 }  // namespace rl
