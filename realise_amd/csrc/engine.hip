@@ -97,6 +97,7 @@ template <typename T> struct Engine : EngineBase {
     int64_t wC1[2], wC2[2], wD[2], wF[2], tn_slab2;      // per-parity dY copies + second slab: weight gradients on the side stream
     // backward scratch of the three concurrent branches: 0 = bert (the fields above), 1 = pho_model + GRU, 2 = glyph ResNet
     struct Scratch { int64_t gB, gE, rowdot, tn_slab, tn_slab2, ln_slots, wC1[2], wC2[2], wD[2], wF[2]; } sc[3];
+    std::vector<std::pair<int64_t, int64_t>> zero_once;      // (offset, bytes): self-cleaning accumulators, zero-filled when the plan is installed
     int64_t gru_dh, gru_dgi, gru_dgh, gru_onehot, gru_dtable;
     int64_t r_dout, r_dc2, r_dcs, r_dh1, r_dc1, r_dx;
   } pl;
@@ -312,7 +313,7 @@ template <typename T> struct Engine : EngineBase {
     p.wC1[1] = b.take(Tw * H * e); p.wC2[1] = b.take(Tw * H * e); p.wD[1] = b.take(Tw * I * e); p.wF[1] = b.take(Tw * 3 * H * e);
     p.tn_slab2 = b.take(TN_SLAB_ELEMS * 4);
     p.tn_slab = b.take(TN_SLAB_ELEMS * 4);
-    p.ln_slots = b.take(32 * 2 * 1024 * 4);
+    p.ln_slots = b.take(LN_SLOT_BYTES); p.zero_once.push_back({p.ln_slots, LN_SLOT_BYTES});
     tap("d_x0", p.gB, Tk * H);
     {
       typename Plan::Scratch& s0 = p.sc[0];
@@ -323,12 +324,12 @@ template <typename T> struct Engine : EngineBase {
         if (!glyph_only) {          // pho branch: a full private set (its layers run next to the bert layers)
           typename Plan::Scratch& s1 = p.sc[1];
           s1.gB = b.take(Tk * H * e); s1.gE = b.take(Tk * H * e); s1.rowdot = b.take((int64_t)B * nh * S * 4);
-          s1.tn_slab = b.take(TN_SLAB_ELEMS * 4); s1.tn_slab2 = s1.tn_slab; s1.ln_slots = b.take(32 * 2 * 1024 * 4);
+          s1.tn_slab = b.take(TN_SLAB_ELEMS * 4); s1.tn_slab2 = s1.tn_slab; s1.ln_slots = b.take(LN_SLOT_BYTES); p.zero_once.push_back({s1.ln_slots, LN_SLOT_BYTES});
           s1.wC1[0] = b.take(Tk * H * e); s1.wC2[0] = b.take(Tk * H * e); s1.wD[0] = b.take(Tk * I * e); s1.wF[0] = b.take(Tk * 3 * H * e);
           s1.wC1[1] = s1.wC1[0]; s1.wC2[1] = s1.wC2[0]; s1.wD[1] = s1.wD[0]; s1.wF[1] = s1.wF[0];
         }
         typename Plan::Scratch& s2 = p.sc[2];   // glyph branch: LayerNorm-backward output, slabs of the conv weight gradients
-        s2.gE = b.take(Tk * H * e); s2.tn_slab = b.take(TN_SLAB_ELEMS * 4); s2.ln_slots = b.take(32 * 2 * 1024 * 4);
+        s2.gE = b.take(Tk * H * e); s2.tn_slab = b.take(TN_SLAB_ELEMS * 4); s2.ln_slots = b.take(LN_SLOT_BYTES); p.zero_once.push_back({s2.ln_slots, LN_SLOT_BYTES});
       }
     }
     if (cfg.model_type == 1) {
@@ -357,7 +358,7 @@ template <typename T> struct Engine : EngineBase {
         hin = a.Hout;
       }
       p.bn_sums = b.take(2 * 1024 * 4);
-      p.bn_slots = b.take((int64_t)COL_SLOT_FLOATS * 4);
+      p.bn_slots = b.take((int64_t)COL_SLOT_BYTES);
       p.gu_first = b.take((int64_t)V * 4); p.gu_flag = b.take(Tk * 4); p.gu_ids = b.take(Tk * 8); p.gu_counts = b.take(Tk * 4);
       p.gu_inv = b.take(Tk * 4); p.gu_bounds = b.take(64); p.seg_acc = b.take(Tk * H * 4);
       p.gu_dense = b.take(Tk * (int64_t)cfg.glyph_size * cfg.glyph_size * 8 * e);      // the distinct glyph images, contiguous (NHWC, 8 channels)
@@ -377,14 +378,14 @@ template <typename T> struct Engine : EngineBase {
     {   // named views of the scratch regions (diagnostics: tools/diag_stale.py zeroes them one at a time)
       const int64_t e1 = (int64_t)sizeof(T);
       auto stap = [&](const char* n, int64_t off, int64_t bytes) { tap(std::string("scratch.") + n, off, bytes / e1); };
-      stap("tn_slab", p.tn_slab, TN_SLAB_ELEMS * 4); stap("ln_slots", p.ln_slots, 32 * 2 * 1024 * 4);
+      stap("tn_slab", p.tn_slab, TN_SLAB_ELEMS * 4); stap("ln_slots", p.ln_slots, LN_SLOT_BYTES);
       stap("gA", p.gA, Tk * H * e); stap("gB", p.gB, Tk * H * e); stap("gC", p.gC, Tk * H * e); stap("gE", p.gE, Tk * H * e);
       stap("gD", p.gD, Tw * I * e); stap("gF", p.gF, Tw * 3 * H * e);
       if (cfg.model_type == 1) {
         const int64_t big = (int64_t)p.blk[0].Pout * 64 * e;
         stap("r_dout", p.r_dout, big); stap("r_dc2", p.r_dc2, big); stap("r_dcs", p.r_dcs, big); stap("r_dh1", p.r_dh1, big);
         stap("r_dc1", p.r_dc1, big); stap("r_dx", p.r_dx, big); stap("bn_sums", p.bn_sums, 2 * 1024 * 4);
-        stap("bn_slots", p.bn_slots, (int64_t)COL_SLOT_FLOATS * 4); stap("seg_acc", p.seg_acc, Tk * H * 4);
+        stap("bn_slots", p.bn_slots, (int64_t)COL_SLOT_BYTES); stap("seg_acc", p.seg_acc, Tk * H * 4);
         stap("X1", p.X1, Tk * H * e); stap("X2", p.X2, Tk * H * e); stap("X3", p.X3, Tk * H * e);
       }
     }
@@ -608,7 +609,6 @@ template <typename T> struct Engine : EngineBase {
   int bn_forward(hipStream_t st, const T* x, int Pn, int C, const BnOff& o, const BnAct& a, const RowBound& rb) {
     if (last.training) {
       float* sums = wp<float>(pl.bn_sums);
-      RL_TRY(fill_f32(st, sums, 0.f, 2 * C));
       RL_TRY(col_sum<T>(st, x, Pn, C, sums, rb));
       RL_TRY(bn_finalize_mean(st, sums, C, Pn, wp<float>(a.mean)));
       RL_TRY(col_sumsq_centered<T>(st, x, Pn, C, wp<float>(a.mean), sums + C, rb));
@@ -676,11 +676,9 @@ template <typename T> struct Engine : EngineBase {
       const int64_t* index = nullptr;
       T* dc2 = wp<T>(pl.r_dc2); T* dcs = wp<T>(pl.r_dcs); T* dh1 = wp<T>(pl.r_dh1); T* dc1 = wp<T>(pl.r_dc1);
       // out = relu(bn2(c2) + bns(cs))
-      RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));
       RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), Pn, Co, sums, rb));
       RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), pp(o.bn2.g), sums,
                              Pn, Co, dc2, gp(o.bn2.g), gp(o.bn2.b), rb, Pn));
-      RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));
       RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), Pn, Co, sums, rb));
       RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), pp(o.bns.g), sums,
                              Pn, Co, dcs, gp(o.bns.g), gp(o.bns.b), rb, Pn));
@@ -690,7 +688,6 @@ template <typename T> struct Engine : EngineBase {
       { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = dh1; ep.ldo = Co;
         RL_TRY(gemm_nt_conv<T>(st, geom(dc2, nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 1, rb.rows_dev), sp<T>(s.w2d), 9 * Co, Pn, Co, 9 * Co, ep)); }
       // h1 = relu(bn1(c1))
-      RL_TRY(fill_f32(st, sums, 0.f, 2 * Co));
       RL_TRY(bn_bwd_reduce<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), Pn, Co, sums, rb));
       RL_TRY(bn_bwd_apply<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), pp(o.bn1.g), sums,
                              Pn, Co, dc1, gp(o.bn1.g), gp(o.bn1.b), rb, Pn));
@@ -777,14 +774,21 @@ template <typename T> struct Engine : EngineBase {
   }
 
   // ---------------------------------------------------------------- forward
+  // a freshly planned workspace: the self-cleaning LayerNorm-backward accumulators start at zero
+  int install_plan(hipStream_t st, const Plan& p) {
+    if (p.total > ws_bytes) { fprintf(stderr, "[realise_hip] workspace too small: need %lld have %lld\n", (long long)p.total, (long long)ws_bytes); return RL_ERR_ARG; }
+    pl = p;
+    for (const auto& z : pl.zero_once)
+      if (hipMemsetAsync(ws + z.first, 0, (size_t)z.second, st) != hipSuccess) return RL_ERR_LAUNCH;
+    return RL_OK;
+  }
   int forward(hipStream_t st, const realise_batch& b) override {
     if (!sh || !ws) return RL_ERR_ARG;
     if (b.B < 1 || b.S < 1 || b.S > 128 || b.S > cfg.max_pos) return RL_ERR_ARG;
     const int Tp = cfg.model_type == 1 ? b.Tp : 1;
     if (cfg.model_type == 1 && (Tp < 1 || !b.pho_idx || !b.pho_perm || !b.pho_lens_sorted || (!b.n_alive && !b.n_alive_dev))) return RL_ERR_ARG;
     if (pl.B != b.B || pl.S != b.S || pl.Tp != Tp) {
-      pl = make_plan(b.B, b.S, Tp);
-      if (pl.total > ws_bytes) { fprintf(stderr, "[realise_hip] workspace too small: need %lld have %lld\n", (long long)pl.total, (long long)ws_bytes); return RL_ERR_ARG; }
+      RL_TRY(install_plan(st, make_plan(b.B, b.S, Tp)));
     }
     last = b;
     last.Tp = Tp;
@@ -842,8 +846,7 @@ template <typename T> struct Engine : EngineBase {
   int glyph_forward(hipStream_t st, const int64_t* ids, int B, int S, int training, void* res_out) override {
     if (!sh || !ws || cfg.model_type != 1 || !ids || !res_out || B < 1 || S < 1) return RL_ERR_ARG;
     if (pl.B != B || pl.S != S || pl.Tp != -1) {
-      pl = make_plan(B, S, -1);
-      if (pl.total > ws_bytes) { fprintf(stderr, "[realise_hip] workspace too small: need %lld have %lld\n", (long long)pl.total, (long long)ws_bytes); return RL_ERR_ARG; }
+      RL_TRY(install_plan(st, make_plan(B, S, -1)));
     }
     last = realise_batch();
     last.B = B; last.S = S; last.Tp = 1; last.training = training; last.src_idx = ids;

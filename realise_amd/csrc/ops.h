@@ -10,11 +10,15 @@ struct DropParams { uint32_t seed = 0, thresh = 0; float scale = 1.0f; };
 // Device-side row bound + per-image multiplicity for the glyph branch, which runs once per DISTINCT token id of the
 // batch: effective rows = min(P, *rows_dev); weight(row) = counts[row / hw] (the number of tokens sharing that glyph).
 constexpr int COL_SLOT_FLOATS = 262144;   // >= (row chunks) x 2C for every launch shape of the column reductions
+constexpr int COL_SLOT_BYTES = COL_SLOT_FLOATS * 4;
+constexpr int LN_SLOT_FLOATS = 32 * 2 * 1024;   // LayerNorm backward: 32 replicated [dgamma | dbeta] accumulators
+constexpr int LN_SLOT_BYTES = LN_SLOT_FLOATS * 4;
 struct RowBound {
   const int* rows_dev = nullptr;
   const float* counts = nullptr;
   int hw = 1;
-  float* slots = nullptr;          // optional scratch of COL_SLOT_FLOATS floats: per-row-chunk partial sums, folded in a fixed order
+  float* slots = nullptr;          // optional scratch of COL_SLOT_BYTES: per-row-chunk partial sums, folded in a fixed order by a second kernel;
+                                   // the outputs are then OVERWRITTEN, not accumulated (no zero-fill needed)
                                    // (bitwise reproducible BatchNorm statistics; without it the reductions use float atomics)
 };
 __device__ __forceinline__ int rb_rows(const RowBound& b, int P) { return b.rows_dev ? min(P, *b.rows_dev) : P; }
@@ -55,7 +59,8 @@ template <typename T> struct LnBwdArgs {
   DropParams out_drop;
   float* dgamma = nullptr;         // accumulated
   float* dbeta = nullptr;
-  float* slots = nullptr;          // optional scratch 32 x 2H floats: replicated accumulators (cuts atomic contention)
+  float* slots = nullptr;          // optional scratch of LN_SLOT_BYTES, all zero before the first use (self-cleaning): replicated accumulators
+                                   // (cuts atomic contention); the fold kernel adds them into dgamma / dbeta and zeroes them again
 };
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a);
 
