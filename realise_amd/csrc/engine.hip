@@ -313,7 +313,7 @@ template <typename T> struct Engine : EngineBase {
     p.wC1[1] = b.take(Tw * H * e); p.wC2[1] = b.take(Tw * H * e); p.wD[1] = b.take(Tw * I * e); p.wF[1] = b.take(Tw * 3 * H * e);
     p.tn_slab2 = b.take(TN_SLAB_ELEMS * 4);
     p.tn_slab = b.take(TN_SLAB_ELEMS * 4);
-    p.ln_slots = b.take(LN_SLOT_BYTES); p.zero_once.push_back({p.ln_slots, LN_SLOT_BYTES});
+    p.ln_slots = b.take(LN_SLOT_BYTES);
     tap("d_x0", p.gB, Tk * H);
     {
       typename Plan::Scratch& s0 = p.sc[0];
@@ -324,12 +324,12 @@ template <typename T> struct Engine : EngineBase {
         if (!glyph_only) {          // pho branch: a full private set (its layers run next to the bert layers)
           typename Plan::Scratch& s1 = p.sc[1];
           s1.gB = b.take(Tk * H * e); s1.gE = b.take(Tk * H * e); s1.rowdot = b.take((int64_t)B * nh * S * 4);
-          s1.tn_slab = b.take(TN_SLAB_ELEMS * 4); s1.tn_slab2 = s1.tn_slab; s1.ln_slots = b.take(LN_SLOT_BYTES); p.zero_once.push_back({s1.ln_slots, LN_SLOT_BYTES});
+          s1.tn_slab = b.take(TN_SLAB_ELEMS * 4); s1.tn_slab2 = s1.tn_slab; s1.ln_slots = b.take(LN_SLOT_BYTES);
           s1.wC1[0] = b.take(Tk * H * e); s1.wC2[0] = b.take(Tk * H * e); s1.wD[0] = b.take(Tk * I * e); s1.wF[0] = b.take(Tk * 3 * H * e);
           s1.wC1[1] = s1.wC1[0]; s1.wC2[1] = s1.wC2[0]; s1.wD[1] = s1.wD[0]; s1.wF[1] = s1.wF[0];
         }
         typename Plan::Scratch& s2 = p.sc[2];   // glyph branch: LayerNorm-backward output, slabs of the conv weight gradients
-        s2.gE = b.take(Tk * H * e); s2.tn_slab = b.take(TN_SLAB_ELEMS * 4); s2.ln_slots = b.take(LN_SLOT_BYTES); p.zero_once.push_back({s2.ln_slots, LN_SLOT_BYTES});
+        s2.gE = b.take(Tk * H * e); s2.tn_slab = b.take(TN_SLAB_ELEMS * 4); s2.ln_slots = b.take(LN_SLOT_BYTES);
       }
     }
     if (cfg.model_type == 1) {
@@ -648,7 +648,13 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(bn_apply<T>(st, wp<T>(a.c1), wp<float>(a.bn1.scale), wp<float>(a.bn1.shift), nullptr, nullptr, nullptr, wp<T>(a.h1), Pn, Co, 1, rb));
       // residual_function.3: 3x3 stride 1 pad 1 (char_cnn.py:19)
       ep.out = wp<T>(a.c2);
-      RL_TRY(gemm_nt_conv<T>(st, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0, rb.rows_dev), sp<T>(s.w2f), 9 * Co, Pn, Co, 9 * Co, ep));
+      if (a.Hout == 1) {
+        // a 3x3 / pad 1 convolution on a 1x1 map touches only its centre tap (the other eight read padding): a dense GEMM against
+        // the centre-tap slice of the [Co][tap][Ci] operand copy, 1/9 of the implicit-GEMM work (block 5: 113 -> ~15 us)
+        RL_TRY(gemm_nt<T>(st, wp<T>(a.h1), Co, sp<T>(s.w2f) + 4 * Co, 9 * Co, Pn, Co, Co, ep, rb.rows_dev));
+      } else {
+        RL_TRY(gemm_nt_conv<T>(st, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0, rb.rows_dev), sp<T>(s.w2f), 9 * Co, Pn, Co, 9 * Co, ep));
+      }
       RL_TRY(bn_forward(st, wp<T>(a.c2), Pn, Co, o.bn2, a.bn2, rb));
       // shortcut: 1x1 stride 2 (char_cnn.py:26-28)
       ep.out = wp<T>(a.cs);
@@ -684,9 +690,11 @@ template <typename T> struct Engine : EngineBase {
                              Pn, Co, dcs, gp(o.bns.g), gp(o.bns.b), rb, Pn));
       // conv2 (3x3 s1): weight grad and data grad
       { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w2); te.Cin = Co; te.Cpad = Co; te.KHW = 9;
-        RL_TRY(gemm_tn_conv<T>(st, dc2, Co, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0, rb.rows_dev), Pn, Co, 9 * Co, te)); }
+        if (a.Hout == 1) { te.tap0 = 4; RL_TRY(gemm_tn<T>(st, dc2, Co, wp<T>(a.h1), Co, Pn, Co, Co, te, rb.rows_dev)); }       // centre tap only
+        else RL_TRY(gemm_tn_conv<T>(st, dc2, Co, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0, rb.rows_dev), Pn, Co, 9 * Co, te)); }
       { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = dh1; ep.ldo = Co;
-        RL_TRY(gemm_nt_conv<T>(st, geom(dc2, nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 1, rb.rows_dev), sp<T>(s.w2d), 9 * Co, Pn, Co, 9 * Co, ep)); }
+        if (a.Hout == 1) RL_TRY(gemm_nt<T>(st, dc2, Co, sp<T>(s.w2d) + 4 * Co, 9 * Co, Pn, Co, Co, ep, rb.rows_dev));          // centre tap only
+        else RL_TRY(gemm_nt_conv<T>(st, geom(dc2, nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 1, rb.rows_dev), sp<T>(s.w2d), 9 * Co, Pn, Co, 9 * Co, ep)); }
       // h1 = relu(bn1(c1))
       RL_TRY(bn_bwd_reduce<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), Pn, Co, sums, rb));
       RL_TRY(bn_bwd_apply<T>(st, dh1, wp<T>(a.h1), wp<T>(a.c1), wp<float>(a.bn1.mean), wp<float>(a.bn1.rstd), pp(o.bn1.g), sums,

@@ -196,7 +196,8 @@ struct TnEpi {
   float* out = nullptr;     // fp32, accumulated (out += result)
   int64_t ldo = 0;
   float alpha = 1.0f;
-  int Cin = 0, Cpad = 0, KHW = 0;   // TN_CONVW: j = tap*Cpad + ci -> out[(i*Cin + ci)*KHW + tap]
+  int Cin = 0, Cpad = 0, KHW = 0;   // TN_CONVW: j = tap*Cpad + ci -> out[(i*Cin + ci)*KHW + tap + tap0]
+  int tap0 = 0;                     // first tap the J columns cover (a 3x3 convolution on a 1x1 map only has its centre tap: J = Cpad, tap0 = 4)
   // split-reduction scratch: when the reduction is split over several workgroups each writes a dense fp32
   // [I][J] partial slab here and a second kernel folds the slabs into `out` (no atomics).  nullptr -> atomics.
   float* slab = nullptr;

@@ -755,7 +755,8 @@ __global__ void __launch_bounds__(256) tn_fold_convw_kernel(TnEpi ep, int nsplit
   for (int64_t e0 = (int64_t)blockIdx.x * EB; e0 < items; e0 += (int64_t)gridDim.x * EB) {
     const int64_t e = e0 + le;
     const int i = (int)(e / ep.Cin), ci = (int)(e - (int64_t)i * ep.Cin);
-    for (int tap = 0; tap < ep.KHW; ++tap) {
+    const int ntaps = J / ep.Cpad;          // the taps the J columns cover (all KH*KW, or the one live tap of a 1x1 map)
+    for (int tap = 0; tap < ntaps; ++tap) {
       float s = 0.f;
       if (e < items) {
         const float* src = ep.slab + (int64_t)i * J + tap * ep.Cpad + ci;
@@ -770,7 +771,7 @@ __global__ void __launch_bounds__(256) tn_fold_convw_kernel(TnEpi ep, int nsplit
         }
         __syncthreads();
       }
-      if (ls == 0 && e < items) ep.out[e * ep.KHW + tap] += s * ep.alpha;
+      if (ls == 0 && e < items) ep.out[e * ep.KHW + tap + ep.tap0] += s * ep.alpha;
     }
   }
 }

@@ -142,7 +142,7 @@ enum TnOut { TN_OUT_DIRECT = 0, TN_OUT_SLAB = 1, TN_OUT_ATOMIC = 2 };
 __device__ __forceinline__ int64_t tn_out_index(const TnEpi& ep, int i, int j) {   // -1: padding column
   if (ep.mode == TN_PLAIN) return (int64_t)i * ep.ldo + j;
   const int tap = j / ep.Cpad, ci = j - tap * ep.Cpad;
-  return ci < ep.Cin ? ((int64_t)i * ep.Cin + ci) * ep.KHW + tap : -1;
+  return ci < ep.Cin ? ((int64_t)i * ep.Cin + ci) * ep.KHW + tap + ep.tap0 : -1;
 }
 
 __device__ __forceinline__ void tn_epilogue4(const TnEpi& ep, int how, int split, int I, int J, int i, int j, floatx4 v) {

@@ -11,7 +11,7 @@ struct DropParams { uint32_t seed = 0, thresh = 0; float scale = 1.0f; };
 // batch: effective rows = min(P, *rows_dev); weight(row) = counts[row / hw] (the number of tokens sharing that glyph).
 constexpr int COL_SLOT_FLOATS = 262144;   // >= (row chunks) x 2C for every launch shape of the column reductions
 constexpr int COL_SLOT_BYTES = COL_SLOT_FLOATS * 4;
-constexpr int LN_SLOT_FLOATS = 32 * 2 * 1024;   // LayerNorm backward: 32 replicated [dgamma | dbeta] accumulators
+constexpr int LN_SLOT_FLOATS = 1024 * 2 * 1024;   // LayerNorm backward: one [dgamma | dbeta] record per workgroup (<= 1024 workgroups, H <= 1024)
 constexpr int LN_SLOT_BYTES = LN_SLOT_FLOATS * 4;
 struct RowBound {
   const int* rows_dev = nullptr;
@@ -59,8 +59,7 @@ template <typename T> struct LnBwdArgs {
   DropParams out_drop;
   float* dgamma = nullptr;         // accumulated
   float* dbeta = nullptr;
-  float* slots = nullptr;          // optional scratch of LN_SLOT_BYTES, all zero before the first use (self-cleaning): replicated accumulators
-                                   // (cuts atomic contention); the fold kernel adds them into dgamma / dbeta and zeroes them again
+  float* slots = nullptr;          // optional scratch of LN_SLOT_BYTES: per-workgroup partial records, folded in a fixed order (no atomics)
 };
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a);
 

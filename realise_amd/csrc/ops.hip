@@ -152,14 +152,39 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
     for (int j = 0; j < 4; ++j) { red[0][wave][c + j] = dg[i][j]; red[1][wave][c + j] = db[i][j]; }
   }
   __syncthreads();
-  float* og = a.dgamma;
-  float* ob = a.dbeta;
-  if (a.slots != nullptr) { og = a.slots + (int64_t)(blockIdx.x & 31) * 2 * H; ob = og + H; }
+  // With scratch: this workgroup's [dgamma | dbeta] partial goes to its own record as plain stores and ln_fold_kernel adds the
+  // records in a fixed order - no atomics (1024 workgroups x 1536 float atomics were ~10 us of this kernel), no zero-fill,
+  // bitwise reproducible.  Without scratch (few rows, C-ABI callers): atomics straight into the gradients.
+  float* rec = a.slots != nullptr ? a.slots + (int64_t)blockIdx.x * 2 * H : nullptr;
   for (int c = threadIdx.x; c < H; c += 256) {
     const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
     const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    if (og != nullptr) atomicAdd(og + c, g);
-    if (ob != nullptr) atomicAdd(ob + c, b);
+    if (rec != nullptr) { rec[c] = g; rec[H + c] = b; }
+    else {
+      if (a.dgamma != nullptr) atomicAdd(a.dgamma + c, g);
+      if (a.dbeta != nullptr) atomicAdd(a.dbeta + c, b);
+    }
+  }
+}
+// dgamma / dbeta += sum of the per-workgroup records: one float4 column group per 64 threads (record lanes k, k + 64, ...),
+// four groups per block, fixed-order LDS tree.
+__global__ void __launch_bounds__(256) ln_fold_kernel(const float* __restrict__ recs, int nrec, int H, float* dgamma, float* dbeta) {
+  __shared__ floatx4 red[4][64];
+  const int q = threadIdx.x >> 6, kl = threadIdx.x & 63;
+  const int i = (blockIdx.x * 4 + q) * 4;                  // column in [0, 2H)
+  floatx4 s = floatx4{0.f, 0.f, 0.f, 0.f};
+  if (i < 2 * H)
+    for (int k = kl; k < nrec; k += 64) s += *(const floatx4*)(recs + (int64_t)k * 2 * H + i);
+  red[q][kl] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 32; w > 0; w >>= 1) {
+    if (kl < w) red[q][kl] += red[q][kl + w];
+    __syncthreads();
+  }
+  if (kl == 0 && i < 2 * H) {
+    float* o = i < H ? dgamma + i : dbeta + (i - H);
+    *(floatx4*)o += red[q][0];
   }
 }
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
@@ -170,8 +195,7 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
   LnBwdArgs<T> b = a;
   if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr;
   hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, b);
-  if (b.slots != nullptr)      // adds the 32 accumulator records into dgamma / dbeta and leaves them zeroed for the next call (no memset)
-    hipLaunchKernelGGL(col_fold_kernel, dim3((2 * a.H + 31) / 32), dim3(256), 0, st, b.slots, 2 * a.H, 32, 2 * a.H, a.dgamma, a.dbeta, a.H, 0, 1);
+  if (b.slots != nullptr) hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * a.H / 4 + 3) / 4), dim3(256), 0, st, b.slots, blocks, a.H, a.dgamma, a.dbeta);
   return RL_LAUNCH_CHECK();
 }
 template int ln_bwd<bf16_t>(hipStream_t, const LnBwdArgs<bf16_t>&);
