@@ -89,6 +89,7 @@ void realise_set_nt_allow_n96(int on);
 void realise_set_nt_probe(int mode);
 /* Diagnostics: force an experimental NT tile shape for dense bf16 GEMMs (0 = production heuristic). */
 void realise_set_nt_variant(int v);
+void realise_set_nt_group_m(int g);        /* tile order of the 8-wave NT GEMM: 0 row-major, g: g tile rows per column step (L2 blocking) */
 /* Diagnostics for the TN kernel: 2 no operand fetches, 3 no MFMA work, 4 skip the slab fold pass. */
 void realise_set_tn_probe(int mode);
 /* Diagnostics: force the number of reduction splits of the TN kernel (0 = heuristic). */

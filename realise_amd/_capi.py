@@ -60,6 +60,7 @@ SYMBOLS = {
     "realise_set_nt_allow_n96": (None, [_I]),
     "realise_set_nt_probe": (None, [_I]),
     "realise_set_nt_variant": (None, [_I]),
+    "realise_set_nt_group_m": (None, [_I]),
     "realise_set_tn_probe": (None, [_I]),
     "realise_set_tn_split": (None, [_I]),
     "realise_set_tn_variant": (None, [_I]),
@@ -133,7 +134,7 @@ def load():
         fn.argtypes = args
     # A/B knobs for measurements (defaults are the production settings)
     for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_WGRAD_GROUP", lib.realise_set_wgrad_group), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup),
-                    ("REALISE_NT_VARIANT", lib.realise_set_nt_variant)):
+                    ("REALISE_NT_VARIANT", lib.realise_set_nt_variant), ("REALISE_NT_GROUP_M", lib.realise_set_nt_group_m)):
         if os.environ.get(env) is not None:
             fn(int(os.environ[env]))
     _lib = lib

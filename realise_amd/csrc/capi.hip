@@ -91,6 +91,7 @@ void realise_set_tn_transpose_read(int enable) { set_tn_transpose_read(enable); 
 void realise_set_nt_allow_n96(int on) { set_nt_allow_n96(on); }
 void realise_set_nt_probe(int mode) { set_nt_probe(mode); }
 void realise_set_nt_variant(int v) { set_nt_variant(v); }
+void realise_set_nt_group_m(int g) { set_nt8_group_m(g); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }
 void realise_set_tn_split(int n) { set_tn_split(n); }

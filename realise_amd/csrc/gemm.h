@@ -245,7 +245,8 @@ int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& l
 bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb);
 int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
              const EpiParams<bf16_t>& ep, int tile);
-void set_nt8_probe(int mode);             // 2 no fetches, 3 no MFMA / fragment reads (results wrong)
+void set_nt8_probe(int mode);
+void set_nt8_group_m(int g);       // tile order of the 8-wave NT kernels: 0/1 row-major, g > 1: g tile rows per column step (L2 blocking)             // 2 no fetches, 3 no MFMA / fragment reads (results wrong)
 
 // Ping-pong 8-wave weight-gradient kernel (gemm_tn8.hip): bf16, dense operands, 256 x 128 output tiles, split reduction + fold
 bool tn8_supported(int64_t lda, int64_t ldb, int P, int I, int J, const TnEpi& ep);

@@ -94,13 +94,29 @@ struct Nt8Cfg {
   static constexpr int LDS = (NS * STAGE > 8 * ER * RS * 4) ? NS * STAGE : 8 * ER * RS * 4;
 };
 
+static int g_nt8_group_m = 0;
+void set_nt8_group_m(int g) { g_nt8_group_m = g; }
+
+// Logical tile id -> (tile row, tile column).  group_m <= 1: row-major (a run of consecutive ids walks along N: its tiles share
+// few A rows but touch every B column panel).  group_m > 1: ids walk down group_m tile rows before moving to the next tile
+// column, so the ~64 tiles an XCD has in flight form a group_m x (64 / group_m) block whose A and B panels fit its 4 MiB L2.
+__device__ __forceinline__ void tile_coords(int tile, int tiles_n, int ntiles, int group_m, int& tm, int& tn) {
+  if (group_m <= 1) { tm = tile / tiles_n; tn = tile - tm * tiles_n; return; }
+  const int tiles_m = ntiles / tiles_n;
+  const int per_group = group_m * tiles_n;
+  const int g = tile / per_group, r = tile - g * per_group;
+  const int rows = min(group_m, tiles_m - g * group_m);
+  tn = r / rows;
+  tm = g * group_m + (r - tn * rows);
+}
+
 static int g_nt8_probe = 0;
 void set_nt8_probe(int mode) { g_nt8_probe = mode; }
 
 template <typename C, int PROBE, bool KTAIL = false>
 __global__ void __launch_bounds__(512, 2 * C::WGS)
 gemm_nt8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int M, int N, int K, int tiles_n,
-                int ntiles, EpiParams<bf16_t> ep) {
+                int ntiles, int group_m, EpiParams<bf16_t> ep) {
   typedef bf16_t T;
   typedef MmaBF16 Mma;
   constexpr int NPW = C::NPW, NPH = C::NPH, NS = C::NS, LEAD = C::LEAD, SQ = C::SQ, HT = C::HT, MT = C::MT, NT = C::NT;
@@ -110,7 +126,8 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
   const int grp = wave >> 2;
   const int wm = wave / C::WN, wn = wave - wm * C::WN;
   const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  int tm, tn;
+  tile_coords(tile, tiles_n, ntiles, group_m, tm, tn);
   const int m0 = tm * C::BM, n0 = tn * C::BN;
   const int nk = (K + 63) >> 6;
   const int ktail = KTAIL ? (K & 63) : 0;   // elements of a ragged last K-tile (multiple of 8); KTAIL = false: K % 64 == 0
@@ -286,10 +303,10 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
   }
   ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
   if constexpr (!KTAIL) {
-    if (g_nt8_probe == 2) { hipLaunchKernelGGL((gemm_nt8_kernel<C, 2>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
-    if (g_nt8_probe == 3) { hipLaunchKernelGGL((gemm_nt8_kernel<C, 3>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
+    if (g_nt8_probe == 2) { hipLaunchKernelGGL((gemm_nt8_kernel<C, 2>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
+    if (g_nt8_probe == 3) { hipLaunchKernelGGL((gemm_nt8_kernel<C, 3>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
   }
-  hipLaunchKernelGGL((gemm_nt8_kernel<C, 0, KTAIL>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
+  hipLaunchKernelGGL((gemm_nt8_kernel<C, 0, KTAIL>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -377,7 +394,7 @@ __device__ __forceinline__ void nt8ws_loader(char* smem, const bf16_t* __restric
 template <typename C, int PROBE>
 __global__ void __launch_bounds__(768)
 gemm_nt8ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int M, int N, int K, int tiles_n,
-                  int ntiles, EpiParams<bf16_t> ep) {
+                  int ntiles, int group_m, EpiParams<bf16_t> ep) {
   typedef bf16_t T;
   typedef MmaBF16 Mma;
   static_assert(C::FW == 4 && C::ISSUE_AT == 0, "loader-wave configuration");
@@ -386,7 +403,8 @@ gemm_nt8ws_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __res
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile = xcd_remap(blockIdx.x, ntiles);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  int tm, tn;
+  tile_coords(tile, tiles_n, ntiles, group_m, tm, tn);
   const int m0 = tm * C::BM, n0 = tn * C::BN;
   const int nk = K >> 6;
 
@@ -506,11 +524,11 @@ static int launch_nt8ws_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const 
     attr_set = true;
   }
   ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
-  if (g_nt8_probe == 2) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 2>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
-  else if (g_nt8_probe == 3) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 3>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
-  else if (g_nt8_probe == 4) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 4>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
-  else if (g_nt8_probe == 5) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 5>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
-  else hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 0>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep);
+  if (g_nt8_probe == 2) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 2>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
+  else if (g_nt8_probe == 3) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 3>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
+  else if (g_nt8_probe == 4) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 4>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
+  else if (g_nt8_probe == 5) hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 5>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
+  else hipLaunchKernelGGL((gemm_nt8ws_kernel<C, 0>), dim3(ntiles), dim3(768), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 

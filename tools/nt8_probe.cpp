@@ -20,7 +20,8 @@ int main(int argc, char** argv) {
   gemm_nt_fn gemm = (gemm_nt_fn)dlsym(h, "realise_gemm_nt");
   seti_fn probe = (seti_fn)dlsym(h, "realise_set_nt_probe");
   seti_fn variant = (seti_fn)dlsym(h, "realise_set_nt_variant");
-  if (!gemm || !probe || !variant) { fprintf(stderr, "missing symbols\n"); return 1; }
+  seti_fn group_m = (seti_fn)dlsym(h, "realise_set_nt_group_m");
+  if (!gemm || !probe || !variant || !group_m) { fprintf(stderr, "missing symbols\n"); return 1; }
   struct Shape { int M, N, K; const char* what; };
   const Shape shapes[] = {{8192, 768, 64, "one K-tile"}, {8192, 3072, 64, "one K-tile"}, {8192, 768, 768, "attn-out / dgrad"}, {8192, 2304, 768, "qkv"},
                           {8192, 3072, 768, "ffn1 / ffn2-dgrad"}, {8192, 768, 3072, "ffn2 / ffn1-dgrad"}, {8192, 768, 2304, "qkv-dgrad"},
@@ -75,6 +76,20 @@ int main(int argc, char** argv) {
     printf("\n");
     return bad;
   };
+  if (argc > 3 && !strcmp(argv[3], "gm")) {     // tile-order sweep: production tile choice, group_m rows per column step
+    size_t bad = 0;
+    for (int g : {8, 5}) { group_m(g); bad += compare(shapes[3], 0, 0); bad += compare(shapes[4], 1, 0); bad += compare(shapes[5], 2, 0); bad += compare(odd[0], 0, 16); bad += compare(odd[3], 0, 16); bad += compare(shapes[7], 0, 0); }
+    printf("TOTAL mismatches: %zu\n", bad);
+    for (const Shape& sh : shapes) {
+      if (sh.K == 64 || sh.K > 4000) continue;
+      printf("%5d x %5d x %5d %-22s", sh.M, sh.N, sh.K, sh.what);
+      variant(0);
+      for (int g : {0, 2, 4, 8, 16, 32}) { group_m(g); printf(" | gm%-2d %7.1f us", g, time_us(sh, 0, sh.N > 3072 ? 5 : 20)); }
+      printf("\n"); fflush(stdout);
+    }
+    group_m(0);
+    return bad ? 2 : 0;
+  }
   size_t total_bad = 0;
   const bool ws = argc > 3 && !strcmp(argv[3], "ws");
   std::vector<int> vars = {11, 12, 13, 14};
