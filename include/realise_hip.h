@@ -58,6 +58,14 @@ int realise_gemm_nt(void* stream, int dtype, const void* A, int64_t lda, const v
 /* Same with A gathered on the fly: nn.Conv2d forward / input gradient (src/char_cnn.py:15-28). */
 int realise_conv_nt(void* stream, int dtype, const realise_conv_geom* a, const void* B, int64_t ldb,
                     int M, int N, int K, const realise_epilogue* ep);
+/* Input gradient of a stride-2 nn.Conv2d (char_cnn.py:16,24 under loss.backward()) by parity classes of the input pixel: pixel
+ * (2yy+py, 2xx+px) is reached only by the taps kh = ((py+pad)&1) + 2i, kw = ((px+pad)&1) + 2j, so four GEMMs over a quarter of the
+ * pixels each with 1 / 2 / 2 / 4 taps (3x3, pad 1) replace one GEMM over all pixels with 9 taps of which 75 % are stride misses.
+ * `a` is the full-map mode-1 geometry (rows = N*Hr*Wr, Hr = Wr a power of two, no img_index); B_classes is the [Cin][slot][Co]
+ * weight copy whose tap slots are ordered class by class (class c = 2*py+px; inside a class i-major); the result rows are written
+ * to their pixel positions.  With a 1x1 / pad 0 kernel only class 0 has a tap: ep->accumulate must be set. */
+int realise_conv_dgrad_s2(void* stream, int dtype, const realise_conv_geom* a, const void* B_classes, int64_t ldb, int Cin,
+                          const realise_epilogue* ep);
 /* out[I,J] += sum_p A[p,i] * B[p,j] (fp32) - nn.Linear weight gradient.  The reduction over p is split
  * over workgroups; `scratch` (fp32, scratch_elems >= I*J, ideally several times that) receives the partial
  * slabs that a second kernel folds into `out`.  scratch == NULL falls back to fp32 atomics. */
@@ -112,6 +120,7 @@ void realise_set_wgrad_overlap(int on);
  * (src/models.py:816 bert | :818-827 pinyin GRU + pho_model | :829-838 glyph ResNet), and their backward passes behind the
  * gate, run on three HIP streams (the caller's + two engine-owned), forked / joined with events inside the engine call; the
  * caller's stream owns every result when the call returns.  0: everything in order on the caller's stream.  Identical results. */
+void realise_set_dgrad_parity(int on);     /* 1 (default): stride-2 conv data gradients as four input-pixel parity-class GEMMs (no stride-miss taps) */
 void realise_set_wgrad_group(int on);      /* 1 (default): the four weight gradients of a transformer layer as one grouped launch */
 void realise_set_branch_overlap(int on);
 

@@ -53,6 +53,7 @@ SYMBOLS = {
     "realise_version": (C.c_char_p, []),
     "realise_gemm_nt": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
     "realise_conv_nt": (_I, [_P, _I, C.POINTER(ConvGeom), _P, _L, _I, _I, _I, C.POINTER(Epilogue)]),
+    "realise_conv_dgrad_s2": (_I, [_P, _I, C.POINTER(ConvGeom), _P, _L, _I, C.POINTER(Epilogue)]),
     "realise_gemm_tn": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, _P, _L, _P, _L, _P]),
     "realise_gemm_tn_grouped": (_I, [_P, _I, _I, C.POINTER(TnProblem), _I]),
     "realise_conv_tn": (_I, [_P, _I, _P, _L, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _L]),
@@ -70,6 +71,7 @@ SYMBOLS = {
     "realise_set_glyph_dedup": (None, [_I]),
     "realise_set_wgrad_overlap": (None, [_I]),
     "realise_set_wgrad_group": (None, [_I]),
+    "realise_set_dgrad_parity": (None, [_I]),
     "realise_attention_fwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _U, _U, _F]),
     "realise_attention_bwd": (_I, [_P, _I, _P, _P, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _L, _I, _I, _I, _U, _U, _F]),
     "realise_mask_to_additive": (_I, [_P, _P, _P, _I]),
@@ -133,7 +135,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # A/B knobs for measurements (defaults are the production settings)
-    for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_WGRAD_GROUP", lib.realise_set_wgrad_group), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup),
+    for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_WGRAD_GROUP", lib.realise_set_wgrad_group), ("REALISE_DGRAD_PARITY", lib.realise_set_dgrad_parity), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup),
                     ("REALISE_NT_VARIANT", lib.realise_set_nt_variant), ("REALISE_NT_GROUP_M", lib.realise_set_nt_group_m)):
         if os.environ.get(env) is not None:
             fn(int(os.environ[env]))

@@ -32,6 +32,31 @@ template <typename T> ConvLoader<T> to_geom(const realise_conv_geom* g) {
 }  // namespace
 
 template <typename T>
+static int conv_dgrad_s2(hipStream_t st, const realise_conv_geom* a, const T* B, int64_t ldb, int Cin, const realise_epilogue* ep) {
+  if (a->mode != 1 || a->stride != 2 || a->Hr != a->Wr || (a->Hr & (a->Hr - 1)) || a->Hr < 2 || a->img_index != nullptr) return RL_ERR_ARG;
+  int hsh = 0; while ((1 << hsh) < a->Hr) ++hsh;
+  const int nimg = a->rows / (a->Hr * a->Wr);
+  for (int c = 0; c < 4; ++c) {
+    int first = 0;
+    const int nt = conv_s2_class(a->KH, a->KW, a->pad, c, &first, nullptr);
+    if (nt == 0) { if (!ep->accumulate) return RL_ERR_ARG; continue; }      // pixels no tap reaches: only meaningful when accumulating
+    ConvLoader<T> g = to_geom<T>(a);
+    g.rows = nimg * (a->Hr / 2) * (a->Wr / 2);
+    g.par = c;
+    int ntaps = nt;
+    if (a->Hr == 2 && a->Hs == 1 && a->KH == 3 && a->KW == 3 && a->pad == 1) {      // one reachable tap per pixel of a 2x2 map
+      g.tap_sel = ((c >> 1) + 1) * 3 + (c & 1) + 1;
+      first = conv_s2_slot(3, 3, 1, (c >> 1) + 1, (c & 1) + 1); ntaps = 1;
+    }
+    EpiParams<T> e = to_epi<T>(ep);
+    e.rm_hw_shift = 2 * hsh; e.rm_w_shift = hsh; e.rm_par = c;
+    const int rc = gemm_nt_conv<T>(st, g, B + (int64_t)first * a->C, ldb, g.rows, Cin, ntaps * a->C, e);
+    if (rc != RL_OK) return rc;
+  }
+  return RL_OK;
+}
+
+template <typename T>
 static int tn_grouped(hipStream_t st, int n, const realise_tn_problem* pr, int P) {
   if (n < 1 || n > TN_GROUP_MAX || pr == nullptr) return RL_ERR_ARG;
   TnGroupProblem<T> g[TN_GROUP_MAX];
@@ -60,6 +85,14 @@ int realise_conv_nt(void* stream, int dtype, const realise_conv_geom* a, const v
   if (!ep || !ep->out || !a) return RL_ERR_ARG;
   if (dtype == REALISE_BF16) return gemm_nt_conv<bf16_t>(st, to_geom<bf16_t>(a), (const bf16_t*)B, ldb, M, N, K, to_epi<bf16_t>(ep));
   if (dtype == REALISE_F32) return gemm_nt_conv<float>(st, to_geom<float>(a), (const float*)B, ldb, M, N, K, to_epi<float>(ep));
+  return RL_ERR_ARG;
+}
+int realise_conv_dgrad_s2(void* stream, int dtype, const realise_conv_geom* a, const void* B_classes, int64_t ldb, int Cin,
+                          const realise_epilogue* ep) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!ep || !ep->out || !a) return RL_ERR_ARG;
+  if (dtype == REALISE_BF16) return conv_dgrad_s2<bf16_t>(st, a, (const bf16_t*)B_classes, ldb, Cin, ep);
+  if (dtype == REALISE_F32) return conv_dgrad_s2<float>(st, a, (const float*)B_classes, ldb, Cin, ep);
   return RL_ERR_ARG;
 }
 int realise_gemm_tn(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int P, int I, int J,
@@ -96,6 +129,7 @@ void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }
 void realise_set_tn_split(int n) { set_tn_split(n); }
 void realise_set_wgrad_group(int on) { set_wgrad_group(on); }
+void realise_set_dgrad_parity(int on) { set_dgrad_parity(on); }
 void realise_set_tn_variant(int v) { set_tn_variant(v); }
 void realise_set_nt_wide_epilogue(int on) { set_nt_wide_epilogue(on); }
 void realise_set_glyph_dedup(int on) { set_glyph_dedup(on); }

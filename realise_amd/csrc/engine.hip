@@ -29,6 +29,10 @@ void set_wgrad_overlap(int on) { g_wgrad_overlap = on; }
 // and fold the slabs afterwards.
 static int g_wgrad_group = 1;
 void set_wgrad_group(int on) { g_wgrad_group = on; }
+// Stride-2 data gradients of the glyph ResNet by input-pixel parity classes (default on): four class GEMMs over a quarter of the rows
+// with 1 / 2 / 2 / 4 taps instead of one GEMM over all rows with 9 taps of which 75 % are stride misses (zeros).
+static int g_dgrad_parity = 1;
+void set_dgrad_parity(int on) { g_dgrad_parity = on; }
 // Branch overlap (default on): the three branches of SpellBertPho2ResArch3 that are independent between the inputs and the gate
 // (models.py:816 bert, :818-827 pinyin GRU + pho_model, :829-838 glyph ResNet) - and their backward passes after the gate -
 // run on three HIP streams (the caller's + two engine-owned ones), forked and joined with events inside one engine call.  The
@@ -67,7 +71,7 @@ template <typename T> struct Engine : EngineBase {
 
   // ---------------------------------------------------------------- shadows (offsets in bytes)
   struct LayerSh { int64_t qkv_w, qkv_wT, ao_w, ao_wT, in_w, in_wT, out_w, out_wT; };
-  struct BlockSh { int64_t w1f, w1d, w2f, w2d, wsf, wsd; int cin_pad; };
+  struct BlockSh { int64_t w1f, w1d, w1p, w2f, w2d, wsf, wsd; int cin_pad; };
   std::vector<LayerSh> sh_bert, sh_pho, sh_out;
   BlockSh sh_blk[5];
   int64_t sh_cls_w = 0, sh_cls_wT = 0, sh_gru_hh = 0, sh_gru_hhT = 0, sh_glyph = 0;
@@ -202,6 +206,7 @@ template <typename T> struct Engine : EngineBase {
         s.cin_pad = pad8(o.cin);
         s.w1f = b.take((int64_t)o.cout * 9 * s.cin_pad * e);
         s.w1d = b.take((int64_t)s.cin_pad * 9 * o.cout * e);
+        s.w1p = b.take((int64_t)s.cin_pad * 9 * o.cout * e);
         s.w2f = b.take((int64_t)o.cout * 9 * o.cout * e);
         s.w2d = b.take((int64_t)o.cout * 9 * o.cout * e);
         s.wsf = b.take((int64_t)o.cout * s.cin_pad * e);
@@ -255,6 +260,11 @@ template <typename T> struct Engine : EngineBase {
         const BlockOff& o = L.blocks[k];
         const BlockSh& s = sh_blk[k];
         RL_TRY(conv_weight_shadow<T>(st, pp(o.w1), o.cout, o.cin, 9, s.cin_pad, s.cin_pad, sp<T>(s.w1f), sp<T>(s.w1d)));
+        {   // second data-gradient copy of the stride-2 conv with its taps stored parity class by parity class
+          TapOrder ord; ord.n = 9; int first = 0;
+          (void)conv_s2_class(3, 3, 1, 0, &first, ord.t);
+          RL_TRY(conv_weight_shadow<T>(st, pp(o.w1), o.cout, o.cin, 9, s.cin_pad, s.cin_pad, (T*)nullptr, sp<T>(s.w1p), ord));
+        }
         RL_TRY(conv_weight_shadow<T>(st, pp(o.w2), o.cout, o.cout, 9, o.cout, o.cout, sp<T>(s.w2f), sp<T>(s.w2d)));
         RL_TRY(conv_weight_shadow<T>(st, pp(o.ws), o.cout, o.cin, 1, s.cin_pad, s.cin_pad, sp<T>(s.wsf), sp<T>(s.wsd)));
       }
@@ -709,9 +719,30 @@ template <typename T> struct Engine : EngineBase {
         const int* in_bound = rbound(k - 1).rows_dev;
         T* dx = (d_out == wp<T>(pl.r_dx)) ? wp<T>(pl.r_dout) : wp<T>(pl.r_dx);
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = dx; ep.ldo = Cin;
-        RL_TRY(gemm_nt_conv<T>(st, geom(dc1, nullptr, Pin, a.Hin, a.Hout, Co, 3, 2, 1, 1, in_bound), sp<T>(s.w1d), 9 * Co, Pin, Cin, 9 * Co, ep));
-        ep.accumulate = 1;
-        RL_TRY(gemm_nt_conv<T>(st, geom(dcs, nullptr, Pin, a.Hin, a.Hout, Co, 1, 2, 0, 1, in_bound), sp<T>(s.wsd), Co, Pin, Cin, Co, ep));
+        int hsh = 0; while ((1 << hsh) < a.Hin) ++hsh;
+        if (g_dgrad_parity && (1 << hsh) == a.Hin && hsh >= 1) {
+          // by parity class of the input pixel: only the taps that reach it, a quarter of the rows per launch; the 1x1 stride-2
+          // shortcut reaches the (even, even) pixels only
+          ep.rm_hw_shift = 2 * hsh; ep.rm_w_shift = hsh;
+          for (int c = 0; c < 4; ++c) {
+            int first = 0;
+            int nt = conv_s2_class(3, 3, 1, c, &first, nullptr);
+            ConvLoader<T> g = geom(dc1, nullptr, Pin / 4, a.Hin, a.Hout, Co, 3, 2, 1, 1, in_bound);
+            g.par = c; ep.rm_par = c; ep.accumulate = 0;
+            if (a.Hout == 1) {      // 2x2 map under a 1x1 output: pixel (py, px) is reached by tap (py + 1, px + 1) alone
+              g.tap_sel = ((c >> 1) + 1) * 3 + (c & 1) + 1;
+              first = conv_s2_slot(3, 3, 1, (c >> 1) + 1, (c & 1) + 1); nt = 1;
+            }
+            RL_TRY(gemm_nt_conv<T>(st, g, sp<T>(s.w1p) + (int64_t)first * Co, 9 * Co, Pin / 4, Cin, nt * Co, ep));
+          }
+          ConvLoader<T> g = geom(dcs, nullptr, Pin / 4, a.Hin, a.Hout, Co, 1, 2, 0, 1, in_bound);
+          g.par = 0; ep.rm_par = 0; ep.accumulate = 1;
+          RL_TRY(gemm_nt_conv<T>(st, g, sp<T>(s.wsd), Co, Pin / 4, Cin, Co, ep));
+        } else {
+          RL_TRY(gemm_nt_conv<T>(st, geom(dc1, nullptr, Pin, a.Hin, a.Hout, Co, 3, 2, 1, 1, in_bound), sp<T>(s.w1d), 9 * Co, Pin, Cin, 9 * Co, ep));
+          ep.accumulate = 1;
+          RL_TRY(gemm_nt_conv<T>(st, geom(dcs, nullptr, Pin, a.Hin, a.Hout, Co, 1, 2, 0, 1, in_bound), sp<T>(s.wsd), Co, Pin, Cin, Co, ep));
+        }
         d_out = dx;
       }
     }

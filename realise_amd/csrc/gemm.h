@@ -24,6 +24,9 @@ template <typename T> struct EpiParams {
   int accumulate = 0;
   uint32_t drop_seed = 0, drop_thresh = 0;
   float drop_scale = 1.0f;
+  // optional output-row map (stride-2 data gradients computed per input-pixel parity class): GEMM row r of the class is pixel
+  // (n, 2*yy + py, 2*xx + px) of an [N][2^(hw-w)][2^w] map, r = (n, yy, xx) over the half-resolution grid; rm_hw_shift < 0: identity
+  int rm_hw_shift = -1, rm_w_shift = 0, rm_par = 0;
   int wide = 0;                 // set by the launcher: rows are 8-element aligned -> LDS-staged epilogue, 16 B per lane
   int probe = 0;                // diagnostics (tools/nt_probe.cpp): 1 all tiles fetch tile 0, 2 no fetches, 3 no MFMA
 };
@@ -61,11 +64,28 @@ template <typename T> struct ConvLoader {
   int rows, Hr, Wr, Hs, Ws, C, KH, KW, stride, pad, mode, K;
   int hw_shift, w_shift;      // log2(Hr*Wr), log2(Wr) when both are powers of two, else -1 (set by finalize())
   const int* rows_dev = nullptr;   // optional device-side row bound (glyph dedup: #distinct ids * pixels per image)
+  // Parity-class form of a stride-2 data gradient (mode 1, 32-bit addressing only): par = 2*py + px in 0..3 restricts the rows to the
+  // input pixels (2*yy + py, 2*xx + px) - rows = N * Hr/2 * Wr/2 - and K to the taps that can reach such a pixel,
+  // kh = kh0 + 2i < KH with kh0 = (py + pad) & 1 (3x3 pad 1: one tap for an even coordinate, two for an odd one), so no fetched tap
+  // is a stride miss: 1 + 2 + 2 + 4 = 9 tap-GEMMs over a quarter of the rows each instead of 9 over all rows (4x less work).
+  // The B operand must hold the taps of a class contiguously (conv_s2_class()).  Hr, Wr powers of two.
+  int par = -1;
+  int tap_sel = -1;                                // class reduced to ONE tap kh * KW + kw (a 2x2 map under a 1x1 output: pixel (y, x) is
+                                                   // reached by tap (y + pad, x + pad) only); the B operand then points at that tap's slot
+  int kh0 = 0, kw0 = 0, nkw = 1, kstep = 1;        // set by finalize()
   struct Ctx { const T* img; int y, x; };
   struct KPos { int kh, kw, ch, k; };
-  __device__ __forceinline__ void clamp_rows() { if (rows_dev != nullptr) rows = min(rows, *rows_dev); }
+  __device__ __forceinline__ void clamp_rows() { if (rows_dev != nullptr) rows = min(rows, par >= 0 ? (*rows_dev >> 2) : *rows_dev); }
   void finalize() {
     K = KH * KW * C;
+    kh0 = kw0 = 0; nkw = KW; kstep = 1;
+    if (par >= 0) {
+      kh0 = ((par >> 1) + pad) & 1; kw0 = ((par & 1) + pad) & 1; kstep = 2;
+      int nkh = kh0 < KH ? (KH - kh0 + 1) / 2 : 0;
+      nkw = kw0 < KW ? (KW - kw0 + 1) / 2 : 0;
+      if (tap_sel >= 0) { kh0 = tap_sel / KW; kw0 = tap_sel - kh0 * KW; nkh = 1; nkw = 1; }
+      K = nkh * nkw * C;
+    }
     hw_shift = w_shift = -1;
     const int hw = Hr * Wr;
     if (hw > 0 && (hw & (hw - 1)) == 0 && (Wr & (Wr - 1)) == 0) {
@@ -114,7 +134,10 @@ template <typename T> struct ConvLoader {
     Row32 r; r.off = 0u; r.y0 = -(1 << 24); r.x0 = -(1 << 24);          // out of range: every tap fails the bounds test
     if (row < rows) {
       int n, rem, y, x;
-      if (hw_shift >= 0) {
+      if (par >= 0) {
+        n = row >> (hw_shift - 2); rem = row & ((1 << (hw_shift - 2)) - 1);
+        y = ((rem >> (w_shift - 1)) << 1) + (par >> 1); x = ((rem & ((1 << (w_shift - 1)) - 1)) << 1) + (par & 1);
+      } else if (hw_shift >= 0) {
         n = row >> hw_shift; rem = row & ((1 << hw_shift) - 1);
         y = rem >> w_shift; x = rem & ((1 << w_shift) - 1);
       } else {
@@ -139,13 +162,14 @@ template <typename T> struct ConvLoader {
   __device__ __forceinline__ Tap32 tap32(int k) const {
     Tap32 q; q.k = k;
     const int tap = k / C;
-    q.ch = k - tap * C; q.kh = tap / KW; q.kw = tap - q.kh * KW;
+    const int i = tap / nkw;
+    q.ch = k - tap * C; q.kh = kh0 + i * kstep; q.kw = kw0 + (tap - i * nkw) * kstep;
     tap_offset(q);
     return q;
   }
   __device__ __forceinline__ void advance32(Tap32& q, int dk) const {
     q.k += dk; q.ch += dk;
-    while (q.ch >= C) { q.ch -= C; if (++q.kw == KW) { q.kw = 0; ++q.kh; } }
+    while (q.ch >= C) { q.ch -= C; q.kw += kstep; if (q.kw >= KW) { q.kw = kw0; q.kh += kstep; } }
     tap_offset(q);
   }
   __device__ __forceinline__ uint32_t voff32(const Row32& r, const Tap32& q) const {
@@ -188,6 +212,32 @@ template <typename T> struct ConvLoader {
     return (const void*)(c.img + ((int64_t)(sy * Ws + sx) * C + q.ch));
   }
 };
+
+// Stride-2 data gradient by parity classes: class c = 2*py + px of a KH x KW / pad convolution uses the taps (kh0 + 2i, kw0 + 2j);
+// the dgrad weight copy stores the taps class by class (class 0's taps, then class 1's, ...), each class i-major.  Returns the
+// number of taps of class c, its first slot in that order, and (optionally) the original tap index of every slot.
+inline int conv_s2_class(int KH, int KW, int pad, int c, int* first_slot, int* order /* nullable, KH*KW entries */) {
+  int slot = 0, count = 0;
+  for (int cc = 0; cc < 4; ++cc) {
+    const int kh0 = ((cc >> 1) + pad) & 1, kw0 = ((cc & 1) + pad) & 1;
+    if (cc == c) { *first_slot = slot; }
+    int n = 0;
+    for (int kh = kh0; kh < KH; kh += 2)
+      for (int kw = kw0; kw < KW; kw += 2) { if (order) order[slot + n] = kh * KW + kw; ++n; }
+    if (cc == c) count = n;
+    slot += n;
+  }
+  return count;
+}
+
+// slot of original tap (kh, kw) in the class-ordered copy
+inline int conv_s2_slot(int KH, int KW, int pad, int kh, int kw) {
+  int order[64];
+  int first = 0;
+  (void)conv_s2_class(KH, KW, pad, 0, &first, order);
+  for (int s = 0; s < KH * KW; ++s) if (order[s] == kh * KW + kw) return s;
+  return -1;
+}
 
 // ---- TN (weight-gradient) epilogue ---------------------------------------------------------------
 enum TnMode { TN_PLAIN = 0, TN_CONVW = 1 };

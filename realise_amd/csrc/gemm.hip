@@ -460,6 +460,7 @@ int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la_, const T* B, int64_t l
   ConvLoader<T> la = la_;
   la.finalize();
   if (la.K != K) return RL_ERR_ARG;
+  if (la.par >= 0 && (la.par > 3 || la.mode != 1 || la.stride != 2 || la.hw_shift < 2 || la.w_shift < 1 || la.img_index != nullptr)) return RL_ERR_ARG;
   return launch_nt<T, ConvLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }
 // hipcc (ROCm 7.2) drops the implicit instantiation of the default-tile conv kernel once the kernel body holds the ConvRows

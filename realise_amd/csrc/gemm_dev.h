@@ -17,8 +17,18 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 }
 
 template <typename T>
+__device__ __forceinline__ int epi_row(const EpiParams<T>& ep, int row) {
+  if (ep.rm_hw_shift < 0) return row;
+  const int hs = ep.rm_hw_shift - 2, ws = ep.rm_w_shift - 1;
+  const int n = row >> hs, rem = row & ((1 << hs) - 1);
+  const int y = ((rem >> ws) << 1) + (ep.rm_par >> 1), x = ((rem & ((1 << ws) - 1)) << 1) + (ep.rm_par & 1);
+  return (n << ep.rm_hw_shift) + (y << ep.rm_w_shift) + x;
+}
+
+template <typename T>
 __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, int row, int col, floatx4 v) {
   if (row >= M || col >= N) return;
+  row = epi_row<T>(ep, row);
   if (ep.alpha != 1.0f) v *= ep.alpha;
   if (ep.bias != nullptr) v += *(const floatx4*)(ep.bias + col);
   switch (ep.mode) {
@@ -57,6 +67,7 @@ __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, 
 template <typename T>
 __device__ __forceinline__ void epilogue8(const EpiParams<T>& ep, int M, int N, int row, int col, floatx4 a, floatx4 b) {
   if (row >= M || col >= N) return;
+  row = epi_row<T>(ep, row);
   if (ep.alpha != 1.0f) { a *= ep.alpha; b *= ep.alpha; }
   if (ep.bias != nullptr) { a += *(const floatx4*)(ep.bias + col); b += *(const floatx4*)(ep.bias + col + 4); }
   T* o = ep.out + (int64_t)row * ep.ldo + col;

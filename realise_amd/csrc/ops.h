@@ -13,6 +13,10 @@ constexpr int COL_SLOT_FLOATS = 262144;   // >= (row chunks) x 2C for every laun
 constexpr int COL_SLOT_BYTES = COL_SLOT_FLOATS * 4;
 constexpr int LN_SLOT_FLOATS = 1024 * 2 * 1024;   // LayerNorm backward: one [dgamma | dbeta] record per workgroup (<= 1024 workgroups, H <= 1024)
 constexpr int LN_SLOT_BYTES = LN_SLOT_FLOATS * 4;
+// tap order of the data-gradient weight copy ([ci][slot][co]): n == 0 identity, else slot s holds original tap t[s] (stride-2 convs
+// store their taps parity class by parity class, conv_s2_class())
+struct TapOrder { int n = 0; int t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; };
+
 struct RowBound {
   const int* rows_dev = nullptr;
   const float* counts = nullptr;
@@ -185,7 +189,7 @@ struct CastDesc { const float* src; void* dst; void* dstT; int R, C; int tile_be
 template <typename T> int cast_transpose_multi(hipStream_t st, const CastDesc* descs, int n, int total_tiles);
 // conv weight [Co][Ci][KH][KW] fp32 -> fwd [Co][KH*KW][Cpad] and dgrad [Ci_rows][KH*KW][Co] (rows >= Ci zero)
 template <typename T>
-int conv_weight_shadow(hipStream_t st, const float* w, int Co, int Ci, int KHW, int Cpad, int CiRows, T* fwd, T* dgrad);
+int conv_weight_shadow(hipStream_t st, const float* w, int Co, int Ci, int KHW, int Cpad, int CiRows, T* fwd, T* dgrad, const TapOrder& order = TapOrder());
 // glyph table [V][F][HW] fp32 -> NHWC [V][HW][Cpad]
 template <typename T> int glyph_shadow(hipStream_t st, const float* tbl, int V, int F, int HW, int Cpad, T* out);
 

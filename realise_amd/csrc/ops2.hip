@@ -444,7 +444,7 @@ template int cast_transpose<float>(hipStream_t, const float*, int, int, float*, 
 
 template <typename T>
 __global__ void conv_weight_shadow_kernel(const float* __restrict__ w, int Co, int Ci, int KHW, int Cpad, int CiRows,
-                                          T* __restrict__ fwd, T* __restrict__ dgrad) {
+                                          T* __restrict__ fwd, T* __restrict__ dgrad, TapOrder order) {
   const int64_t nf = (int64_t)Co * KHW * Cpad, nd = (int64_t)CiRows * KHW * Co;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (int64_t)gridDim.x * blockDim.x) {
     if (i < nf) {
@@ -459,18 +459,20 @@ __global__ void conv_weight_shadow_kernel(const float* __restrict__ w, int Co, i
       const int co = (int)(k % Co);
       const int tap = (int)((k / Co) % KHW);
       const int ci = (int)(k / ((int64_t)Co * KHW));
-      dgrad[k] = from_f<T>(ci < Ci ? w[((int64_t)co * Ci + ci) * KHW + tap] : 0.f);
+      const int src_tap = order.n ? order.t[tap] : tap;          // slot `tap` of the data-gradient copy holds original tap order.t[tap]
+      dgrad[k] = from_f<T>(ci < Ci ? w[((int64_t)co * Ci + ci) * KHW + src_tap] : 0.f);
     }
   }
 }
 template <typename T>
-int conv_weight_shadow(hipStream_t st, const float* w, int Co, int Ci, int KHW, int Cpad, int CiRows, T* fwd, T* dgrad) {
+int conv_weight_shadow(hipStream_t st, const float* w, int Co, int Ci, int KHW, int Cpad, int CiRows, T* fwd, T* dgrad, const TapOrder& order) {
+  if (order.n != 0 && order.n != KHW) return RL_ERR_ARG;
   const int64_t n = (int64_t)Co * KHW * Cpad + (int64_t)CiRows * KHW * Co;
-  hipLaunchKernelGGL((conv_weight_shadow_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, w, Co, Ci, KHW, Cpad, CiRows, fwd, dgrad);
+  hipLaunchKernelGGL((conv_weight_shadow_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, w, Co, Ci, KHW, Cpad, CiRows, fwd, dgrad, order);
   return RL_LAUNCH_CHECK();
 }
-template int conv_weight_shadow<bf16_t>(hipStream_t, const float*, int, int, int, int, int, bf16_t*, bf16_t*);
-template int conv_weight_shadow<float>(hipStream_t, const float*, int, int, int, int, int, float*, float*);
+template int conv_weight_shadow<bf16_t>(hipStream_t, const float*, int, int, int, int, int, bf16_t*, bf16_t*, const TapOrder&);
+template int conv_weight_shadow<float>(hipStream_t, const float*, int, int, int, int, int, float*, float*, const TapOrder&);
 
 template <typename T>
 __global__ void glyph_shadow_kernel(const float* __restrict__ tbl, int64_t V, int F, int HW, int Cpad, T* __restrict__ out) {

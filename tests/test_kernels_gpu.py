@@ -201,7 +201,8 @@ def _geom(src, index, rows, Hr, Hs, Cc, k, stride, pad, mode):
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("Ci,Cp,Co,Hin,k,stride,pad,use_index", [
     (3, 8, 64, 32, 3, 2, 1, True), (3, 8, 64, 32, 1, 2, 0, True), (64, 64, 64, 16, 3, 1, 1, False),
-    (64, 64, 128, 16, 3, 2, 1, False), (128, 128, 256, 2, 3, 2, 1, False), (256, 256, 256, 1, 3, 1, 1, False)])
+    (64, 64, 128, 16, 3, 2, 1, False), (128, 128, 256, 2, 3, 2, 1, False), (256, 256, 256, 1, 3, 1, 1, False),
+    (64, 64, 128, 8, 1, 2, 0, False), (128, 128, 256, 4, 3, 2, 1, False)])
 def test_conv_forward_dgrad_wgrad(dt, Ci, Cp, Co, Hin, k, stride, pad, use_index):
     """implicit-im2col conv forward / input gradient / weight gradient vs torch.nn.functional.conv2d"""
     lib = _capi.load()
@@ -245,6 +246,24 @@ def test_conv_forward_dgrad_wgrad(dt, Ci, Cp, Co, Hin, k, stride, pad, use_index
         ep2 = epilogue(_capi.EPI_STORE, dx, Cp)
         _capi.check(lib.realise_conv_nt(stream(), code, C.byref(g2), P(wd_t), k * k * Co, Pin, Cp, k * k * Co, C.byref(ep2)), "conv dgrad")
         close(dx.view(N, Hin, Hin, Cp)[..., :Ci], xr.grad.permute(0, 2, 3, 1), tol, "conv dgrad")
+        if stride == 2 and Hin & (Hin - 1) == 0 and Hin >= 2:
+            # the same gradient by parity classes of the input pixel (realise_conv_dgrad_s2): class c = 2*py + px uses the taps
+            # kh = ((py + pad) & 1) + 2i, kw likewise; the weight copy holds the tap slots class by class
+            order = []
+            for c in range(4):
+                kh0, kw0 = ((c >> 1) + pad) & 1, ((c & 1) + pad) & 1
+                order += [kh * k + kw for kh in range(kh0, k, 2) for kw in range(kw0, k, 2)]
+            assert sorted(order) == list(range(k * k))
+            wd_c = wd[:, order, :].to(tdt).contiguous()
+            dx2 = torch.full((Pin, Cp), 7.0, device=dev(), dtype=tdt)
+            ep3 = epilogue(_capi.EPI_STORE, dx2, Cp)
+            if k == 1:                                   # only (even, even) pixels are reached: accumulate onto zeros
+                dx2.zero_()
+                ep3.accumulate = 1
+            _capi.check(lib.realise_conv_dgrad_s2(stream(), code, C.byref(g2), P(wd_c), k * k * Co, Cp, C.byref(ep3)), "conv dgrad by parity classes")
+            close(dx2.view(N, Hin, Hin, Cp)[..., :Ci], xr.grad.permute(0, 2, 3, 1), tol, "conv dgrad by parity classes")
+            if dt == "fp32" and k == 3:
+                assert torch.equal(dx2, dx), "class-wise and full-tap data gradients differ (same products, zero taps removed)"
     dw = torch.zeros((Co, Ci, k, k), device=dev())
     g3 = _geom(x_t, idx, Pn, Hout, Hin, Cp, k, stride, pad, 0)
     slab = torch.empty(4 * Co * k * k * Cp, device=dev())
