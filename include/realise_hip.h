@@ -220,6 +220,13 @@ int realise_engine_forward(realise_engine* e, void* stream, const realise_batch*
  * Runs buckets [first_bucket, last_bucket] of the backward pass (see realise_bucket_bounds) so a
  * caller can overlap the all-reduce of finished buckets; pass 0, -1 for the whole pass. */
 int realise_engine_backward(realise_engine* e, void* stream, int first_bucket, int last_bucket);
+/* The whole pass (as first_bucket = 0, last_bucket = -1: the three model branches on three streams, weight gradients deferred
+ * to the engine's side stream) that also tells a data-parallel caller when each gradient bucket is final: bucket_events[i]
+ * (n_events = realise_bucket_count hipEvent_t handles owned by the caller) is recorded on the stream that finishes bucket i;
+ * the caller's communication stream waits on it (hipStreamWaitEvent) and all-reduces the bucket while the rest of the backward
+ * runs - what DistributedDataParallel's gradient hooks do for run.py:165-167,200.  On return the caller's stream is ordered after
+ * the whole pass. */
+int realise_engine_backward_signalled(realise_engine* e, void* stream, void* const* bucket_events, int n_events);
 /* Glyph-only entry points (BASELINE configs[3], the glyph-CNN stress run): CharResNet.forward (src/char_cnn.py:46-55) on the
  * B*S glyph stacks char_images_multifonts[src_idx] (src/models.py:829-836), before resnet_layernorm.  res_out / d_res are
  * [B*S, 768] in the engine's compute dtype.  The workspace is sized with realise_engine_workspace_bytes(e, B, S, -1).

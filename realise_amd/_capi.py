@@ -95,6 +95,7 @@ SYMBOLS = {
     "realise_engine_invalidate_frozen": (None, [_P]),
     "realise_engine_forward": (_I, [_P, _P, C.POINTER(Batch)]),
     "realise_engine_backward": (_I, [_P, _P, _I, _I]),
+    "realise_engine_backward_signalled": (_I, [_P, _P, C.POINTER(C.c_void_p), _I]),
     "realise_engine_glyph_forward": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "realise_engine_glyph_backward": (_I, [_P, _P, _P]),
     "realise_engine_tap": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_L)]),

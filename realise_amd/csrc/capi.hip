@@ -268,6 +268,9 @@ int realise_engine_forward(realise_engine* e, void* stream, const realise_batch*
 int realise_engine_backward(realise_engine* e, void* stream, int first_bucket, int last_bucket) {
   return e ? e->impl->backward((hipStream_t)stream, first_bucket, last_bucket) : RL_ERR_ARG;
 }
+int realise_engine_backward_signalled(realise_engine* e, void* stream, void* const* bucket_events, int n_events) {
+  return e ? e->impl->backward_signalled((hipStream_t)stream, bucket_events, n_events) : RL_ERR_ARG;
+}
 int realise_engine_glyph_forward(realise_engine* e, void* stream, const int64_t* src_idx, int B, int S, int training, void* res_out) {
   return e ? e->impl->glyph_forward((hipStream_t)stream, src_idx, B, S, training, res_out) : RL_ERR_ARG;
 }

@@ -19,6 +19,7 @@ struct EngineBase {
   virtual void invalidate_frozen() = 0;
   virtual int forward(hipStream_t st, const realise_batch& b) = 0;
   virtual int backward(hipStream_t st, int first, int last) = 0;
+  virtual int backward_signalled(hipStream_t st, void* const* bucket_events, int n_events) = 0;
   virtual int glyph_forward(hipStream_t st, const int64_t* ids, int B, int S, int training, void* res_out) = 0;
   virtual int glyph_backward(hipStream_t st, const void* d_res) = 0;
   virtual int get_tap(const char* name, void** ptr, int64_t* numel) = 0;

@@ -141,6 +141,7 @@ template <typename T> struct Engine : EngineBase {
       for (int p = 0; p < 2; ++p) { for (int k = 0; k < 4; ++k) (void)hipEventDestroy(ev_ready[p][k]); (void)hipEventDestroy(ev_done[p]); }
       (void)hipStreamDestroy(side);
     }
+    for (int i = 0; i < 8; ++i) if (ev_sig[i] != nullptr) (void)hipEventDestroy(ev_sig[i]);
   }
   // branch overlap: two engine-owned streams next to the caller's, fork / join events
   hipStream_t bst[2] = {nullptr, nullptr};
@@ -986,6 +987,55 @@ template <typename T> struct Engine : EngineBase {
   }
 
   bool branch_mode = false;
+  // Whole backward pass with a "bucket final" signal per gradient bucket: evs[i] (caller-owned hipEvent_t) is recorded once every
+  // kernel that writes into bucket i has been enqueued, on the stream that runs last for that bucket - so a data-parallel caller can
+  // start the all-reduce of bucket i on its own stream (hipStreamWaitEvent) while the three model branches and the deferred weight
+  // gradients keep running.  The per-bucket form of backward() would serialise the branches and join the weight-gradient stream at
+  // every bucket boundary.
+  hipEvent_t ev_sig[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int signal_bucket(void* ev, hipStream_t s, bool through_side, int slot) {
+    hipEvent_t e = (hipEvent_t)ev;
+    if (through_side && g_wgrad_overlap && side_ok()) {      // the bert branch: its weight gradients finish on the side stream
+      if (ev_sig[slot] == nullptr && hipEventCreateWithFlags(&ev_sig[slot], hipEventDisableTiming) != hipSuccess) return RL_ERR_LAUNCH;
+      if (hipEventRecord(ev_sig[slot], s) != hipSuccess || hipStreamWaitEvent(side, ev_sig[slot], 0) != hipSuccess ||
+          hipEventRecord(e, side) != hipSuccess) return RL_ERR_LAUNCH;
+      return RL_OK;
+    }
+    return hipEventRecord(e, s) == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+  }
+  int backward_signalled(hipStream_t st, void* const* evs, int n_events) override {
+    if (!have_fwd) { fprintf(stderr, "[realise_hip] backward without a training forward (tgt_idx + want_dlogits)\n"); return RL_ERR_ARG; }
+    const int n = n_stages();
+    if (n_events != n || evs == nullptr || n > 8) return RL_ERR_ARG;
+    for (int i = 0; i < n; ++i) if (evs[i] == nullptr) return RL_ERR_ARG;
+    cs = 0;
+    if (cfg.model_type == 1 && g_branch_overlap && branches_ok()) {
+      branch_mode = true;
+      int rc = stage_out_block(st);
+      if (rc == RL_OK) rc = signal_bucket(evs[0], st, true, 0);
+      if (rc == RL_OK) rc = stage_gate(st);
+      if (rc == RL_OK) rc = fork(st);
+      if (rc == RL_OK) { cs = 2; rc = stage_glyph(bst[1]); }
+      if (rc == RL_OK) rc = signal_bucket(evs[1], bst[1], false, 1);          // gate (before the fork) + glyph ResNet
+      if (rc == RL_OK) { cs = 1; rc = stage_pho(bst[0]); }
+      if (rc == RL_OK) rc = signal_bucket(evs[2], bst[0], false, 2);
+      cs = 0;
+      for (int g = 0; rc == RL_OK && g <= L.bert_groups; ++g) {
+        rc = stage_bert(st, g);
+        if (rc == RL_OK) rc = signal_bucket(evs[3 + g], st, true, 3 + g);
+      }
+      const int rj = join(st);
+      const int rs = join_side(st);
+      branch_mode = false;
+      return rc != RL_OK ? rc : (rj != RL_OK ? rj : rs);
+    }
+    for (int s = 0; s < n; ++s) {
+      RL_TRY(run_stage(st, s));
+      RL_TRY(join_side(st));
+      RL_TRY(signal_bucket(evs[s], st, false, s));
+    }
+    return RL_OK;
+  }
   int backward(hipStream_t st, int first, int last_stage) override {
     if (!have_fwd) { fprintf(stderr, "[realise_hip] backward without a training forward (tgt_idx + want_dlogits)\n"); return RL_ERR_ARG; }
     const int n = n_stages();

@@ -34,6 +34,24 @@ class _GradSync:
         else:
             self.works.append((i, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
+    # ---- event-driven form: the engine runs the whole (branch-overlapped) backward in one call and records events[i] when
+    # bucket i is final; the communication stream waits on each event in a FIXED order (identical on every rank, as the
+    # collectives require) and all-reduces the bucket while the rest of the backward runs.
+    def bucket_events(self):
+        if self.stream is None:
+            return None
+        if getattr(self, "events", None) is None:
+            self.events = [torch.cuda.Event() for _ in self.buckets]
+            for e in self.events:
+                e.record()                                  # forces the handle into existence
+        return self.events
+
+    def buckets_signalled(self, order):
+        with torch.cuda.stream(self.stream):
+            for i in order:
+                self.stream.wait_event(self.events[i])
+                self._launch(i)
+
     def bucket_ready(self, i):
         if self.stream is not None:
             ev = torch.cuda.Event()

@@ -88,6 +88,7 @@ class RealiseModule(nn.Module):
         self._step_seed = int(seed) * 1000003 + 12345
         self.assume_unit_loss_grad = False
         self.grad_sync = None               # optional object with bucket_ready(i) / finish(), set by the DDP wrapper
+        self.signalled_backward = os.environ.get("REALISE_SIGNALLED_BACKWARD", "1") != "0"    # DDP: one-call backward + bucket events
         self._last = None
         # ---- arenas (CPU first, like the reference: Model(config) -> load -> .to(device)) ----
         self._arenas = [torch.zeros(max(self._sizes[0], 1), dtype=torch.float32),
@@ -518,11 +519,26 @@ class RealiseModule(nn.Module):
         if self.grad_sync is None:
             _capi.check(lib.realise_engine_backward(self._engine, st, 0, -1), "realise_engine_backward")
         else:
-            for i in range(n):
-                _capi.check(lib.realise_engine_backward(self._engine, st, i, i), "realise_engine_backward")
-                self.grad_sync.bucket_ready(i)
+            events = self.grad_sync.bucket_events() if hasattr(self.grad_sync, "bucket_events") else None
+            if events is not None and self.signalled_backward:
+                # one engine call (three branch streams + deferred weight gradients stay overlapped); the engine records a "bucket
+                # final" event per bucket and the communication stream all-reduces them in a fixed order as they complete
+                import ctypes as _C
+                handles = (_C.c_void_p * n)(*[_C.c_void_p(e.cuda_event) for e in events])
+                _capi.check(lib.realise_engine_backward_signalled(self._engine, st, handles, n), "realise_engine_backward_signalled")
+                self.grad_sync.buckets_signalled(self._bucket_comm_order(n))
+            else:
+                for i in range(n):
+                    _capi.check(lib.realise_engine_backward(self._engine, st, i, i), "realise_engine_backward")
+                    self.grad_sync.bucket_ready(i)
             self.grad_sync.finish()
         self._attach_grads()
+
+    @staticmethod
+    def _bucket_comm_order(n):
+        """order in which the buckets are all-reduced (the same on every rank).  arch3: output_block first, then the bert groups
+        interleaved with the shorter pinyin and glyph branches that run next to them, the embeddings (+ tied classifier) last"""
+        return [0, 3, 2, 4, 1, 5, 6] if n == 7 else list(range(n))
 
     def tap_dlogits(self):
         return self.tap("dlogits")

@@ -20,8 +20,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, signalled):
     try:
+        os.environ["REALISE_SIGNALLED_BACKWARD"] = signalled
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -64,11 +65,14 @@ def _worker(rank, world, port, q):
             dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_bucketed_allreduce_matches_reference():
+@pytest.mark.parametrize("signalled", ["1", "0"])
+def test_two_ranks_one_gpu_bucketed_allreduce_matches_reference(signalled):
+    """signalled = 1: one-call branch-overlapped backward + per-bucket 'final' events (the default under DDP);
+    0: one engine call per bucket"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, signalled)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
