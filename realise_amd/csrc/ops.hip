@@ -90,30 +90,37 @@ template int ln_fwd<float>(hipStream_t, const LnFwdArgs<float>&);
 // partials are kept in registers across a grid-stride loop over rows, reduced through LDS, then
 // one atomicAdd per column per workgroup.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NV>
 __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
-  __shared__ float red[2][4][LN_MAXV * 256];
+  __shared__ float red[2][4][NV * 256];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int H = a.H;
-  floatx4 dg[LN_MAXV], db[LN_MAXV], gm[LN_MAXV];
+  floatx4 dg[NV], db[NV], gm[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     dg[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     db[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     const int c = (i * 64 + lane) * 4;
     gm[i] = c < H ? *(const floatx4*)(a.gamma + c) : floatx4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
-    floatx4 dy[LN_MAXV], xh[LN_MAXV];
-    float s1 = 0.f, s2 = 0.f;
+  auto load_row = [&](int row, floatx4 (&dy)[NV], floatx4 (&xh)[NV]) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       dy[i] = floatx4{0.f, 0.f, 0.f, 0.f};
       xh[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-      if (c < H) {
+      if (c < H && row < a.rows) {
         dy[i] = load4<T>(a.dy + (int64_t)row * H + c);
         xh[i] = load4<T>(a.xhat + (int64_t)row * H + c);
+      }
+    }
+  };
+  auto do_row = [&](int row, floatx4 (&dy)[NV], floatx4 (&xh)[NV]) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           dy[i][j] *= drop_mult(a.in_drop.seed, a.in_drop.thresh, a.in_drop.scale,
@@ -130,7 +137,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
     s2 = wave_sum(s2) / (float)H;
     const float rstd = a.rstd[row];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < H) {
         floatx4 dx, dxd;
@@ -144,17 +151,27 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
         if (a.dx_drop != nullptr) store4<T>(a.dx_drop + (int64_t)row * H + c, dxd);
       }
     }
+  };
+  // two rows of a wave in flight: both rows' loads are issued before either row's reductions (one row at a time left the kernel at
+  // 1.9 TB/s: load, two wave reductions, store, and only then the next row's loads)
+  const int stride = gridDim.x * 4;
+  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += 2 * stride) {
+    floatx4 dy0[NV], xh0[NV], dy1[NV], xh1[NV];
+    load_row(row, dy0, xh0);
+    load_row(row + stride, dy1, xh1);
+    do_row(row, dy0, xh0);
+    if (row + stride < a.rows) do_row(row + stride, dy1, xh1);
   }
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[0][wave][c + j] = dg[i][j]; red[1][wave][c + j] = db[i][j]; }
   }
   __syncthreads();
   // With scratch: this workgroup's [dgamma | dbeta] partial goes to its own record as plain stores and ln_fold_kernel adds the
-  // records in a fixed order - no atomics (1024 workgroups x 1536 float atomics were ~10 us of this kernel), no zero-fill,
-  // bitwise reproducible.  Without scratch (few rows, C-ABI callers): atomics straight into the gradients.
+  // records in a fixed order - no atomics, no zero-fill, bitwise reproducible.  Without scratch (few rows, C-ABI callers):
+  // atomics straight into the gradients.
   float* rec = a.slots != nullptr ? a.slots + (int64_t)blockIdx.x * 2 * H : nullptr;
   for (int c = threadIdx.x; c < H; c += 256) {
     const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
@@ -191,10 +208,15 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
   if (a.rows <= 0) return RL_OK;
   if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
   int blocks = (a.rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;          // 4096 waves: two rows each at config 2 (memory-level parallelism; 112 VGPRs -> 4 waves/SIMD)
+  const int cap = a.H <= 512 ? 1024 : 768;   // resident workgroups: 4 (<= 110 VGPRs) or 3 (146 VGPRs with two rows in flight) waves per SIMD x 256 CUs
+  if (blocks > cap) blocks = cap;
   LnBwdArgs<T> b = a;
   if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr;
-  hipLaunchKernelGGL((ln_bwd_kernel<T>), dim3(blocks), dim3(256), 0, st, b);
+  const int nv = (a.H + 255) / 256;
+  if (nv == 1) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, b);
+  else if (nv == 2) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, b);
+  else if (nv == 3) hipLaunchKernelGGL((ln_bwd_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, b);
+  else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, b);
   if (b.slots != nullptr) hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * a.H / 4 + 3) / 4), dim3(256), 0, st, b.slots, blocks, a.H, a.dgamma, a.dbeta);
   return RL_LAUNCH_CHECK();
 }
@@ -229,12 +251,13 @@ __global__ void embed_bwd_kernel(const T* __restrict__ de, const int64_t* __rest
     }
   }
   if (quad_is_zero(acc)) return;
-  float* p = pos_grad + (int64_t)(pos_zero ? 0 : s) * H + c;
+  // The token-type row (every token adds to it) and, with position_ids == 0, the single position row are plain column sums of de:
+  // they come from a column reduction (embed_bwd below) - as per-block atomics they were a 1024-way pile-up on 768 addresses
+  // (~80 of this kernel's 117 us).
+  if (pos_zero) return;
+  float* p = pos_grad + (int64_t)s * H + c;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    atomicAdd(p + j, acc[j]);
-    atomicAdd(type_grad + c + j, acc[j]);
-  }
+  for (int j = 0; j < 4; ++j) atomicAdd(p + j, acc[j]);
 }
 template <typename T>
 int embed_bwd(hipStream_t st, const T* de, const int64_t* ids, int B, int S, int H, float* word_grad, float* pos_grad,
@@ -242,9 +265,12 @@ int embed_bwd(hipStream_t st, const T* de, const int64_t* ids, int B, int S, int
   if (H & 3) return RL_ERR_ARG;
   const int tx = 64;
   const int bz = B >= 32 ? 8 : (B >= 8 ? 4 : 1);
-  hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3((H / 4 + tx - 1) / tx, S, bz), dim3(tx), 0, st, de, ids, B, S, H, word_grad,
-                     pos_grad, pos_zero, type_grad);
-  return RL_LAUNCH_CHECK();
+  if (word_grad != nullptr || !pos_zero)
+    hipLaunchKernelGGL((embed_bwd_kernel<T>), dim3((H / 4 + tx - 1) / tx, S, bz), dim3(tx), 0, st, de, ids, B, S, H, word_grad,
+                       pos_grad, pos_zero, type_grad);
+  int rc = bias_grad<T>(st, de, H, B * S, H, type_grad, nullptr);
+  if (rc == RL_OK && pos_zero) rc = bias_grad<T>(st, de, H, B * S, H, pos_grad, nullptr);
+  return rc != RL_OK ? rc : RL_LAUNCH_CHECK();
 }
 template int embed_bwd<bf16_t>(hipStream_t, const bf16_t*, const int64_t*, int, int, int, float*, float*, int, float*);
 template int embed_bwd<float>(hipStream_t, const float*, const int64_t*, int, int, int, float*, float*, int, float*);
