@@ -620,12 +620,10 @@ template <typename T> struct Engine : EngineBase {
   int bn_forward(hipStream_t st, const T* x, int Pn, int C, const BnOff& o, const BnAct& a, const RowBound& rb) {
     if (last.training) {
       float* sums = wp<float>(pl.bn_sums);
-      RL_TRY(col_sum<T>(st, x, Pn, C, sums, rb));
-      RL_TRY(bn_finalize_mean(st, sums, C, Pn, wp<float>(a.mean)));
+      RL_TRY(col_sum<T>(st, x, Pn, C, wp<float>(a.mean), rb, 1.0f / (float)Pn));          // the fold writes the mean directly
       RL_TRY(col_sumsq_centered<T>(st, x, Pn, C, wp<float>(a.mean), sums + C, rb));
       RL_TRY(bn_finalize_train(st, wp<float>(a.mean), sums + C, C, Pn, pp(o.g), pp(o.b), 1e-5f, 0.1f, BF + o.rmean, BF + o.rvar,
-                               wp<float>(a.rstd), wp<float>(a.scale), wp<float>(a.shift)));
-      RL_TRY(add_i64(st, BI + o.nbt, 1, 1));
+                               wp<float>(a.rstd), wp<float>(a.scale), wp<float>(a.shift), BI + o.nbt));
     } else {
       RL_TRY(bn_finalize_eval(st, C, pp(o.g), pp(o.b), 1e-5f, BF + o.rmean, BF + o.rvar, wp<float>(a.scale), wp<float>(a.shift)));
     }

@@ -302,7 +302,8 @@ void set_nt8_group_m(int g);       // tile order of the 8-wave NT kernels: 0/1 r
 bool tn8_supported(int64_t lda, int64_t ldb, int P, int I, int J, const TnEpi& ep);
 int gemm_tn8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int P, int I, int J, const TnEpi& ep, int force_split);
 void tn_fold_launch(hipStream_t st, const TnEpi& ep, int nsplit, int I, int J);     // out += alpha * sum of the split slabs, fixed order
-void set_tn_variant(int v);               // 0 production, 9 force the 4-wave TN kernel
+void set_tn_variant(int v);
+void set_tn_group_ring(int on);     // grouped TN: 0 two full stages (default), 1 four stages of half-height K-tiles (measured 11 % slower)               // 0 production, 9 force the 4-wave TN kernel
 
 void set_tn_transpose_read(int use_tr);
 void set_nt_wide_epilogue(int on);        // A/B knob: LDS-staged 16-B-per-lane epilogue (default on)

@@ -510,14 +510,17 @@ template <typename T, int NB> struct ConvTaps<ConvLoader<T>, NB> {
 };
 
 // One (split, tile) of a TN problem; `logical` = split * ntiles + tile.
-template <typename T, typename BLoader, bool TR, int WI, int WJ>
+// NST LDS stages of BP = TnGeo::BP / BPD reduction rows each (default: 2 stages of full tiles; the grouped kernel runs 4 stages of half
+// tiles in the same 64 KB: three tiles in flight per workgroup instead of one).
+template <typename T, typename BLoader, bool TR, int WI, int WJ, int NST = 2, int BPD = 1>
 __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, int J, int tiles_j, int ntiles,
                                              int nsplit, int pchunk, int how, TnEpi ep, int logical) {
   typedef typename MmaOf<T>::type Mma;
   typedef TnGeo<T> G;
+  constexpr int BP = G::BP / BPD, KST = G::KSTEPS / BPD;
   constexpr int BI = 64 * WI, BJ = 64 * WJ;
   constexpr int RPA = BI * (int)sizeof(T), RPB = BJ * (int)sizeof(T);         // row pitches (bytes)
-  constexpr int A_BYTES = G::BP * RPA, B_BYTES = G::BP * RPB, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = BP * RPA, B_BYTES = BP * RPB, STAGE = A_BYTES + B_BYTES;
   constexpr int NA = A_BYTES / 4096, NB = B_BYTES / 4096;                     // 1-KiB instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
@@ -528,7 +531,7 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
   const int i0 = ti * BI, j0 = tj * BJ;
   lb.clamp_rows();
   const int Pe = min(P, lb.rows);                      // device-side row bound (glyph dedup): re-split the live rows evenly
-  if (Pe < P) pchunk = (((Pe + nsplit - 1) / nsplit + G::BP - 1) / G::BP) * G::BP;
+  if (Pe < P) pchunk = (((Pe + nsplit - 1) / nsplit + BP - 1) / BP) * BP;
   const int p_begin = split * pchunk;
   const int p_end = max(p_begin, min(Pe, p_begin + pchunk));
   const void* zero = (const void*)g_zero16;
@@ -585,7 +588,7 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
 #pragma unroll
   for (int q = 0; q < NA; ++q) {
     pa[q] = acol[q] != nullptr ? (const char*)(acol[q] + (int64_t)(p_begin + apl[q]) * lda) : (const char*)zero;
-    inca[q] = acol[q] != nullptr ? (int64_t)G::BP * lda * (int64_t)sizeof(T) : 0;
+    inca[q] = acol[q] != nullptr ? (int64_t)BP * lda * (int64_t)sizeof(T) : 0;
   }
   if constexpr (kDenseB) {
 #pragma unroll
@@ -596,13 +599,13 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
       const char* r1 = (const char*)lb.addr(c1, bq[q], zero);
       const int64_t ldb_bytes = r1 - r0;                                       // row pitch of the dense B operand
       pb[q] = bok[q] ? r0 + (int64_t)(p_begin + bpl[q]) * ldb_bytes : (const char*)zero;
-      incb[q] = bok[q] ? (int64_t)G::BP * ldb_bytes : 0;
+      incb[q] = bok[q] ? (int64_t)BP * ldb_bytes : 0;
     }
   }
   auto issue = [&](int pt, int stage) {
     if (ep.probe == 2) return;
     char* base = smem + stage * STAGE;
-    const bool full = pt + G::BP <= p_end;
+    const bool full = pt + BP <= p_end;
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const void* src = pa[q];
@@ -626,17 +629,30 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
     }
   };
 
-  if (p_begin < p_end) issue(p_begin, 0);
-  int cur = 0;
-  for (int pt = p_begin; pt < p_end; pt += G::BP) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (pt + G::BP < p_end) issue(pt + G::BP, cur ^ 1);
+  constexpr int NL = NA + NB;                          // fetch instructions per wave per tile
+  const int nt = (p_end - p_begin + BP - 1) / BP;
+  int issued = 0;
+  auto issue_next = [&]() {
+    if (issued < nt) { issue(p_begin + issued * BP, issued % NST); ++issued; }
+  };
+#pragma unroll
+  for (int q = 0; q < NST - 1; ++q) issue_next();
+  for (int t = 0; t < nt; ++t) {
+    // tile t has landed once at most the (issued - 1 - t) younger tiles' fetches are outstanding (counted vmcnt; raw barrier:
+    // __syncthreads() would drain vmcnt to 0)
+    const int younger = issued - 1 - t;
+    if (NST == 2 || younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (NST == 3 || younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_next();                                      // into the stage every wave finished reading before this barrier
+    const int cur = t % NST;
     const char* At = smem + cur * STAGE;
     const char* Bt = At + A_BYTES;
-    if (ep.probe == 3) { cur ^= 1; continue; }
+    if (ep.probe == 3) continue;
 #pragma unroll
-    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+    for (int ks = 0; ks < KST; ++ks) {
       typename Mma::Frag a[4], b[4];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
@@ -659,7 +675,6 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
         for (int f = 0; f < 4; ++f) csum[f] = Mma::mma(ones, a[f], csum[f]);   // every row of the result = sum_p A[p, i]
       }
     }
-    cur ^= 1;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -688,7 +703,7 @@ gemm_tn_kernel(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, i
 // 128x128 tile of one problem over the whole reduction (no split: nothing to fold).  The four weight gradients of a transformer
 // layer are 432 such tiles - one round of the chip's 512 workgroup slots - where launched one by one each needs a 3-4 way
 // reduction split (slab write + fold pass) to fill the chip: 8 launches and ~75 MB of slab traffic per layer become 1 launch.
-template <typename T, bool TR>
+template <typename T, bool TR, int NST, int BPD>
 __global__ void __launch_bounds__(256, 2)
 gemm_tn_group_kernel(TnGroup<T> grp, int P, int pchunk) {
   const int logical = xcd_remap(blockIdx.x, grp.total_tiles);
@@ -699,8 +714,8 @@ gemm_tn_group_kernel(TnGroup<T> grp, int P, int pchunk) {
   DenseLoader<T> lb{pr.B, pr.ldb, P, pr.J};
   TnEpi ep;
   ep.out = pr.out; ep.ldo = pr.ldo; ep.colsum = pr.colsum; ep.alpha = grp.alpha; ep.probe = grp.probe;
-  tn_tile_body<T, DenseLoader<T>, TR, 2, 2>(pr.A, pr.lda, lb, P, pr.I, pr.J, pr.tiles_j, pr.ntiles, 1, pchunk, TN_OUT_DIRECT, ep,
-                                            logical - pr.tile_begin);
+  tn_tile_body<T, DenseLoader<T>, TR, 2, 2, NST, BPD>(pr.A, pr.lda, lb, P, pr.I, pr.J, pr.tiles_j, pr.ntiles, 1, pchunk, TN_OUT_DIRECT, ep,
+                                                      logical - pr.tile_begin);
 }
 
 // out(mapped) += alpha * sum_s slab[s][i][j], in a fixed order (bitwise reproducible).
@@ -861,6 +876,9 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb,
 static int g_tn_variant = 0;      // 0 production (the 4-wave kernel), 8 the experimental 8-wave ping-pong kernel (gemm_tn8.hip: correct, 7-16 % slower)
 void set_tn_variant(int v) { g_tn_variant = v; }
 
+static int g_tn_group_ring = 0;      // measured: 4 x 32-row stages 3.76 ms/step vs 3.39 for 2 x 64-row stages (more barriers, smaller DMA batches)
+void set_tn_group_ring(int on) { g_tn_group_ring = on; }
+
 template <typename T>
 int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha) {
   typedef TnGeo<T> G;
@@ -883,15 +901,16 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
   const int pchunk = ((P + G::BP - 1) / G::BP) * G::BP;
   const size_t lds = 2 * (size_t)G::BP * 256 * sizeof(T);
   ProfScope ps(st, PK_GEMM_TN, flops);
-  if (sizeof(T) == 2 && g_tn_tr) {
-    static bool a1 = false;
-    if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
-    hipLaunchKernelGGL((gemm_tn_group_kernel<T, true>), dim3(total), dim3(256), lds, st, grp, P, pchunk);
-  } else {
-    static bool a2 = false;
-    if (!a2) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
-    hipLaunchKernelGGL((gemm_tn_group_kernel<T, false>), dim3(total), dim3(256), lds, st, grp, P, pchunk);
-  }
+  // ring: the 2 full stages of the single-problem kernel (default) or 4 stages of half tiles (three tiles in flight per workgroup,
+  // g_tn_group_ring = 1: built to test the fetch-latency hypothesis - 11 % slower)
+#define RL_TN_GROUP(TRV, NSTV, BPDV) do { \
+    static bool attr = false; \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<T, TRV, NSTV, BPDV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    hipLaunchKernelGGL((gemm_tn_group_kernel<T, TRV, NSTV, BPDV>), dim3(total), dim3(256), lds, st, grp, P, pchunk); } while (0)
+  const bool tr = sizeof(T) == 2 && g_tn_tr;
+  if (g_tn_group_ring) { if (tr) RL_TN_GROUP(true, 4, 2); else RL_TN_GROUP(false, 4, 2); }
+  else { if (tr) RL_TN_GROUP(true, 2, 1); else RL_TN_GROUP(false, 2, 1); }
+#undef RL_TN_GROUP
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 template int gemm_tn_group<bf16_t>(hipStream_t, int, const TnGroupProblem<bf16_t>*, int, float);

@@ -139,12 +139,13 @@ int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const floa
                   float* d_emb, float* d_w_ih, float* d_b_ih);
 
 // ---- BatchNorm over NHWC activations [P][C] (K9) -------------------------------------------------
-template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out, RowBound rb = RowBound());
+template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out, RowBound rb = RowBound(), float scale = 1.0f);   // scale != 1 needs rb.slots
 template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out, RowBound rb = RowBound());
 // train-mode finalize: stats -> (mean, rstd, scale, shift), running-stat update (unbiased var, momentum)
 int bn_finalize_mean(hipStream_t st, const float* sum, int C, int P, float* mean);
 int bn_finalize_train(hipStream_t st, const float* mean, const float* sqsum, int C, int P, const float* gamma, const float* beta,
-                      float eps, float momentum, float* running_mean, float* running_var, float* rstd, float* scale, float* shift);
+                      float eps, float momentum, float* running_mean, float* running_var, float* rstd, float* scale, float* shift,
+                      int64_t* num_batches_tracked = nullptr /* += 1 when given */);
 int bn_finalize_eval(hipStream_t st, int C, const float* gamma, const float* beta, float eps, const float* running_mean,
                      const float* running_var, float* scale, float* shift);
 // y = [relu]( x1*sc1 + sh1 [+ x2*sc2 + sh2] )

@@ -5,7 +5,7 @@
 #include "ops.h"
 
 namespace rl {
-__global__ void col_fold_kernel(float* __restrict__ slots, int slot_stride, int nrec, int n, float* out0, float* out1, int C, int overwrite, int clean);
+__global__ void col_fold_kernel(float* __restrict__ slots, int slot_stride, int nrec, int n, float* out0, float* out1, int C, int overwrite, int clean, float alpha);
 
 #define RL_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH)
 static constexpr int LN_MAXV = 4;   // up to 4 x (64 lanes x 4 elems) = 1024 columns per row
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(F f, int rows_max, int 
 // overwrite: out = sum (no zero-fill needed before the reduction); clean: the records are left zeroed (accumulator records that the
 // next launch adds into with atomics need no memset).
 __global__ void __launch_bounds__(256) col_fold_kernel(float* __restrict__ slots, int slot_stride, int nrec, int n, float* out0,
-                                                        float* out1, int C, int overwrite, int clean) {
+                                                        float* out1, int C, int overwrite, int clean, float alpha) {
   __shared__ floatx4 red[32][8];
   const int cq = threadIdx.x & 7, kl = threadIdx.x >> 3;
   const int i = (blockIdx.x * 8 + cq) * 4;                 // i in [0, n): n = C or 2C laid out [C | C], C % 4 == 0
@@ -350,13 +350,13 @@ __global__ void __launch_bounds__(256) col_fold_kernel(float* __restrict__ slots
   }
   if (kl == 0 && i < n) {
     float* o = i < C ? out0 + i : out1 + (i - C);
-    if (overwrite) *(floatx4*)o = red[0][cq];
-    else *(floatx4*)o += red[0][cq];
+    if (overwrite) *(floatx4*)o = red[0][cq] * alpha;
+    else *(floatx4*)o += red[0][cq] * alpha;
   }
 }
 template <typename F>
 static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float* out0, float* out1, RowBound rb = RowBound(),
-                             float* slots = nullptr) {
+                             float* slots = nullptr, float alpha = 1.0f) {
   if (rows <= 0 || C <= 0) return RL_OK;
   if (C & 3) return RL_ERR_ARG;
   int tpr_shift = 5;
@@ -375,8 +375,9 @@ static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float*
     if (gy < 1) return RL_ERR_ARG;
     hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, tpr_shift, out0, out1, rb, slots, stride);
     const int n = out1 ? 2 * C : C;
-    hipLaunchKernelGGL(col_fold_kernel, dim3((n + 31) / 32), dim3(256), 0, st, slots, stride, gy, n, out0, out1, C, 1, 0);     // OVERWRITES out0 / out1
+    hipLaunchKernelGGL(col_fold_kernel, dim3((n + 31) / 32), dim3(256), 0, st, slots, stride, gy, n, out0, out1, C, 1, 0, alpha);     // OVERWRITES out0 / out1
   } else {
+    if (alpha != 1.0f) return RL_ERR_ARG;        // the scaled form exists on the record + fold path only
     hipLaunchKernelGGL((col_reduce_kernel<F>), dim3(gx, gy), dim3(256), 0, st, f, rows, C, tpr_shift, out0, out1, rb, (float*)nullptr, 0);
   }
   return RL_LAUNCH_CHECK();
@@ -402,12 +403,12 @@ template <typename T> struct WSumF {
     a0 += load4<T>(x + (int64_t)r * ld + c) * rb_weight(rb, r);
   }
 };
-template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out, RowBound rb) {
+template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out, RowBound rb, float scale) {
   WSumF<T> f{x, (int64_t)C, rb};
-  return launch_col_reduce(st, f, P, C, out, nullptr, rb, rb.slots);
+  return launch_col_reduce(st, f, P, C, out, nullptr, rb, rb.slots, scale);
 }
-template int col_sum<bf16_t>(hipStream_t, const bf16_t*, int, int, float*, RowBound);
-template int col_sum<float>(hipStream_t, const float*, int, int, float*, RowBound);
+template int col_sum<bf16_t>(hipStream_t, const bf16_t*, int, int, float*, RowBound, float);
+template int col_sum<float>(hipStream_t, const float*, int, int, float*, RowBound, float);
 
 template <typename T> struct SumSqCF {
   const T* x; int64_t ld; const float* mean; RowBound rb;

@@ -205,8 +205,9 @@ int bn_finalize_mean(hipStream_t st, const float* sum, int C, int P, float* mean
   return RL_LAUNCH_CHECK();
 }
 __global__ void bn_train_kernel(const float* mean, const float* sqsum, int C, int P, const float* gamma, const float* beta,
-                                float eps, float momentum, float* rmean, float* rvar, float* rstd, float* scale, float* shift) {
+                                float eps, float momentum, float* rmean, float* rvar, float* rstd, float* scale, float* shift, int64_t* nbt) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt != nullptr) *nbt += 1;                               // num_batches_tracked
   if (c >= C) return;
   const float var = sqsum[c] / (float)P;                                 // biased: used to normalise
   const float unbiased = sqsum[c] / (float)(P > 1 ? P - 1 : 1);          // running_var update
@@ -218,9 +219,10 @@ __global__ void bn_train_kernel(const float* mean, const float* sqsum, int C, in
   rvar[c] = (1.0f - momentum) * rvar[c] + momentum * unbiased;
 }
 int bn_finalize_train(hipStream_t st, const float* mean, const float* sqsum, int C, int P, const float* gamma, const float* beta,
-                      float eps, float momentum, float* running_mean, float* running_var, float* rstd, float* scale, float* shift) {
+                      float eps, float momentum, float* running_mean, float* running_var, float* rstd, float* scale, float* shift,
+                      int64_t* num_batches_tracked) {
   hipLaunchKernelGGL(bn_train_kernel, dim3((C + 255) / 256), dim3(256), 0, st, mean, sqsum, C, P, gamma, beta, eps, momentum,
-                     running_mean, running_var, rstd, scale, shift);
+                     running_mean, running_var, rstd, scale, shift, num_batches_tracked);
   return RL_LAUNCH_CHECK();
 }
 __global__ void bn_eval_kernel(int C, const float* gamma, const float* beta, float eps, const float* rmean, const float* rvar,
@@ -269,7 +271,10 @@ template int bn_apply<float>(hipStream_t, const float*, const float*, const floa
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ relu_src, const T* __restrict__ x,
                                     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ sums, int P, int C, float inv_p, T* __restrict__ dx, RowBound rb) {
+                                    const float* __restrict__ sums, int P, int C, float inv_p, T* __restrict__ dx, RowBound rb,
+                                    float* dgamma, float* dbeta) {
+  if (blockIdx.x == 0 && dgamma != nullptr)            // parameter gradients ride along: dbeta += sum g, dgamma += sum g * xhat
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { dbeta[c] += sums[c]; dgamma[c] += sums[C + c]; }
   const int64_t n = (int64_t)rb_rows(rb, P) * C;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * blockDim.x * 4) {
     const int c = (int)(i % C);
@@ -296,8 +301,7 @@ int bn_bwd_apply(hipStream_t st, const T* dy, const T* relu_src, const T* x, con
   if (C & 3) return RL_ERR_ARG;
   const int64_t n = (int64_t)P * C;
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, dy, relu_src, x, mean, rstd, gamma,
-                     sums, P, C, 1.0f / (float)(n_stat > 0 ? n_stat : P), dx, rb);
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, C, dgamma, dbeta);
+                     sums, P, C, 1.0f / (float)(n_stat > 0 ? n_stat : P), dx, rb, dgamma, dbeta);
   return RL_LAUNCH_CHECK();
 }
 template int bn_bwd_apply<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, const float*, const float*, int, int, bf16_t*, float*, float*, RowBound, int);
