@@ -66,6 +66,7 @@ SYMBOLS = {
     "realise_set_tn_split": (None, [_I]),
     "realise_set_tn_variant": (None, [_I]),
     "realise_set_tn_group_ring": (None, [_I]),
+    "realise_set_conv_c64": (None, [_I]),
     "realise_set_attn_probe": (None, [_I]),
     "realise_set_branch_overlap": (None, [_I]),
     "realise_set_nt_wide_epilogue": (None, [_I]),
@@ -137,7 +138,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # A/B knobs for measurements (defaults are the production settings)
-    for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_WGRAD_GROUP", lib.realise_set_wgrad_group), ("REALISE_TN_GROUP_RING", lib.realise_set_tn_group_ring), ("REALISE_DGRAD_PARITY", lib.realise_set_dgrad_parity), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup),
+    for env, fn in (("REALISE_WGRAD_OVERLAP", lib.realise_set_wgrad_overlap), ("REALISE_WGRAD_GROUP", lib.realise_set_wgrad_group), ("REALISE_TN_GROUP_RING", lib.realise_set_tn_group_ring), ("REALISE_CONV_C64", lib.realise_set_conv_c64), ("REALISE_DGRAD_PARITY", lib.realise_set_dgrad_parity), ("REALISE_GLYPH_DEDUP", lib.realise_set_glyph_dedup),
                     ("REALISE_NT_VARIANT", lib.realise_set_nt_variant), ("REALISE_NT_GROUP_M", lib.realise_set_nt_group_m)):
         if os.environ.get(env) is not None:
             fn(int(os.environ[env]))

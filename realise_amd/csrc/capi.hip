@@ -132,6 +132,7 @@ void realise_set_wgrad_group(int on) { set_wgrad_group(on); }
 void realise_set_dgrad_parity(int on) { set_dgrad_parity(on); }
 void realise_set_tn_variant(int v) { set_tn_variant(v); }
 void realise_set_tn_group_ring(int on) { set_tn_group_ring(on); }
+void realise_set_conv_c64(int on) { set_conv_c64(on); }
 void realise_set_nt_wide_epilogue(int on) { set_nt_wide_epilogue(on); }
 void realise_set_glyph_dedup(int on) { set_glyph_dedup(on); }
 void realise_set_wgrad_overlap(int on) { set_wgrad_overlap(on); }

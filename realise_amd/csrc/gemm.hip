@@ -873,6 +873,8 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb,
   return launch_tn_tile<T, BLoader, 2, 2>(st, A, lda, lb, P, I, J, ep);
 }
 
+static int g_conv_c64 = 1;          // block-1 conv2 weight gradient through conv_wgrad_c64.hip (LDS-resident input tile)
+void set_conv_c64(int on) { g_conv_c64 = on; }
 static int g_tn_variant = 0;      // 0 production (the 4-wave kernel), 8 the experimental 8-wave ping-pong kernel (gemm_tn8.hip: correct, 7-16 % slower)
 void set_tn_variant(int v) { g_tn_variant = v; }
 
@@ -934,6 +936,14 @@ int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& l
   ConvLoader<T> lb = lb_;
   lb.finalize();
   if (lb.K != J) return RL_ERR_ARG;
+  if constexpr (sizeof(T) == 2) {
+    // 64 -> 64 channels, 3x3 / stride 1 / pad 1 on 16x16 maps (glyph ResNet block 1): the LDS-resident-input kernel
+    if (g_conv_c64 && g_tn_probe == 0 && lb.C == 64 && lb.KH == 3 && lb.KW == 3 && lb.stride == 1 && lb.pad == 1 && lb.mode == 0 && lb.Hr == 16 &&
+        lb.Wr == 16 && lb.Hs == 16 && lb.Ws == 16 && lb.img_index == nullptr && I == 64 && lda == 64 && P == lb.rows && (P % 256) == 0 &&
+        ep.mode == TN_CONVW && ep.Cin == 64 && ep.Cpad == 64 && ep.KHW == 9 && ep.tap0 == 0 && ep.alpha == 1.0f && ep.slab != nullptr &&
+        ep.slab_elems >= 64 * 576 && (int64_t)P * 128 < 0xFFFFFE00ll)
+      return conv_wgrad_c64(st, A, lb.src, P, lb.rows_dev, ep);
+  }
   return launch_tn<T, ConvLoader<T>>(st, A, lda, lb, P, I, J, ep);
 }
 template int gemm_tn<bf16_t>(hipStream_t, const bf16_t*, int64_t, const bf16_t*, int64_t, int, int, int, const TnEpi&, const int*);
