@@ -104,7 +104,7 @@ void realise_set_tn_probe(int mode);
 void realise_set_tn_split(int n);
 /* weight-gradient kernel selection: 0 production (8-wave 256x128-tile kernel for the big dense bf16 shapes), 9 force the 4-wave kernel */
 void realise_set_tn_variant(int v);
-void realise_set_conv_c64(int on);         /* 1 (default): the 64->64 channel 3x3 conv weight gradient on 16x16 maps runs the LDS-resident-input kernel */
+void realise_set_conv_c64(int on);         /* 1 (default): the 64->64 channel 3x3 conv on 16x16 maps (forward, input and weight gradient) runs the LDS-resident kernels */
 void realise_set_tn_group_ring(int on);    /* grouped weight gradients: 0 (default) two LDS stages of 64-row K-tiles, 1 four stages of 32 rows (measured 11 % slower) */
 /* Diagnostics for the attention forward kernel: 1 stop after operand staging, 2 skip the softmax (results WRONG). */
 void realise_set_attn_probe(int mode);

@@ -303,7 +303,8 @@ bool tn8_supported(int64_t lda, int64_t ldb, int P, int I, int J, const TnEpi& e
 int gemm_tn8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int P, int I, int J, const TnEpi& ep, int force_split);
 void tn_fold_launch(hipStream_t st, const TnEpi& ep, int nsplit, int I, int J);     // out += alpha * sum of the split slabs, fixed order
 void set_tn_variant(int v);
-void set_conv_c64(int on);          // 1 (default): 64-channel 3x3 s1 conv wgrad on 16x16 maps via the LDS-resident-input kernel
+void set_conv_c64(int on);          // 1 (default): 64-channel 3x3 s1 conv forward / dgrad / wgrad on 16x16 maps via the LDS-resident kernels
+int conv_c64_nt(hipStream_t st, const bf16_t* X, const bf16_t* Wt, bf16_t* out, int rows, const int* rows_dev, int flip);         // conv_c64_nt.hip
 int conv_wgrad_c64(hipStream_t st, const bf16_t* dY, const bf16_t* X, int rows, const int* rows_dev, const TnEpi& te);   // conv_wgrad_c64.hip
 void set_tn_group_ring(int on);     // grouped TN: 0 two full stages (default), 1 four stages of half-height K-tiles (measured 11 % slower)               // 0 production, 9 force the 4-wave TN kernel
 

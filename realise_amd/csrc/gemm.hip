@@ -233,6 +233,8 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
 static int g_nt_n96 = 1;             // allow 128x96 tiles (tuning / A-B knob)
 void set_nt_allow_n96(int on) { g_nt_n96 = on; }
 static int g_nt_probe = 0, g_nt_wide = 1, g_nt_variant = 0;
+static int g_conv_c64 = 1;          // block-1 conv2 (64 channels, 16x16 maps) through the LDS-resident kernels conv_c64_nt.hip / conv_wgrad_c64.hip
+void set_conv_c64(int on) { g_conv_c64 = on; }
 void set_nt_variant(int v) { g_nt_variant = v; }
 static int g_tn_probe = 0, g_tn_split = 0;
 void set_tn_split(int n) { g_tn_split = n; }
@@ -461,6 +463,14 @@ int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la_, const T* B, int64_t l
   la.finalize();
   if (la.K != K) return RL_ERR_ARG;
   if (la.par >= 0 && (la.par > 3 || la.mode != 1 || la.stride != 2 || la.hw_shift < 2 || la.w_shift < 1 || la.img_index != nullptr)) return RL_ERR_ARG;
+  if constexpr (sizeof(T) == 2) {
+    // 64 -> 64 channels, 3x3 / stride 1 / pad 1 on 16x16 maps (glyph ResNet block 1), plain store: the LDS-resident image + weights kernel
+    if (g_conv_c64 && g_nt_probe == 0 && la.par < 0 && la.C == 64 && la.KH == 3 && la.KW == 3 && la.stride == 1 && la.pad == 1 && la.mode <= 1 &&
+        la.Hr == 16 && la.Wr == 16 && la.Hs == 16 && la.Ws == 16 && la.img_index == nullptr && N == 64 && K == 576 && ldb == 576 &&
+        M == la.rows && (M % 256) == 0 && (int64_t)M * 128 < 0xFFFFFE00ll && ep.mode == EPI_STORE && ep.accumulate == 0 && ep.bias == nullptr &&
+        ep.out2 == nullptr && ep.alpha == 1.0f && ep.ldo == 64 && ep.rm_hw_shift < 0)
+      return conv_c64_nt(st, la.src, B, ep.out, M, la.rows_dev, la.mode);
+  }
   return launch_nt<T, ConvLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }
 // hipcc (ROCm 7.2) drops the implicit instantiation of the default-tile conv kernel once the kernel body holds the ConvRows
@@ -873,8 +883,6 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb,
   return launch_tn_tile<T, BLoader, 2, 2>(st, A, lda, lb, P, I, J, ep);
 }
 
-static int g_conv_c64 = 1;          // block-1 conv2 weight gradient through conv_wgrad_c64.hip (LDS-resident input tile)
-void set_conv_c64(int on) { g_conv_c64 = on; }
 static int g_tn_variant = 0;      // 0 production (the 4-wave kernel), 8 the experimental 8-wave ping-pong kernel (gemm_tn8.hip: correct, 7-16 % slower)
 void set_tn_variant(int v) { g_tn_variant = v; }
 
