@@ -4,6 +4,9 @@
 //   gemm_tn : C[I,J] += sum_p A[p,i] B[p,j]  (weight gradients, K14)
 // One code path for both numerics modes: T = bf16 (v_mfma_f32_16x16x32_bf16, speed mode) and
 // T = float (v_mfma_f32_16x16x4_f32, exact-fp32 parity mode).
+// Round 2: dense bf16 NT GEMMs with M >= 1024, N >= 256 go to the 8-wave kernels of gemm_nt8.hip (launch_nt routes); the four weight
+// gradients of a transformer layer go out as one grouped TN launch (gemm_tn_group); block-1 64-channel convolutions go to the
+// LDS-resident kernels (conv_c64_nt.hip, conv_wgrad_c64.hip); stride-2 data gradients run per parity class (ConvLoader::par).
 //
 // Structure (both kernels): 256-thread workgroup = WA x WB waves of a 64x64 output each (4x4 MFMA
 // tiles per wave).  Operand tiles go HBM -> LDS directly with global_load_lds_dwordx4 (no VGPR round

@@ -1,10 +1,15 @@
 // Ping-pong 8-wave NT GEMM for gfx950 (bf16 operands, K % 8 == 0, dense rows):  C[M,N] = A[M,K] . B[N,K]^T + fused epilogue.
 //
-// Why a second NT kernel: the LDS-DMA fill path delivers ~40 B/clk per CU whatever the tile shape, so the
-// FLOPs one fetched byte feeds - the workgroup tile - decide how close the MFMA pipe can get to its peak:
-//   128 x 128 (gemm.hip, two 4-wave workgroups per CU)   64 FLOP/B  -> fetch-bound at 62 % of the MFMA peak
-//   256 x 192 / 256 x 256 (this kernel, one per CU)      110 / 128  -> MFMA-bound
-// One 512-thread workgroup per CU, 2 waves per SIMD: waves 0-3 (group 0) and 4-7 (group 1) sit pairwise on the four SIMDs and
+// Why a second NT kernel: the LDS-DMA fill path delivers ~36-45 B/clk per CU whatever the tile shape, so the
+// FLOPs one fetched byte feeds - the workgroup tile - decide how far the fill is from binding:
+//   128 x 128 (gemm.hip, two 4-wave workgroups per CU)   64 FLOP/B
+//   128 x 192 (this kernel, TWO workgroups per CU)        77 FLOP/B   <- every layer GEMM (N < 4096): the second workgroup's MFMAs run
+//                                                                       under the first one's output write and fetch waits
+//   256 x 192 / 256 x 256 (this kernel, one per CU)      110 / 128     <- the 21128-wide classifier
+// Measured (tools/nt8_probe.cpp, profiles/round2_nt8_probe.log): MFMA, fill and output write are three comparable costs on the
+// K = 768 shapes; with the fragment reads the LDS is ~100 % busy (reads queue behind the DMA writes), which is why dedicated
+// loader waves (gemm_nt8ws_kernel below) change nothing, and the result sits level with hipBLASLt on the same shapes.
+// A 512-thread workgroup, 2 waves per SIMD: waves 0-3 (group 0) and 4-7 (group 1) sit pairwise on the four SIMDs and
 // run HALF A PHASE apart (group 1 executes one extra s_barrier up front), so on every SIMD one wave is in its MEMORY segment
 // (fragment ds_reads + its share of the LDS-DMA fetches + the counted vmcnt wait) while its partner is in its MFMA segment
 // (16 v_mfma_f32_16x16x32_bf16 on register-resident fragments, s_setprio 1).

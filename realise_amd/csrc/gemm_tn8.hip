@@ -1,3 +1,7 @@
+// EXPERIMENTAL (realise_set_tn_variant(8); the production weight-gradient path is the 4-wave kernel of gemm.hip and its grouped
+// launch): correct on every probe shape (tools/tn8_probe.cpp) but 7-16 % slower - one workgroup per CU loses more overlap than the
+// 256 x 128 tile's lower fill volume returns.  Kept as the starting point for a deeper-ring TN kernel.
+//
 // Ping-pong 8-wave TN GEMM for gfx950 (bf16, dense operands): the weight gradients of the Linear layers,
 //   C[I,J] (+)= sum_p A[p,i] * B[p,j]      A = dY [P, lda], B = X [P, ldb], both row-major with the reduction index p slowest.
 //
