@@ -86,7 +86,7 @@ def _oracle_train(model_type, cfg, sd_np, batch, taps=None):
 def _relu_boundary_flips(m, taps):
     """The glyph ResNet has 10 ReLUs over ~10^7 activations per batch; one whose pre-activation is within rounding
     (~1e-6) of zero can land on the other side than in the oracle, which legitimately selects a different subgradient
-    for everything upstream of it (tools/diag_relu_flip.py shows such a case).  Returns the deepest block (1..5) with a
+    for everything upstream of it (tests/diag_relu_flip.py shows such a case).  Returns the deepest block (1..5) with a
     mask disagreement (0 = masks identical) after checking that every disagreement IS such a boundary case."""
     deepest = 0
     T_ = taps["resnet.block1"].shape[0]
