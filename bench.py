@@ -110,7 +110,7 @@ def cpu_baseline(sd_cpu, cfg, sample_b, S):
     import realise_ref as R
     from realise_amd.data import synthetic_batch
     model, physical, logical = cpu_info()
-    threads = max(1, min(physical, 64))
+    threads = max(1, physical)                  # all physical cores
     torch.set_num_threads(threads)
     sd = {}
     for k, v in sd_cpu.items():
@@ -221,6 +221,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--profile-markers", action="store_true",
+                    help="time launches with event markers recorded around them (round 1/2 form) instead of the dispatch's own timestamps")
+    ap.add_argument("--no-glyph256", action="store_true", help="skip the BASELINE configs[3] sub-measurement of the default run")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch durations of the first sampled step to this JSON file")
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only measurements")
     ap.add_argument("--no-overlap", action="store_true", help="run the bert / pho / glyph branches serially on one stream")
@@ -253,11 +256,17 @@ def main():
     from realise_amd.modeling import SpellBertPho2ResArch3
     from realise_amd.optim import FusedAdamW, get_linear_schedule_with_warmup
     lib = _capi.load()
+    lib.realise_profile_mode(0 if args.profile_markers else 1)
 
     cfg = RealiseConfig()                                   # full model: 12 + 4 + 3 layers, 3 fonts, dropout 0.1
     model = SpellBertPho2ResArch3(cfg, compute_dtype=args.dtype, seed=0)
     if args.workload == "glyph256":
-        return glyph_workload(args, model, dev, lib, world, rank)
+        out = glyph_workload(args, model, dev, lib, world, rank)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     B = args.batch or 64
     sd_cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
@@ -396,9 +405,24 @@ def main():
                                "avg_launch_us": round(f["avg_launch_us"], 2),
                                "launches_per_step": f["launches_per_step"],
                                "flops_per_launch": round(f["tflops"] * 1e12 * f["avg_launch_us"] * 1e-6),
-                               "note": "per-launch HIP-event durations from every %dth timed step; those steps run the three model "
+                               "timing": "event markers around each launch" if args.profile_markers else
+                                         "HIP events attached to each dispatch (hipExtLaunchKernelGGL start/stop = the kernel's own begin/end timestamps)",
+                               "note": "per-launch durations from every %dth timed step; those steps run the three model "
                                        "branches serially so each kernel is timed alone" % PROFILE_EVERY}
             out["kernel_families"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in fams.items()}
+    if world == 1 and not args.no_glyph256:
+        # BASELINE configs[3] next to the headline number (same process, same model object): the glyph ResNet alone on 256 x 128 stacks
+        import copy
+        gargs = copy.copy(args)
+        gargs.batch, gargs.steps, gargs.warmup = 256, max(3, min(args.steps, 8)), 2
+        g = glyph_workload(gargs, model, dev, lib, world, rank)
+        out["glyph256"] = {"ms_per_step_dense": g["ms_per_step"], "stacks_per_s_dense": g["value"],
+                           "forward_ms_dense": g["forward"]["ms"], "model_mfma_util_dense": g["model_mfma_util"],
+                           "ms_per_step_dedup": g["dedup"]["ms_per_step"], "stacks_per_s_dedup": g["dedup"]["stacks_per_s"],
+                           "distinct_glyphs": g["dedup"]["distinct_glyphs"], "steps": gargs.steps,
+                           "kernel_families": g.get("kernel_families"),
+                           "workload": g["config"]["workload"]}
+    if rank == 0:
         if sd_cpu is not None:
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, args.cpu_sample, args.seq)
         print(json.dumps(out), flush=True)
@@ -472,9 +496,8 @@ def glyph_workload(args, model, dev, lib, world, rank):
                                "avg_launch_us": round(f["avg_launch_us"], 2), "launches_per_step": f["launches_per_step"],
                                "flops_per_launch": round(f["tflops"] * 1e12 * f["avg_launch_us"] * 1e-6)}
             out["kernel_families"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in fams.items()}
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

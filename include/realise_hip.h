@@ -88,43 +88,7 @@ int realise_gemm_tn_grouped(void* stream, int dtype, int n, const realise_tn_pro
 /* Conv2d weight gradient into the reference's [Co][Ci][KH][KW] layout. */
 int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const realise_conv_geom* b,
                     int P, int Co, int Ci, float* out, float* scratch, int64_t scratch_elems);
-/* 1: ds_read_b64_tr_b16 transposed operand reads in the TN kernel (bf16), 0: 16-bit LDS gathers. */
-void realise_set_tn_transpose_read(int enable);
-/* A/B knob: allow the 128x96 NT tile chosen by the chip-balance heuristic (default 1) */
-void realise_set_nt_allow_n96(int on);
-/* Diagnostics only (tools/nt_probe.cpp; results are WRONG when != 0): 1 every tile fetches tile 0's operands (cache-hot),
- * 2 no operand fetches, 3 no MFMA work - separates the memory, issue and compute shares of the NT kernel's time. */
-void realise_set_nt_probe(int mode);
-/* Diagnostics: force an experimental NT tile shape for dense bf16 GEMMs (0 = production heuristic). */
-void realise_set_nt_variant(int v);
-void realise_set_nt_group_m(int g);        /* tile order of the 8-wave NT GEMM: 0 row-major, g: g tile rows per column step (L2 blocking) */
-/* Diagnostics for the TN kernel: 2 no operand fetches, 3 no MFMA work, 4 skip the slab fold pass. */
-void realise_set_tn_probe(int mode);
-/* Diagnostics: force the number of reduction splits of the TN kernel (0 = heuristic). */
-void realise_set_tn_split(int n);
-/* weight-gradient kernel selection: 0 production (8-wave 256x128-tile kernel for the big dense bf16 shapes), 9 force the 4-wave kernel */
-void realise_set_tn_variant(int v);
-void realise_set_conv_c64(int on);         /* 1 (default): the 64->64 channel 3x3 conv on 16x16 maps (forward, input and weight gradient) runs the LDS-resident kernels */
-void realise_set_tn_group_ring(int on);    /* grouped weight gradients: 0 (default) two LDS stages of 64-row K-tiles, 1 four stages of 32 rows (measured 11 % slower) */
-/* Diagnostics for the attention forward kernel: 1 stop after operand staging, 2 skip the softmax (results WRONG). */
-void realise_set_attn_probe(int mode);
-/* A/B knob: 1 (default) the NT epilogue goes through a per-wave LDS transpose so every global access is 16 B per lane over
- * whole 128-byte row segments; 0 stores the MFMA fragments directly (8 B per lane). Identical results. */
-void realise_set_nt_wide_epilogue(int on);
-/* A/B knob: 1 (default) run the glyph ResNet once per distinct token id with multiplicity-weighted BatchNorm;
- * 0 run it densely over all B*S tokens like the reference (identical results) */
-void realise_set_glyph_dedup(int on);
-/* A/B knob: 1 (default) = the four weight-gradient GEMMs of each BERT layer run on an engine-owned side stream, overlapped with the
- * data-gradient chain on the caller's stream (joined before realise_engine_backward returns); 0 everything in order on the
- * caller's stream.  Identical results; +2 % throughput measured, per-kernel timings become overlap-dependent. */
-void realise_set_wgrad_overlap(int on);
-/* 1 (default): the three branches of SpellBertPho2ResArch3.forward that are independent between the inputs and the gate
- * (src/models.py:816 bert | :818-827 pinyin GRU + pho_model | :829-838 glyph ResNet), and their backward passes behind the
- * gate, run on three HIP streams (the caller's + two engine-owned), forked / joined with events inside the engine call; the
- * caller's stream owns every result when the call returns.  0: everything in order on the caller's stream.  Identical results. */
-void realise_set_dgrad_parity(int on);     /* 1 (default): stride-2 conv data gradients as four input-pixel parity-class GEMMs (no stride-miss taps) */
-void realise_set_wgrad_group(int on);      /* 1 (default): the four weight gradients of a transformer layer as one grouped launch */
-void realise_set_branch_overlap(int on);
+/* A/B knobs, probe modes and the per-launch timing hooks live in include/realise_hip_debug.h (diagnostics, not operators). */
 
 /* BertSelfAttention core (modeling_bert.py:239-260): softmax(QK^T/8 + mask_add) -> dropout -> .V
  * q/k/v: [B*S][ldq] token-major, head h at columns 64h..64h+63; ctx [B*S][ldc]; lse [B][nh][S]. */
@@ -249,18 +213,6 @@ int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, in
 int realise_fill_f32(void* stream, float* p, float value, int64_t n);
 /* widen a compute-dtype tensor to fp32 (the reference returns fp32 logits, src/models.py:859); 16-byte aligned pointers */
 int realise_cast_to_f32(void* stream, int dtype, const void* src, float* dst, int64_t n);
-
-/* Per-launch timing of the MFMA kernel families with HIP events on the launch stream (bench.py roofline).
- * family: 0 gemm_nt, 1 conv_nt (implicit im2col), 2 gemm_tn, 3 conv_tn, 4 attention fwd, 5 attention bwd.
- * total_work = algorithmic FLOPs (2*M*N*K per GEMM launch). */
-int realise_profile_enable(int max_launches);
-void realise_profile_disable(void);
-/* 1: stop bracketing launches but keep what was recorded, 0: resume (an event pair costs ~4 us of stream time per launch, so
- * bench.py samples every 10th timed step instead of all of them) */
-void realise_profile_pause(int paused);
-int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work);
-/* per-launch records of one family in launch order (host arrays of max_records entries); returns the number written */
-int realise_profile_dump(int kernel_family, int max_records, float* ms_out, double* work_out);
 
 const char* realise_version(void);
 

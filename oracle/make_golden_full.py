@@ -11,6 +11,12 @@ TEST INFRASTRUCTURE; run only where /root/reference exists (a few minutes on 8 c
   batch (BASELINE configs[3]), in train mode (batch statistics; updated BN buffers stored) and in eval mode: per-block output
   statistics and strided samples of the [32768, 768] result.
 
+* ``arch3_b64s128_train`` - the reference's TRAINING step at the same size (train mode, dropout 0): loss, forward taps, the
+  gradient of every gradient-receiving parameter (L2 norm, sum, |sum|, 192 strided samples) after ``loss.backward()``
+  (src/run.py:191-200) and the updated BatchNorm buffers.
+* ``resnet_b256s128_bwd`` - the reference CharResNet's backward on the 32768 glyph stacks for a seeded upstream gradient
+  (``glyph_upstream_grad``): gradient norm / sums / samples of its 45 parameters.
+
 Inputs are regenerated from seeds (realise_amd.data / realise_amd.init); only outputs are stored.
 """
 import os
@@ -108,6 +114,82 @@ def case_resnet(models, BertConfig, name="resnet_b256s128", B=256, S=128, seed=9
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
 
 
+N_GRAD_SAMPLE = 1024
+
+
+def put_grad(store, key, g):
+    """gradient summary: the 192-sample summary of every fixture + L2 norm, |max| and 1024 strided samples (the bf16 test
+    estimates the direction cosine on them)"""
+    put(store, key, g)
+    a = g.detach().to(torch.float64).reshape(-1)
+    store[key + "/l2"] = np.float64(a.norm().item())
+    store[key + "/absmax"] = np.float64(a.abs().max().item())
+    stride = max(1, a.numel() // N_GRAD_SAMPLE)
+    store[key + "/sample1k"] = a[::stride][:N_GRAD_SAMPLE].to(torch.float32).numpy()
+
+
+def case_full_train(models, BertConfig, name="arch3_b64s128_train", B=64, S=128, seed=8):
+    t0 = time.time()
+    cfg = RealiseConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = init_state_dict_numpy(cfg, "arch3", seed=seed, scheme="perturbed")
+    batch = synthetic_batch(B, S, seed=seed)
+    m = build_reference(models, BertConfig, cfg, "arch3", sd_np, True)
+    taps = {}
+    hooks = [
+        m.bert.register_forward_hook(lambda mod, i, o: taps.__setitem__("bert_h", o[0])),
+        m.pho_gru.register_forward_hook(lambda mod, i, o: taps.__setitem__("pho_gru", o[1].squeeze(0))),
+        m.resnet.register_forward_hook(lambda mod, i, o: taps.__setitem__("res", o)),
+        m.resnet_layernorm.register_forward_hook(lambda mod, i, o: taps.__setitem__("res_h", o)),
+        m.output_block.register_forward_hook(lambda mod, i, o: taps.__setitem__("out", o[0])),
+    ]
+    loss, logits = m(batch)[:2]
+    print("[%s] forward %.1fs" % (name, time.time() - t0))
+    loss.backward()                                                        # src/run.py:200
+    print("[%s] backward %.1fs" % (name, time.time() - t0))
+    for h in hooks:
+        h.remove()
+    store = {"meta/B": np.int64(B), "meta/S": np.int64(S), "meta/seed": np.int64(seed), "meta/n_layers": np.int64(12),
+             "meta/train": np.int64(1), "loss": np.float64(loss.item())}
+    for k, v in taps.items():
+        put(store, "tap/" + k, v)
+    put(store, "logits", logits)
+    store["argmax"] = logits.argmax(-1).to(torch.int32).numpy()
+    for k, v in m.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            put(store, "buf/" + k, v.to(torch.float64))
+    n_none = 0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            store["gradnone/" + k] = np.int64(1)
+            n_none += 1
+        else:
+            put_grad(store, "grad/" + k, p.grad)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print("[%s] loss %.6f, %d tensors without gradient, %.1fs" % (name, loss.item(), n_none, time.time() - t0))
+
+
+def case_resnet_bwd(models, BertConfig, name="resnet_b256s128_bwd", B=256, S=128, seed=9):
+    from realise_amd.data import glyph_upstream_grad
+    t0 = time.time()
+    cfg = RealiseConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = init_state_dict_numpy(cfg, "arch3", seed=seed, scheme="perturbed")
+    batch = synthetic_batch(B, S, seed=seed, with_pho=False)
+    m = build_reference(models, BertConfig, cfg, "arch3", sd_np, True)
+    ids = batch["src_idx"].view(-1)
+    d_res = torch.from_numpy(glyph_upstream_grad(B * S, 768, seed=seed))
+    images = m.char_images_multifonts.index_select(0, ids)                # src/models.py:831-834 (frozen table: no gradient)
+    res = m.resnet(images)                                                # src/char_cnn.py:35-55, train mode
+    print("[%s] forward %.1fs" % (name, time.time() - t0))
+    res.backward(d_res)
+    print("[%s] backward %.1fs" % (name, time.time() - t0))
+    store = {"meta/B": np.int64(B), "meta/S": np.int64(S), "meta/seed": np.int64(seed)}
+    put(store, "res", res)
+    for k, p in m.resnet.named_parameters():
+        put_grad(store, "grad/resnet." + k, p.grad)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **store)
+    print("[%s] %d gradient tensors, %.1fs" % (name, len(list(m.resnet.parameters())), time.time() - t0))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -117,6 +199,10 @@ def main():
         case_full_eval(models, BertConfig)
     if "resnet" in which:
         case_resnet(models, BertConfig)
+    if "train" in which:
+        case_full_train(models, BertConfig)
+    if "resnet_bwd" in which:
+        case_resnet_bwd(models, BertConfig)
 
 
 if __name__ == "__main__":

@@ -62,6 +62,9 @@ SYMBOLS = {
     "realise_set_nt_probe": (None, [_I]),
     "realise_set_nt_variant": (None, [_I]),
     "realise_set_nt_group_m": (None, [_I]),
+    "realise_set_nt8p": (None, [_I, _I]),
+    "realise_set_ln": (None, [_I, _I]),
+    "realise_layernorm_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_float, _P, _P, _P, _I, _I]),
     "realise_set_tn_probe": (None, [_I]),
     "realise_set_tn_split": (None, [_I]),
     "realise_set_tn_variant": (None, [_I]),
@@ -108,6 +111,7 @@ SYMBOLS = {
     "realise_profile_enable": (_I, [_I]),
     "realise_profile_disable": (None, []),
     "realise_profile_pause": (None, [_I]),
+    "realise_profile_mode": (None, [_I]),
     "realise_profile_dump": (_I, [_I, _I, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "realise_profile_read": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }

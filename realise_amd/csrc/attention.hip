@@ -435,7 +435,7 @@ int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
   static bool once = false;
   if (!once) { set_lds(attn_fwd_kernel<T>, lds); once = true; }
   ProfScope ps(st, PK_ATTN_FWD, 4.0 * B * nh * (double)S * S * 64);
-  hipLaunchKernelGGL((attn_fwd_kernel<T>), dim3(B * nh), dim3(256), lds, st, q, k, v, ldq, mask_add, ctx, ldc, lse, B, nh, S,
+  RL_LAUNCH((attn_fwd_kernel<T>), dim3(B * nh), dim3(256), lds, st, q, k, v, ldq, mask_add, ctx, ldc, lse, B, nh, S,
                      drop_seed, drop_thresh, drop_scale, g_attn_probe);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
@@ -450,11 +450,18 @@ int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
   const size_t lds2 = 2 * G::KT_BYTES + SMAX * sizeof(float);
   static bool once = false;
   if (!once) { set_lds(attn_bwd_dkv_kernel<T>, lds1); set_lds(attn_bwd_dq_kernel<T>, lds2); once = true; }
-  ProfScope ps(st, PK_ATTN_BWD, 10.0 * B * nh * (double)S * S * 64);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), dim3(B * nh), dim3(256), lds1, st, q, k, v, ldq, mask_add, ctx, dctx, ldc,
-                     lse, rowdot, dk, dv, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), dim3(B * nh), dim3(256), lds2, st, q, k, v, ldq, mask_add, dctx, ldc, lse,
-                     rowdot, dq, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale);
+  // the algorithmic 10 * B * nh * S^2 * 64 FLOPs of the attention gradient (dV, dP, dK, dQ + the score recompute), booked 6 : 4
+  // on the two kernels so that each launch carries its own dispatch timestamps
+  {
+    ProfScope ps(st, PK_ATTN_BWD, 6.0 * B * nh * (double)S * S * 64);
+    RL_LAUNCH((attn_bwd_dkv_kernel<T>), dim3(B * nh), dim3(256), lds1, st, q, k, v, ldq, mask_add, ctx, dctx, ldc,
+              lse, rowdot, dk, dv, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale);
+  }
+  {
+    ProfScope ps(st, PK_ATTN_BWD, 4.0 * B * nh * (double)S * S * 64);
+    RL_LAUNCH((attn_bwd_dq_kernel<T>), dim3(B * nh), dim3(256), lds2, st, q, k, v, ldq, mask_add, dctx, ldc, lse,
+              rowdot, dq, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale);
+  }
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 

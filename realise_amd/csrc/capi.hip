@@ -1,4 +1,4 @@
-// extern "C" surface of librealise_hip.so (declared in include/realise_hip.h).
+// extern "C" surface of librealise_hip.so (declared in include/realise_hip.h; diagnostics in include/realise_hip_debug.h).
 #include <math.h>
 #include <string.h>
 
@@ -8,6 +8,7 @@
 #include "layout.h"
 #include "ops.h"
 #include "prof.h"
+#include "../../include/realise_hip_debug.h"
 
 using namespace rl;
 
@@ -125,6 +126,8 @@ void realise_set_nt_allow_n96(int on) { set_nt_allow_n96(on); }
 void realise_set_nt_probe(int mode) { set_nt_probe(mode); }
 void realise_set_nt_variant(int v) { set_nt_variant(v); }
 void realise_set_nt_group_m(int g) { set_nt8_group_m(g); }
+void realise_set_ln(int key, int value) { if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); }
+void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }
 void realise_set_tn_split(int n) { set_tn_split(n); }
@@ -197,6 +200,13 @@ int realise_layernorm_bwd(void* stream, int dtype, const void* dy, const void* x
     return ln_bwd<float>(st, a);
   }
   return RL_ERR_ARG;
+}
+int realise_layernorm_bwd_ex(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,
+                             uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* dgamma, float* dbeta, float* slots, int rows, int H) {
+  LnBwdArgs<bf16_t> a; a.rows = rows; a.H = H; a.dy = (const bf16_t*)dy; a.xhat = (const bf16_t*)xhat; a.rstd = rstd;
+  a.gamma = gamma; a.dx = (bf16_t*)dx; a.dx_drop = (bf16_t*)dx_drop; a.out_drop.seed = drop_seed; a.out_drop.thresh = drop_thresh;
+  a.out_drop.scale = drop_scale; a.dgamma = dgamma; a.dbeta = dbeta; a.slots = slots;
+  return ln_bwd<bf16_t>((hipStream_t)stream, a);
 }
 int realise_build_pho(void* stream, const int64_t* src_idx, int T, const int64_t* table, const int32_t* vlens, int V, int Tw,
                       int64_t* pho_idx, int32_t* perm, int32_t* lens_sorted, int32_t* n_alive_dev) {
@@ -296,6 +306,7 @@ int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, in
 }
 int realise_profile_enable(int max_launches) { return prof_enable(max_launches); }
 void realise_profile_pause(int paused) { prof_pause(paused); }
+void realise_profile_mode(int attached) { prof_set_mode(attached); }
 void realise_profile_disable(void) { prof_disable(); }
 int realise_profile_dump(int kernel_family, int max_records, float* ms_out, double* work_out) { return prof_dump(kernel_family, max_records, ms_out, work_out); }
 int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work) {

@@ -162,7 +162,10 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // Speed-mode GELU: erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below bf16 resolution) - one v_exp_f32, one
 // v_rcp_f32 and 6 FMAs instead of the ~45-instruction erff; the same exponential serves the density term of the gradient.
 // T = float (parity mode) keeps erff / expf.
+// (contraction is pinned off inside: every kernel that inlines these - LDS-staged or register epilogue, forward or backward - must
+// round identically, whatever the surrounding code invites the compiler to fuse)
 __device__ __forceinline__ void gelu_parts_fast(float x, float& two_phi, float& e) {
+#pragma clang fp contract(off)
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
   e = __expf(-z * z);                                        // exp(-x^2 / 2)
@@ -172,10 +175,12 @@ __device__ __forceinline__ void gelu_parts_fast(float x, float& two_phi, float& 
   two_phi = x < 0.f ? q : 2.0f - q;                          // 2 * Phi(x), no cancellation in the negative tail
 }
 template <typename T> __device__ __forceinline__ float gelu_fwd(float x) {
+#pragma clang fp contract(off)
   if constexpr (sizeof(T) == 4) return gelu_erf(x);
   else { float tp, e; gelu_parts_fast(x, tp, e); return 0.5f * x * tp; }
 }
 template <typename T> __device__ __forceinline__ float gelu_bwd(float x) {
+#pragma clang fp contract(off)
   if constexpr (sizeof(T) == 4) return gelu_erf_grad(x);
   else { float tp, e; gelu_parts_fast(x, tp, e); return fmaf(x * 0.39894228040143267794f, e, 0.5f * tp); }
 }

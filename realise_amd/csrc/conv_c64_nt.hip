@@ -122,8 +122,8 @@ int conv_c64_nt(hipStream_t st, const bf16_t* X, const bf16_t* Wt, bf16_t* out, 
     attr = true;
   }
   ProfScope ps(st, PK_CONV_NT, 2.0 * rows * 64 * 576);
-  if (flip) hipLaunchKernelGGL(conv_c64_nt_kernel<1>, dim3(grid), dim3(512), CN_LDS, st, X, Wt, out, rows, rows_dev);
-  else hipLaunchKernelGGL(conv_c64_nt_kernel<0>, dim3(grid), dim3(512), CN_LDS, st, X, Wt, out, rows, rows_dev);
+  if (flip) RL_LAUNCH(conv_c64_nt_kernel<1>, dim3(grid), dim3(512), CN_LDS, st, X, Wt, out, rows, rows_dev);
+  else RL_LAUNCH(conv_c64_nt_kernel<0>, dim3(grid), dim3(512), CN_LDS, st, X, Wt, out, rows, rows_dev);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 

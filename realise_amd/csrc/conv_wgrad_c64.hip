@@ -162,7 +162,7 @@ int conv_wgrad_c64(hipStream_t st, const bf16_t* dY, const bf16_t* X, int rows, 
   if (!attr) { (void)hipFuncSetAttribute((const void*)conv_wgrad_c64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr = true; }
   {
     ProfScope ps(st, PK_CONV_TN, 2.0 * rows * 64 * 576);
-    hipLaunchKernelGGL(conv_wgrad_c64_kernel, dim3(nsplit), dim3(256), lds, st, dY, X, rows, rows_dev, nsplit, te.slab);
+    RL_LAUNCH(conv_wgrad_c64_kernel, dim3(nsplit), dim3(256), lds, st, dY, X, rows, rows_dev, nsplit, te.slab);
     tn_fold_launch(st, te, nsplit, 64, 576);
   }
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;

@@ -293,6 +293,11 @@ int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& l
 // Ping-pong 8-wave kernel (gemm_nt8.hip): bf16, dense operands, K % 64 == 0.  tile: 0 heuristic, 1 256x256, 2 256x192,
 // 3 256x128, 4 128x192.
 bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb);
+// persistent 256 x 192 kernel with the LDS-free epilogue (gemm_nt8p.hip): EPI_STORE / EPI_GELU / EPI_GELU_BWD, K % 64 == 0
+bool nt8p_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb);
+int gemm_nt8p(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
+void set_nt8p_wgs(int n);
+void set_nt8p_order(int o);
 int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
              const EpiParams<bf16_t>& ep, int tile);
 void set_nt8_probe(int mode);

@@ -383,7 +383,7 @@ static int launch_nt_pp(hipStream_t st, const DenseLoader<bf16_t>& la, const Den
   ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
   EpiParams<bf16_t> epp = ep;
   epp.wide = g_nt_wide && (N % 8 == 0) && (ep.ldo % 8 == 0) && (ep.aux == nullptr || ep.ldaux % 8 == 0);
-  hipLaunchKernelGGL(gemm_nt_pp_kernel, dim3(ntiles), dim3(512), lds, st, la, lb, M, N, K, tiles_n, ntiles, epp);
+  RL_LAUNCH(gemm_nt_pp_kernel, dim3(ntiles), dim3(512), lds, st, la, lb, M, N, K, tiles_n, ntiles, epp);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -403,7 +403,7 @@ static int launch_nt_tile(hipStream_t st, const ALoader& la, const DenseLoader<T
   EpiParams<T> epp = ep;
   epp.probe = g_nt_probe;
   epp.wide = g_nt_wide && (N % 8 == 0) && (ep.ldo % 8 == 0) && (ep.aux == nullptr || ep.ldaux % 8 == 0);
-  hipLaunchKernelGGL((gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF, SPREAD>), dim3(ntiles), dim3(64 * WM * WN), lds, st, la, lb, M, N, K, tiles_n, ntiles, epp);
+  RL_LAUNCH((gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF, SPREAD>), dim3(ntiles), dim3(64 * WM * WN), lds, st, la, lb, M, N, K, tiles_n, ntiles, epp);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -425,8 +425,14 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
   if constexpr (sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos) && sizeof(T) == 2) {
     // Production path for the big dense GEMMs: the ping-pong 8-wave kernel (gemm_nt8.hip), tile by chip fill.  Variants 10..34
     // force one of its tiles / issue flavours, variant 9 forces the 4-wave kernel below (tools/nt8_probe.cpp).
-    if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 44))) {
-      if (nt8_supported(M, N, K, ep, la.ld, ldb)) return gemm_nt8(st, la.base, la.ld, B, ldb, M, N, K, ep, g_nt_variant >= 10 ? g_nt_variant - 10 : 0);
+    // Wide outputs (qkv, FFN-up + GELU, FFN-down data gradient + GELU', the classifier: >= 1.5 tiles of 256 x 192 per CU): the persistent
+    // kernel, whose register epilogue and next-tile prologue overlap what the one-tile kernels leave exposed (gemm_nt8p.hip).
+    // Variant 50 forces it wherever it is supported, variant 51 keeps it off.
+    if (la.rows_dev == nullptr && g_nt_probe == 0 && (g_nt_variant == 50 || (g_nt_variant == 0 && M >= 1024 && (long)((M + 255) / 256) * ((N + 191) / 192) >= 384)) &&
+        nt8p_supported(M, N, K, ep, la.ld, ldb))
+      return gemm_nt8p(st, la.base, la.ld, B, ldb, M, N, K, ep);
+    if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 44) || g_nt_variant >= 50)) {
+      if (nt8_supported(M, N, K, ep, la.ld, ldb)) return gemm_nt8(st, la.base, la.ld, B, ldb, M, N, K, ep, (g_nt_variant >= 10 && g_nt_variant < 50) ? g_nt_variant - 10 : 0);
     }
     switch (g_nt_variant) {       // experimental tile shapes (tools/nt_probe.cpp)
       case 1: return launch_nt_tile<T, ALoader, 2, 4, 2, 3>(st, la, lb, M, N, K, ep);     // 128 x 192, 8 waves, 2 stages
@@ -866,11 +872,11 @@ static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader
     if (sizeof(T) == 2 && g_tn_tr) {
       static bool a1 = false;
       if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, true, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
-      hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, true, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
+      RL_LAUNCH((gemm_tn_kernel<T, BLoader, true, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
     } else {
       static bool a2 = false;
       if (!a2) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, false, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
-      hipLaunchKernelGGL((gemm_tn_kernel<T, BLoader, false, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
+      RL_LAUNCH((gemm_tn_kernel<T, BLoader, false, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
     }
     if (how == TN_OUT_SLAB && ep.probe != 4) tn_fold_launch(st, ep, nsplit, I, J);
   }
@@ -919,7 +925,7 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
 #define RL_TN_GROUP(TRV, NSTV, BPDV) do { \
     static bool attr = false; \
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<T, TRV, NSTV, BPDV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
-    hipLaunchKernelGGL((gemm_tn_group_kernel<T, TRV, NSTV, BPDV>), dim3(total), dim3(256), lds, st, grp, P, pchunk); } while (0)
+    RL_LAUNCH((gemm_tn_group_kernel<T, TRV, NSTV, BPDV>), dim3(total), dim3(256), lds, st, grp, P, pchunk); } while (0)
   const bool tr = sizeof(T) == 2 && g_tn_tr;
   if (g_tn_group_ring) { if (tr) RL_TN_GROUP(true, 4, 2); else RL_TN_GROUP(false, 4, 2); }
   else { if (tr) RL_TN_GROUP(true, 2, 1); else RL_TN_GROUP(false, 2, 1); }

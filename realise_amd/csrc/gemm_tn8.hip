@@ -232,7 +232,7 @@ int gemm_tn8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int6
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_set = true; }
   ProfScope ps(st, PK_GEMM_TN, 2.0 * P * I * J);
-  hipLaunchKernelGGL(gemm_tn8_kernel, dim3(ntiles * nsplit), dim3(512), C::LDS, st, A, lda, B, ldb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
+  RL_LAUNCH(gemm_tn8_kernel, dim3(ntiles * nsplit), dim3(512), C::LDS, st, A, lda, B, ldb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
   if (how == TN_OUT_SLAB) tn_fold_launch(st, ep, nsplit, I, J);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }

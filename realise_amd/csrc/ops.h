@@ -66,6 +66,8 @@ template <typename T> struct LnBwdArgs {
   float* slots = nullptr;          // optional scratch of LN_SLOT_BYTES: per-workgroup partial records, folded in a fixed order (no atomics)
 };
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a);
+void set_ln_fast(int on);            // 1 (default): bf16 rows of 256 / 512 / 768 / 1024 columns take the half-wave-per-row kernels (16-byte accesses)
+void set_ln_bwd_blocks(int n);       // workgroups of the fast LayerNorm backward (default 512)
 
 // scatter d(embedding sum) to the word / position / type tables
 template <typename T>

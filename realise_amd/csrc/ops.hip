@@ -76,9 +76,108 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs<T> a) {
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// bf16 fast path of the two kernels below (H % 256 == 0, H <= 1024, plain input): HALF a wave owns a row - 32 lanes x NV8 chunks
+// of 8 consecutive columns - so every global access is 16 bytes per lane (the 8-byte accesses of the one-wave-per-row form run at
+// 0.55-0.7 of that rate, MI355X_MICROARCH.md) and a wave-instruction covers two whole 512-byte row segments; a wave keeps RP
+// row pairs in flight (all loads issued before the first reduction).  Reductions run inside the 32-lane half.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_sum(float v) {        // sum over the 32 lanes of this half-wave
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void unpack8(const uint4 u, float (&f)[8]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 u;
+  u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
+  return u;
+}
+
+template <int NV8, int RP>
+__global__ void __launch_bounds__(256) ln_fwd16_kernel(LnFwdArgs<bf16_t> a) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+  const int H = a.H;
+  const int row0 = (blockIdx.x * 4 + wave) * (2 * RP) + half;
+  uint4 raw[RP][NV8];
+#pragma unroll
+  for (int r = 0; r < RP; ++r) {
+    const int row = row0 + 2 * r;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i)
+      raw[r][i] = row < a.rows ? *(const uint4*)((const char*)a.x + ((int64_t)row * H + (i * 32 + hl) * 8) * 2) : uint4{0u, 0u, 0u, 0u};
+  }
+  float gm[NV8][8], bt[NV8][8];
+#pragma unroll
+  for (int i = 0; i < NV8; ++i) {
+    const int c = (i * 32 + hl) * 8;
+    *(floatx4*)&gm[i][0] = *(const floatx4*)(a.gamma + c); *(floatx4*)&gm[i][4] = *(const floatx4*)(a.gamma + c + 4);
+    *(floatx4*)&bt[i][0] = *(const floatx4*)(a.beta + c); *(floatx4*)&bt[i][4] = *(const floatx4*)(a.beta + c + 4);
+  }
+#pragma unroll
+  for (int r = 0; r < RP; ++r) {
+    const int row = row0 + 2 * r;
+    float v[NV8][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      unpack8(raw[r][i], v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    }
+    const float mean = half_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+    const float rstd = 1.0f / sqrtf(half_sum(sq) / (float)H + a.eps);
+    if (row >= a.rows) continue;
+    if (hl == 0 && a.rstd != nullptr) a.rstd[row] = rstd;
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+      const int c = (i * 32 + hl) * 8;
+      float xh[8], y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[j] = (v[i][j] - mean) * rstd;
+        y[j] = xh[j] * gm[i][j] + bt[i][j];
+        y[j] *= drop_mult(a.drop.seed, a.drop.thresh, a.drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
+      }
+      if (a.xhat != nullptr) *(uint4*)((char*)a.xhat + ((int64_t)row * H + c) * 2) = pack8(xh);
+      *(uint4*)((char*)a.y + ((int64_t)row * H + c) * 2) = pack8(y);
+    }
+  }
+}
+
+static int g_ln_fast = 1, g_ln_bwd_blocks = 512;
+void set_ln_fast(int on) { g_ln_fast = on; }
+void set_ln_bwd_blocks(int n) { g_ln_bwd_blocks = n > 0 ? n : 512; }
+
+template <typename T> int ln_fwd_fast(hipStream_t st, const LnFwdArgs<T>& a) { return -1; }
+template <> int ln_fwd_fast<bf16_t>(hipStream_t st, const LnFwdArgs<bf16_t>& a) {
+  if (!g_ln_fast || a.in_mode != 0 || a.row_index != nullptr || (a.H % 256) != 0 || a.H > 1024) return -1;
+  constexpr int RP = 2;
+  const int blocks = (a.rows + 4 * 2 * RP - 1) / (4 * 2 * RP);
+  switch (a.H / 256) {
+    case 1: hipLaunchKernelGGL((ln_fwd16_kernel<1, RP>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((ln_fwd16_kernel<2, RP>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((ln_fwd16_kernel<3, RP>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((ln_fwd16_kernel<4, RP>), dim3(blocks), dim3(256), 0, st, a); break;
+  }
+  return RL_LAUNCH_CHECK();
+}
+
 template <typename T> int ln_fwd(hipStream_t st, const LnFwdArgs<T>& a) {
   if (a.rows <= 0) return RL_OK;
   if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
+  { const int rc = ln_fwd_fast<T>(st, a); if (rc >= 0) return rc; }
   hipLaunchKernelGGL((ln_fwd_kernel<T>), dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
   return RL_LAUNCH_CHECK();
 }
@@ -183,6 +282,111 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
     }
   }
 }
+
+// bf16 fast path of LayerNorm backward (H % 16 == 0, H <= 1024).  The fused [dgamma | dbeta] accumulators are what costs registers
+// here, and registers are what decides how many rows a CU keeps in flight (the 8-byte-per-lane form: 146 VGPRs, 3 waves per SIMD,
+// 1.9 TB/s; a half-wave-per-row form with 24 columns per lane: 186 VGPRs, 2.2 TB/s).  This form gives a WAVE one row and a lane two
+// 8-column chunks (columns 8l.. and H/2 + 8l..: H / 16 active lanes - 48 of 64 at H = 768; the idle quarter costs nothing on a
+// memory-bound kernel): 16-byte accesses, 32 accumulator registers, and the next row's loads are issued before the current row is
+// processed (two register sets, statically named), so every wave always has a row in flight.
+struct LnRow16 { uint4 dy[2], xh[2]; };
+template <bool DROP>
+__global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
+  __shared__ float red[2][4][1024];
+  __shared__ float gsm[1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int H = a.H, HH = H >> 1;
+  const bool active = lane * 16 < H;
+  const int c0 = lane * 8, c1 = HH + lane * 8;
+  for (int c = threadIdx.x; c < H; c += 256) gsm[c] = a.gamma[c];
+  __syncthreads();
+  float dg[2][8], db[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+  auto load = [&](int row, LnRow16& r) {
+    const bool ok = active && row < a.rows;
+    const uint32_t o0 = ((uint32_t)row * (uint32_t)H + (uint32_t)c0) * 2u, o1 = o0 + (uint32_t)H;      // rows * H * 2 < 4 GiB (launcher)
+    const uint4 z = uint4{0u, 0u, 0u, 0u};
+    r.dy[0] = ok ? *(const uint4*)((const char*)a.dy + o0) : z; r.dy[1] = ok ? *(const uint4*)((const char*)a.dy + o1) : z;
+    r.xh[0] = ok ? *(const uint4*)((const char*)a.xhat + o0) : z; r.xh[1] = ok ? *(const uint4*)((const char*)a.xhat + o1) : z;
+  };
+  auto process = [&](int row, LnRow16& r) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i ? c1 : c0;
+      float dy[8], xh[8], gm[8];
+      unpack8(r.dy[i], dy);
+      unpack8(r.xh[i], xh);
+      *(floatx4*)&gm[0] = *(const floatx4*)&gsm[active ? c : 0]; *(floatx4*)&gm[4] = *(const floatx4*)&gsm[active ? c + 4 : 4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = dy[j] * gm[j];
+        s1 += t;
+        s2 += t * xh[j];
+        dg[i][j] += dy[j] * xh[j];
+        db[i][j] += dy[j];
+      }
+    }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    if (!active || row >= a.rows) return;
+    const float rstd = a.rstd[row];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i ? c1 : c0;
+      float dy[8], xh[8], gm[8], dx[8];
+      unpack8(r.dy[i], dy);
+      unpack8(r.xh[i], xh);
+      *(floatx4*)&gm[0] = *(const floatx4*)&gsm[c]; *(floatx4*)&gm[4] = *(const floatx4*)&gsm[c + 4];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dx[j] = rstd * (dy[j] * gm[j] - s1 - xh[j] * s2);
+      const uint32_t off = ((uint32_t)row * (uint32_t)H + (uint32_t)c) * 2u;
+      *(uint4*)((char*)a.dx + off) = pack8(dx);
+      if (a.dx_drop != nullptr) {
+        if constexpr (DROP) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dx[j] *= drop_mult(a.out_drop.seed, a.out_drop.thresh, a.out_drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
+        }
+        *(uint4*)((char*)a.dx_drop + off) = pack8(dx);
+      }
+    }
+  };
+  const int stride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  LnRow16 ra, rb;
+  load(row, ra);
+  while (row < a.rows) {
+    load(row + stride, rb);
+    process(row, ra);
+    row += stride;
+    if (row >= a.rows) break;
+    load(row + stride, ra);
+    process(row, rb);
+    row += stride;
+  }
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i ? c1 : c0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { red[0][wave][c + j] = dg[i][j]; red[1][wave][c + j] = db[i][j]; }
+    }
+  }
+  __syncthreads();
+  float* rec = a.slots != nullptr ? a.slots + (int64_t)blockIdx.x * 2 * H : nullptr;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    if (rec != nullptr) { rec[c] = g; rec[H + c] = b; }
+    else {
+      if (a.dgamma != nullptr) atomicAdd(a.dgamma + c, g);
+      if (a.dbeta != nullptr) atomicAdd(a.dbeta + c, b);
+    }
+  }
+}
 // dgamma / dbeta += sum of the per-workgroup records: one float4 column group per 64 threads (record lanes k, k + 64, ...),
 // four groups per block, fixed-order LDS tree.
 __global__ void __launch_bounds__(256) ln_fold_kernel(const float* __restrict__ recs, int nrec, int H, float* dgamma, float* dbeta) {
@@ -213,6 +417,17 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
   LnBwdArgs<T> b = a;
   if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr;
   const int nv = (a.H + 255) / 256;
+  if constexpr (sizeof(T) == 2) {
+    if (g_ln_fast && a.in_drop.thresh == 0u && (a.H % 16) == 0 && a.H <= 1024 && (int64_t)a.rows * a.H * 2 < (1ll << 32)) {     // (the embedding LayerNorm, whose input gradient is dropout-masked first, keeps the general kernel)
+      const int groups = (a.rows + 3) / 4;
+      blocks = groups < g_ln_bwd_blocks ? groups : g_ln_bwd_blocks;
+      if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr; else b.slots = a.slots;
+      if (a.out_drop.thresh != 0u) hipLaunchKernelGGL((ln_bwd16_kernel<true>), dim3(blocks), dim3(256), 0, st, b);
+      else hipLaunchKernelGGL((ln_bwd16_kernel<false>), dim3(blocks), dim3(256), 0, st, b);
+      if (b.slots != nullptr) hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * a.H / 4 + 3) / 4), dim3(256), 0, st, b.slots, blocks, a.H, a.dgamma, a.dbeta);
+      return RL_LAUNCH_CHECK();
+    }
+  }
   if (nv == 1) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, b);
   else if (nv == 2) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, b);
   else if (nv == 3) hipLaunchKernelGGL((ln_bwd_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, b);

@@ -1,13 +1,21 @@
 // Optional per-launch timing of the MFMA kernel families with HIP events recorded on the launch
 // stream (bench.py's `roofline` object).  Disabled by default: zero cost when off.
+//
+// Two timing modes (prof_set_mode): 1 (default) = the two events are ATTACHED to the kernel dispatch (hipExtLaunchKernelGGL start /
+// stop events: the dispatch packet's own begin / end timestamps, the quantity rocprofv3's kernel trace reports); 0 = the events are
+// recorded around the launch as separate stream markers (round 1/2 form; adds the two marker packets' processing, ~1-4 us, to
+// every bracketed kernel).  Launch sites inside a ProfScope go through RL_LAUNCH so that mode 1 can hand them the events.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace rl {
 enum ProfKernel { PK_GEMM_NT = 0, PK_CONV_NT = 1, PK_GEMM_TN = 2, PK_CONV_TN = 3, PK_ATTN_FWD = 4, PK_ATTN_BWD = 5, PK_COUNT = 6 };
 void prof_begin(hipStream_t st, int kid, double work);
 void prof_end(hipStream_t st);
 int prof_enable(int max_launches);
+void prof_set_mode(int attached);  // 1: events attached to the dispatch (default), 0: event markers around the launch
+bool prof_take(hipEvent_t* e0, hipEvent_t* e1);   // mode 1, inside an open scope: the scope's event pair (at most once per scope)
 void prof_disable();
 void prof_pause(int paused);      // keep the collected records, stop / resume bracketing launches (sampled steps)
 int prof_read(int kid, long long* count, double* total_ms, double* total_work);
@@ -18,3 +26,10 @@ struct ProfScope {
   ~ProfScope() { prof_end(st); }
 };
 }  // namespace rl
+
+#define RL_LAUNCH(kern, grid, block, lds, st, ...)                                                          \
+  do {                                                                                                      \
+    hipEvent_t rl_e0_, rl_e1_;                                                                              \
+    if (rl::prof_take(&rl_e0_, &rl_e1_)) hipExtLaunchKernelGGL(kern, grid, block, lds, st, rl_e0_, rl_e1_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                                       \
+  } while (0)

@@ -10,7 +10,17 @@ std::vector<Rec> g_recs;
 size_t g_used = 0;
 bool g_open = false;
 bool g_paused = false;
+int g_mode = 1;
+bool g_taken = false;
 }  // namespace
+
+void prof_set_mode(int attached) { g_mode = attached ? 1 : 0; }
+bool prof_take(hipEvent_t* e0, hipEvent_t* e1) {
+  if (!g_open || g_mode != 1 || g_taken) return false;
+  *e0 = g_ev[g_used]; *e1 = g_ev[g_used + 1];
+  g_taken = true;
+  return true;
+}
 
 int prof_enable(int max_launches) {
   prof_disable();
@@ -36,15 +46,17 @@ void prof_pause(int paused) { g_paused = paused != 0; }
 void prof_begin(hipStream_t st, int kid, double work) {
   g_open = false;
   if (!g_on || g_paused || g_used + 2 > g_ev.size()) return;
-  (void)hipEventRecord(g_ev[g_used], st);
+  if (g_mode == 0) (void)hipEventRecord(g_ev[g_used], st);
   g_recs.push_back({kid, work, g_used});
   g_open = true;
+  g_taken = false;
 }
 void prof_end(hipStream_t st) {
   if (!g_open) return;
-  (void)hipEventRecord(g_ev[g_used + 1], st);
-  g_used += 2;
   g_open = false;
+  if (g_mode == 0) (void)hipEventRecord(g_ev[g_used + 1], st);
+  else if (!g_taken) { g_recs.pop_back(); return; }     // no launch inside the scope picked the events up: nothing was timed
+  g_used += 2;
 }
 int prof_read(int kid, long long* count, double* total_ms, double* total_work) {
   *count = 0; *total_ms = 0.0; *total_work = 0.0;

@@ -78,3 +78,10 @@ def synthetic_vocab(vocab_size=21128):
         toks.append(chr(cp))
         cp += 1
     return toks[:vocab_size]
+
+
+def glyph_upstream_grad(rows, width=768, seed=0, scale=1e-3):
+    """A seeded upstream gradient ``d res`` [rows, width] (fp32) for the glyph-ResNet-only backward (BASELINE configs[3]):
+    the same array on the reference side (oracle/make_golden_full.py) and on the device side (tests, bench.py)."""
+    g = np.random.Generator(np.random.Philox(key=[0x61F9, seed]))
+    return (g.standard_normal((rows, width), dtype=np.float32) * np.float32(scale)).astype(np.float32)

@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     lib = _capi.load()
-    header = open(os.path.join(ROOT, "include", "realise_hip.h")).read()
+    header = "".join(open(os.path.join(ROOT, "include", f)).read() for f in sorted(os.listdir(os.path.join(ROOT, "include"))) if f.endswith(".h"))
+    main = open(os.path.join(ROOT, "include", "realise_hip.h")).read()
+    assert "realise_set_" not in main and "realise_profile_" not in main, "diagnostic knobs belong in realise_hip_debug.h"
     declared = set(re.findall(r"\b(realise_[a-z0-9_]+)\s*\(", header))
     declared -= {"realise_engine"}
     assert declared, "no declarations parsed"
