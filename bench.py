@@ -218,6 +218,10 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "glyph256"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: CPU-staged collectives (N ranks may share one GPU)")
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient buckets on the wire (N > 1)")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="N = 1: still initialise the process group and wrap the model in the data-parallel wrapper (RCCL initialisation, the "
+                         "communication stream and the per-bucket events are exercised with a one-rank all-reduce)")
+    ap.add_argument("--dist-timeout", type=int, default=300, help="seconds before a rendezvous / collective gives up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--no-profile", action="store_true")
@@ -242,12 +246,27 @@ def main():
     local_dev = local % ndev
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    ddp = world > 1 or args.force_ddp
+    if ddp:
+        import datetime
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend="gloo")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        for k in ("MASTER_ADDR", "MASTER_PORT"):
+            if k not in os.environ:
+                raise SystemExit("%s is not set: launch through torch.distributed.run (--master-addr 127.0.0.1 --master-port P)" % k)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.dist_timeout))
+            else:
+                dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=args.dist_timeout))
+        except Exception as e:      # noqa: BLE001 - whatever the backend raises, say which rank / rendezvous it was
+            raise SystemExit("rank %d/%d: %s process group did not come up within %d s at %s:%s (%s: %s)"
+                             % (rank, world, args.backend, args.dist_timeout, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"),
+                                type(e).__name__, e))
 
     from realise_amd import _capi
     from realise_amd.config import RealiseConfig
@@ -264,7 +283,7 @@ def main():
         out = glyph_workload(args, model, dev, lib, world, rank)
         if rank == 0:
             print(json.dumps(out), flush=True)
-        if world > 1:
+        if ddp:
             dist.destroy_process_group()
         return
     B = args.batch or 64
@@ -274,7 +293,7 @@ def main():
     model.to(dev)
     model.train()
     model.assume_unit_loss_grad = True                      # plain loss.backward(), as in run.py:200
-    wrapped = DistributedDataParallel(model, grad_dtype=args.grad_dtype) if world > 1 else model
+    wrapped = DistributedDataParallel(model, grad_dtype=args.grad_dtype) if ddp else model
     no_decay = ["bias", "LayerNorm.weight"]                 # run.py:146-151
     groups = [{"params": [p for n, p in model.named_parameters() if p.requires_grad and not any(nd in n for nd in no_decay)],
                "weight_decay": 0.0},
@@ -375,9 +394,9 @@ def main():
                                    "3-font glyph ResNet, gate, tied 21128-way classifier), train step = fwd+bwd%s+clip+AdamW, "
                                    "dropout 0.1, random-init weights, SIGHAN-shaped synthetic batch"
                                    % ("" if world == 1 else " x%d GPUs (configs[2])" % world,
-                                      "" if world == 1 else "+%s all-reduce (%s buckets)" % ("RCCL" if args.backend == "nccl" else "gloo", args.grad_dtype)),
+                                      "" if not ddp else "+%s all-reduce (%s buckets)" % ("RCCL" if args.backend == "nccl" else "gloo", args.grad_dtype)),
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": args.seq,
-                       "parallelism": "dp%d" % world, "backend": args.backend if world > 1 else None,
+                       "parallelism": "dp%d" % world, "backend": args.backend if ddp else None,
                        "mean_pinyin_len": round(mean_len, 3), "mean_loss": round(final_loss, 4),
                        "branch_overlap": bool(overlap),
                        "distinct_glyphs": uniq, "tokens": T_},
@@ -410,7 +429,7 @@ def main():
                                "note": "per-launch durations from every %dth timed step; those steps run the three model "
                                        "branches serially so each kernel is timed alone" % PROFILE_EVERY}
             out["kernel_families"] = {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in fams.items()}
-    if world == 1 and not args.no_glyph256:
+    if world == 1 and not ddp and not args.no_glyph256:
         # BASELINE configs[3] next to the headline number (same process, same model object): the glyph ResNet alone on 256 x 128 stacks
         import copy
         gargs = copy.copy(args)
@@ -426,7 +445,7 @@ def main():
         if sd_cpu is not None:
             out["cpu_baseline"] = cpu_baseline(sd_cpu, cfg, args.cpu_sample, args.seq)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

@@ -154,6 +154,12 @@ int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_
 int realise_engine_refresh_shadows(realise_engine* e, void* stream);
 /* the frozen glyph table (arena 2) changed: rebuild its NHWC operand image at the next refresh */
 void realise_engine_invalidate_frozen(realise_engine* e);
+/* Token-id range errors.  nn.Embedding raises IndexError for an id outside its table (modeling_bert.py:183-186 word ids,
+ * models.py:818 pinyin ids, :831 glyph lookup).  The engine never indexes with a caller's id: every forward first copies src_idx /
+ * pho_idx into its workspace with out-of-range ids replaced by 0 and sets *flag = 1 (sticky; device memory or host-mapped pinned
+ * memory, nullable) when it replaced one.  The caller reads the flag when it next touches the host (the Python module: at the
+ * next forward / backward / decode) and raises; results of a flagged step are meaningless, but no memory outside the tables was read. */
+void realise_engine_set_id_flag(realise_engine* e, int32_t* flag);
 
 typedef struct {
   int32_t B, S, Tp;
@@ -210,6 +216,15 @@ int realise_sumsq(void* stream, const float* g, int64_t n, float* out_accum);
 int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, int correct_bias,
                   const float* grad_norm_sq, float max_grad_norm);
+/* clip_grad_norm_ (run.py:207) for a caller that steps with a stock optimizer: g *= min(1, max_norm / (sqrt(*grad_norm_sq) + 1e-6)),
+ * grad_norm_sq from realise_sumsq - no host synchronisation */
+int realise_clip_scale(void* stream, float* g, int64_t n, const float* grad_norm_sq, float max_grad_norm);
+/* The same sweep with per-group hyper-parameters (the trainer's decay / no-decay groups, run.py:146-151, with a non-zero
+ * --weight_decay): group_of_block64[i / 64] is the group (index into `groups`, HOST array of <= 8) of elements [64 b, 64 b + 64)
+ * - every tensor of the parameter arena starts on a 64-element boundary - and 255 marks elements no group holds. */
+typedef struct { float lr, beta1, beta2, eps, weight_decay; int32_t correct_bias; } realise_adamw_group;
+int realise_adamw_grouped(void* stream, float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_block64,
+                          const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm);
 int realise_fill_f32(void* stream, float* p, float value, int64_t n);
 /* widen a compute-dtype tensor to fp32 (the reference returns fp32 logits, src/models.py:859); 16-byte aligned pointers */
 int realise_cast_to_f32(void* stream, int dtype, const void* src, float* dst, int64_t n);

@@ -14,6 +14,11 @@ F32, BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_DROP_RESID, EPI_GELU_BWD = 0, 1, 2, 4
 
 
+class AdamwGroup(C.Structure):
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("correct_bias", C.c_int32)]
+
+
 class Epilogue(C.Structure):
     _fields_ = [("mode", C.c_int32), ("accumulate", C.c_int32), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("out2", C.c_void_p), ("bias", C.c_void_p), ("aux", C.c_void_p), ("ldaux", C.c_int64),
@@ -98,6 +103,7 @@ SYMBOLS = {
     "realise_engine_bind": (_I, [_P, _P, _P, _L]),
     "realise_engine_refresh_shadows": (_I, [_P, _P]),
     "realise_engine_invalidate_frozen": (None, [_P]),
+    "realise_engine_set_id_flag": (None, [_P, _P]),
     "realise_engine_forward": (_I, [_P, _P, C.POINTER(Batch)]),
     "realise_engine_backward": (_I, [_P, _P, _I, _I]),
     "realise_engine_backward_signalled": (_I, [_P, _P, C.POINTER(C.c_void_p), _I]),
@@ -106,6 +112,8 @@ SYMBOLS = {
     "realise_engine_tap": (_I, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(_L)]),
     "realise_sumsq": (_I, [_P, _P, _L, _P]),
     "realise_adamw": (_I, [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _I, _P, _F]),
+    "realise_clip_scale": (_I, [_P, _P, _L, _P, _F]),
+    "realise_adamw_grouped": (_I, [_P, _P, _P, _P, _P, _L, _P, C.POINTER(AdamwGroup), _I, _L, _P, _F]),
     "realise_fill_f32": (_I, [_P, _P, _F, _L]),
     "realise_cast_to_f32": (_I, [_P, _I, _P, _P, _L]),
     "realise_profile_enable": (_I, [_I]),

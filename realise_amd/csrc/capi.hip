@@ -274,6 +274,7 @@ int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_
 }
 int realise_engine_refresh_shadows(realise_engine* e, void* stream) { return e ? e->impl->refresh_shadows((hipStream_t)stream) : RL_ERR_ARG; }
 void realise_engine_invalidate_frozen(realise_engine* e) { if (e) e->impl->invalidate_frozen(); }
+void realise_engine_set_id_flag(realise_engine* e, int32_t* flag) { if (e) e->impl->set_id_flag((int*)flag); }
 int realise_engine_forward(realise_engine* e, void* stream, const realise_batch* batch) {
   return (e && batch) ? e->impl->forward((hipStream_t)stream, *batch) : RL_ERR_ARG;
 }
@@ -303,6 +304,19 @@ int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, in
     bc2 = (float)(1.0 - pow((double)beta2, (double)step));
   }
   return adamw_flat((hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_norm_sq, max_grad_norm);
+}
+int realise_clip_scale(void* stream, float* g, int64_t n, const float* grad_norm_sq, float max_grad_norm) { return clip_scale((hipStream_t)stream, g, n, grad_norm_sq, max_grad_norm); }
+int realise_adamw_grouped(void* stream, float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_block64,
+                          const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm) {
+  if (!groups || n_groups < 1 || n_groups > ADAMW_MAX_GROUPS) return RL_ERR_ARG;
+  AdamwGroups gs; gs.n = n_groups;
+  for (int i = 0; i < n_groups; ++i) {
+    const realise_adamw_group& h = groups[i];
+    double bc1 = 1.0, bc2 = 1.0;
+    if (h.correct_bias) { bc1 = 1.0 - pow((double)h.beta1, (double)step); bc2 = 1.0 - pow((double)h.beta2, (double)step); }
+    gs.g[i] = AdamwGroup{h.lr, h.beta1, h.beta2, h.eps, h.weight_decay, (float)(h.lr * sqrt(bc2) / bc1)};
+  }
+  return adamw_grouped((hipStream_t)stream, p, g, m, v, n, group_of_block64, gs, grad_norm_sq, max_grad_norm);
 }
 int realise_profile_enable(int max_launches) { return prof_enable(max_launches); }
 void realise_profile_pause(int paused) { prof_pause(paused); }

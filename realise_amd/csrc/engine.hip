@@ -92,6 +92,7 @@ template <typename T> struct Engine : EngineBase {
     StackAct bert, pho, outb;
     BlockAct blk[5];
     int64_t mask_add, out_d, dlogits, count, loss_internal;
+    int64_t ids_clean = 0, pho_clean = 0;                 // range-checked copies of src_idx / pho_idx (sanitize_ids)
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
     int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
     int64_t bn_sums, bn_slots;
@@ -141,7 +142,7 @@ template <typename T> struct Engine : EngineBase {
       for (int p = 0; p < 2; ++p) { for (int k = 0; k < 4; ++k) (void)hipEventDestroy(ev_ready[p][k]); (void)hipEventDestroy(ev_done[p]); }
       (void)hipStreamDestroy(side);
     }
-    for (int i = 0; i < 8; ++i) if (ev_sig[i] != nullptr) (void)hipEventDestroy(ev_sig[i]);
+    for (hipEvent_t e : ev_sig) if (e != nullptr) (void)hipEventDestroy(e);
   }
   // branch overlap: two engine-owned streams next to the caller's, fork / join events
   hipStream_t bst[2] = {nullptr, nullptr};
@@ -306,6 +307,8 @@ template <typename T> struct Engine : EngineBase {
       }
     };
     p.mask_add = b.take(Tk * 4);
+    p.ids_clean = b.take(Tk * 8);
+    p.pho_clean = (!glyph_only && cfg.model_type == 1) ? b.take(Tk * (int64_t)(Tp > 0 ? Tp : 1) * 8) : 0;
     if (!glyph_only) {
       plan_stack(p.bert, cfg.bert_layers, "bert");
       p.out_d = b.take(Tk * H * e);
@@ -416,6 +419,8 @@ template <typename T> struct Engine : EngineBase {
     return RL_OK;
   }
   void invalidate_frozen() override { glyph_built = false; }
+  int* id_flag = nullptr;
+  void set_id_flag(int* flag) override { id_flag = flag; }
   int get_tap(const char* name, void** ptr, int64_t* numel) override {
     auto it = taps.find(name);
     if (it == taps.end() || !ws) return RL_ERR_ARG;
@@ -830,6 +835,7 @@ template <typename T> struct Engine : EngineBase {
     }
     last = b;
     last.Tp = Tp;
+    have_glyph_fwd = false;            // the activations a glyph_backward would read are about to be overwritten
     last_alive.assign(Tp, 0);
     // host counts (the reference's contract: pho_lens is a host list) or, after realise_build_pho, device counts: every
     // step is then launched over all B*S rows and bounded on the device
@@ -839,18 +845,25 @@ template <typename T> struct Engine : EngineBase {
     have_fwd = false;
     const int Tk = b.B * b.S;
     RL_TRY(mask_to_additive(st, b.masks, wp<float>(pl.mask_add), Tk));
+    // everything below (and the backward) reads range-checked copies of the ids: a bad id raises in the module, never faults here
+    RL_TRY(sanitize_ids(st, b.src_idx, Tk, V, wp<int64_t>(pl.ids_clean), id_flag));
+    last.src_idx = wp<int64_t>(pl.ids_clean);
+    if (cfg.model_type == 1) {
+      RL_TRY(sanitize_ids(st, b.pho_idx, (int64_t)Tk * Tp, cfg.pho_vocab, wp<int64_t>(pl.pho_clean), id_flag));
+      last.pho_idx = wp<int64_t>(pl.pho_clean);
+    }
     const T* bert_h = nullptr;
     const bool ovl = cfg.model_type == 1 && g_branch_overlap && branches_ok();
     hipStream_t s_pho = ovl ? bst[0] : st, s_glyph = ovl ? bst[1] : st;
     if (ovl) RL_TRY(fork(st));                                    // bert | pinyin GRU + pho_model | glyph ResNet
-    RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, b.src_idx, nullptr, 0, &bert_h));
+    RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, last.src_idx, nullptr, 0, &bert_h));
     const T* top = bert_h;
     if (cfg.model_type == 1) {
       RL_TRY(gru_forward(s_pho));
       const T* pho_h = nullptr;
       RL_TRY(stack_forward(s_pho, 1, L.pho, sh_pho, pl.pho, nullptr, wp<T>(pl.gru_out), 0, &pho_h));
       const T* res = nullptr;
-      RL_TRY(resnet_forward(s_glyph, b.src_idx, &res));
+      RL_TRY(resnet_forward(s_glyph, last.src_idx, &res));
       {
         LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = res; ln.row_index = wp<int>(pl.gu_inv);      // token t reads its glyph's row
         ln.gamma = pp(L.res_ln_g); ln.beta = pp(L.res_ln_b); ln.eps = cfg.ln_eps;
@@ -887,10 +900,12 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(install_plan(st, make_plan(B, S, -1)));
     }
     last = realise_batch();
-    last.B = B; last.S = S; last.Tp = 1; last.training = training; last.src_idx = ids;
+    last.B = B; last.S = S; last.Tp = 1; last.training = training;
+    RL_TRY(sanitize_ids(st, ids, (int64_t)B * S, V, wp<int64_t>(pl.ids_clean), id_flag));
+    last.src_idx = wp<int64_t>(pl.ids_clean);
     have_fwd = false; have_glyph_fwd = false;
     const T* res = nullptr;
-    RL_TRY(resnet_forward(st, ids, &res));
+    RL_TRY(resnet_forward(st, last.src_idx, &res));
     RL_TRY(gather_rows<T>(st, res, wp<int>(pl.gu_inv), B * S, H, (T*)res_out));
     have_glyph_fwd = training != 0;
     return RL_OK;
@@ -990,9 +1005,10 @@ template <typename T> struct Engine : EngineBase {
   // start the all-reduce of bucket i on its own stream (hipStreamWaitEvent) while the three model branches and the deferred weight
   // gradients keep running.  The per-bucket form of backward() would serialise the branches and join the weight-gradient stream at
   // every bucket boundary.
-  hipEvent_t ev_sig[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev_sig;       // one per bucket (any number of bert groups)
   int signal_bucket(void* ev, hipStream_t s, bool through_side, int slot) {
     hipEvent_t e = (hipEvent_t)ev;
+    if ((int)ev_sig.size() <= slot) ev_sig.resize(slot + 1, nullptr);
     if (through_side && g_wgrad_overlap && side_ok()) {      // the bert branch: its weight gradients finish on the side stream
       if (ev_sig[slot] == nullptr && hipEventCreateWithFlags(&ev_sig[slot], hipEventDisableTiming) != hipSuccess) return RL_ERR_LAUNCH;
       if (hipEventRecord(ev_sig[slot], s) != hipSuccess || hipStreamWaitEvent(side, ev_sig[slot], 0) != hipSuccess ||
@@ -1004,7 +1020,7 @@ template <typename T> struct Engine : EngineBase {
   int backward_signalled(hipStream_t st, void* const* evs, int n_events) override {
     if (!have_fwd) { fprintf(stderr, "[realise_hip] backward without a training forward (tgt_idx + want_dlogits)\n"); return RL_ERR_ARG; }
     const int n = n_stages();
-    if (n_events != n || evs == nullptr || n > 8) return RL_ERR_ARG;
+    if (n_events != n || evs == nullptr) return RL_ERR_ARG;
     for (int i = 0; i < n; ++i) if (evs[i] == nullptr) return RL_ERR_ARG;
     cs = 0;
     if (cfg.model_type == 1 && g_branch_overlap && branches_ok()) {

@@ -64,6 +64,17 @@ template <typename T> struct ConvLoader {
   int rows, Hr, Wr, Hs, Ws, C, KH, KW, stride, pad, mode, K;
   int hw_shift, w_shift;      // log2(Hr*Wr), log2(Wr) when both are powers of two, else -1 (set by finalize())
   const int* rows_dev = nullptr;   // optional device-side row bound (glyph dedup: #distinct ids * pixels per image)
+  int64_t index_rows = 0;          // with img_index: number of images in `src` (0 = unknown: the caller vouches for < 4 GiB)
+  // the gathered source must span less than 4 GiB: the fetches carry 32-bit buffer offsets
+  bool span_ok() const {
+    const int64_t per = (int64_t)Hs * Ws * C * (int64_t)sizeof(T);
+    int64_t images = index_rows;
+    if (img_index == nullptr) {        // rows = images x pixels of the Hr x Wr map (a quarter of them per parity class)
+      const int64_t hw = (int64_t)Hr * Wr;
+      images = hw > 0 ? ((int64_t)rows * (par >= 0 ? 4 : 1) + hw - 1) / hw : 0;
+    }
+    return images * per < 0xFFFFFE00ll;
+  }
   // Parity-class form of a stride-2 data gradient (mode 1, 32-bit addressing only): par = 2*py + px in 0..3 restricts the rows to the
   // input pixels (2*yy + py, 2*xx + px) - rows = N * Hr/2 * Wr/2 - and K to the taps that can reach such a pixel,
   // kh = kh0 + 2i < KH with kh0 = (py + pad) & 1 (3x3 pad 1: one tap for an even coordinate, two for an odd one), so no fetched tap

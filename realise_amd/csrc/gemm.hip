@@ -470,7 +470,7 @@ int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la_, const T* B, int64_t l
   if (la_.C % Geo<T>::VEC) return RL_ERR_ARG;
   ConvLoader<T> la = la_;
   la.finalize();
-  if (la.K != K) return RL_ERR_ARG;
+  if (la.K != K || !la.span_ok()) return RL_ERR_ARG;
   if (la.par >= 0 && (la.par > 3 || la.mode != 1 || la.stride != 2 || la.hw_shift < 2 || la.w_shift < 1 || la.img_index != nullptr)) return RL_ERR_ARG;
   if constexpr (sizeof(T) == 2) {
     // 64 -> 64 channels, 3x3 / stride 1 / pad 1 on 16x16 maps (glyph ResNet block 1), plain store: the LDS-resident image + weights kernel
@@ -952,7 +952,7 @@ int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& l
   if (lb_.C % TnGeo<T>::VEC) return RL_ERR_ARG;
   ConvLoader<T> lb = lb_;
   lb.finalize();
-  if (lb.K != J) return RL_ERR_ARG;
+  if (lb.K != J || !lb.span_ok()) return RL_ERR_ARG;
   if constexpr (sizeof(T) == 2) {
     // 64 -> 64 channels, 3x3 / stride 1 / pad 1 on 16x16 maps (glyph ResNet block 1): the LDS-resident-input kernel
     if (g_conv_c64 && g_tn_probe == 0 && lb.C == 64 && lb.KH == 3 && lb.KW == 3 && lb.stride == 1 && lb.pad == 1 && lb.mode == 0 && lb.Hr == 16 &&

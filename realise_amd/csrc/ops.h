@@ -29,6 +29,8 @@ __device__ __forceinline__ int rb_rows(const RowBound& b, int P) { return b.rows
 __device__ __forceinline__ float rb_weight(const RowBound& b, int row) { return b.counts ? b.counts[row / b.hw] : 1.0f; }
 
 int mask_to_additive(hipStream_t st, const int64_t* masks, float* out, int n);
+// out[i] = ids[i] if 0 <= ids[i] < V else 0, *flag = 1 when any id was out of range (flag nullable)
+int sanitize_ids(hipStream_t st, const int64_t* ids, int64_t n, int V, int64_t* out, int* flag);
 
 // ---- LayerNorm (K1, K4 tail, K10) ------------------------------------------------------------
 template <typename T> struct LnFwdArgs {
@@ -203,6 +205,12 @@ int sumsq_accum(hipStream_t st, const float* g, int64_t n, float* out);         
 int adamw_flat(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, float bias_c1, float bias_c2, const float* norm_sq, float max_norm);
 
+constexpr int ADAMW_MAX_GROUPS = 8;
+struct AdamwGroup { float lr, beta1, beta2, eps, weight_decay, step_size; };      // step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t) (or lr)
+struct AdamwGroups { int n; AdamwGroup g[ADAMW_MAX_GROUPS]; };
+int adamw_grouped(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_block,
+                  const AdamwGroups& gs, const float* norm_sq, float max_norm);
+int clip_scale(hipStream_t st, float* g, int64_t n, const float* norm_sq, float max_norm);
 int fill_f32(hipStream_t st, float* p, float v, int64_t n);
 int add_i64(hipStream_t st, int64_t* p, int64_t v, int n);
 

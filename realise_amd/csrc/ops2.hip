@@ -96,6 +96,22 @@ __global__ void __launch_bounds__(1024) pho_prepare_kernel(const int64_t* __rest
     __syncthreads();
   }
 }
+// Token-id range check (nn.Embedding raises on an id outside its table, modeling_bert.py:183-186; models.py:818,831): the engine
+// reads CLEAN copies - ids clamped into [0, V) so that nothing downstream can index past a table - and a sticky flag (device- or
+// host-mapped int) records that a bad id was seen; the module raises IndexError when it reads the flag.
+__global__ void sanitize_ids_kernel(const int64_t* __restrict__ ids, int64_t n, int V, int64_t* __restrict__ out, int* flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = ids[i];
+  const bool bad = v < 0 || v >= V;
+  out[i] = bad ? 0 : v;
+  if (bad && flag != nullptr) *flag = 1;
+}
+int sanitize_ids(hipStream_t st, const int64_t* ids, int64_t n, int V, int64_t* out, int* flag) {
+  if (n <= 0) return RL_OK;
+  hipLaunchKernelGGL(sanitize_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ids, n, V, out, flag);
+  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+}
 int pho_prepare(hipStream_t st, const int64_t* src, int T_, const int64_t* table, const int32_t* vlens, int V, int Tw,
                 int64_t* pho_idx, int32_t* perm, int32_t* lens_sorted, int32_t* n_alive) {
   if (T_ <= 0) return RL_OK;
@@ -542,6 +558,50 @@ int adamw_flat(hipStream_t st, float* p, const float* g, float* m, float* v, int
   if (n <= 0) return RL_OK;
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                      bias_c1, bias_c2, norm_sq, max_norm);
+  return RL_LAUNCH_CHECK();
+}
+
+// AdamW with per-group hyper-parameters in ONE launch over the arena (the reference's decay / no-decay parameter groups,
+// run.py:146-151, with a non-zero weight decay): group_of_block[i >> 6] names the group of elements [64 b, 64 b + 64) (every tensor
+// of the arena starts on a 64-element boundary), 255 = not optimised.
+__global__ void adamw_grouped_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                     int64_t n, const uint8_t* __restrict__ group_of_block, AdamwGroups gs,
+                                     const float* __restrict__ norm_sq, float max_norm) {
+  float clip = 1.0f;
+  if (norm_sq != nullptr) {
+    const float c = max_norm / (sqrtf(norm_sq[0]) + 1e-6f);
+    clip = c < 1.0f ? c : 1.0f;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int gid = group_of_block[i >> 6];
+    if (gid >= gs.n) continue;
+    const AdamwGroup h = gs.g[gid];
+    const float gi = g[i] * clip;
+    const float mi = m[i] * h.beta1 + (1.0f - h.beta1) * gi;
+    const float vi = v[i] * h.beta2 + (1.0f - h.beta2) * gi * gi;
+    float pi = p[i] - h.step_size * (mi / (sqrtf(vi) + h.eps));
+    if (h.weight_decay > 0.f) pi -= h.lr * h.weight_decay * pi;
+    m[i] = mi; v[i] = vi; p[i] = pi;
+  }
+}
+int adamw_grouped(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_block,
+                  const AdamwGroups& gs, const float* norm_sq, float max_norm) {
+  if (n <= 0) return RL_OK;
+  if (gs.n < 1 || gs.n > ADAMW_MAX_GROUPS || group_of_block == nullptr) return RL_ERR_ARG;
+  hipLaunchKernelGGL(adamw_grouped_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, p, g, m, v, n, group_of_block, gs, norm_sq, max_norm);
+  return RL_LAUNCH_CHECK();
+}
+
+// g *= min(1, max_norm / (sqrt(*norm_sq) + 1e-6)) - the in-place half of clip_grad_norm_ (run.py:207) for callers that step with a
+// stock optimizer (FusedAdamW applies the coefficient inside its own sweep instead)
+__global__ void clip_scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ norm_sq, float max_norm) {
+  const float c = max_norm / (sqrtf(norm_sq[0]) + 1e-6f);
+  if (c >= 1.0f) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] *= c;
+}
+int clip_scale(hipStream_t st, float* g, int64_t n, const float* norm_sq, float max_norm) {
+  if (n <= 0) return RL_OK;
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, g, n, norm_sq, max_norm);
   return RL_LAUNCH_CHECK();
 }
 

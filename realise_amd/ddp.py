@@ -23,15 +23,20 @@ class _GradSync:
         self.buckets, self.world, self.group = buckets, world, group
         self.stream = torch.cuda.Stream() if use_side_stream else None
         self.wire = [torch.empty_like(b, dtype=torch.bfloat16) for b in buckets] if grad_dtype == "bf16" else None
+        self.avg_op = dist.get_backend(group) == "nccl"
         self.works = []
 
     def _launch(self, i):
         buf = self.buckets[i]
-        buf.div_(self.world)                               # pre-divide: SUM of (g / W) == mean, overflow-safe
         if self.wire is not None:
-            self.wire[i].copy_(buf)
+            # pre-divide and narrow in ONE pass over the bucket: SUM of bf16(g / W) == mean, overflow-safe
+            torch.mul(buf, 1.0 / self.world, out=self.wire[i])
             self.works.append((i, dist.all_reduce(self.wire[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+        elif self.avg_op:
+            # RCCL averages inside the collective (ncclAvg): no pre-divide pass over the 679 MB arena
+            self.works.append((i, dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)))
         else:
+            buf.div_(self.world)                           # gloo has no AVG: pre-divide, then SUM
             self.works.append((i, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     # ---- event-driven form: the engine runs the whole (branch-overlapped) backward in one call and records events[i] when

@@ -56,8 +56,14 @@ def read_label_file(path):
     out = []
     with open(path, "r", encoding="utf-8") as f:
         for line in f.read().splitlines():
-            parts = line.strip().split(", ")
+            # ``drop_de_corrections`` keeps the reference's quirk of ending a line with ``id, `` / ``id,`` when every correction of the
+            # LAST prediction was dropped (src/remove_de.py); such a line means "no edits" (deviation from the reference, whose own
+            # reader would crash on it - ADVICE round 2)
+            parts = [x for x in line.strip().rstrip(",").split(", ") if x != ""]
+            parts = [parts[0].rstrip(",")] + parts[1:] if parts else parts
             edits = []
+            if len(parts) == 1:
+                parts = [parts[0], "0"]
             if not (len(parts) == 2 and parts[1] == "0"):
                 edits = [(int(parts[k]), parts[k + 1]) for k in range(1, len(parts), 2)]
             out.append((parts[0], sorted(edits)))

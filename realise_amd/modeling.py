@@ -299,10 +299,12 @@ class RealiseModule(nn.Module):
 
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ over the flat gradient arena (run.py:207): two kernels."""
-        total = torch.linalg.vector_norm(self._grads)
-        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-        self._grads.mul_(coef)
-        return total
+        lib = _capi.load()
+        st = self._stream()
+        nsq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        _capi.check(lib.realise_sumsq(st, self._grads.data_ptr(), self._grads.numel(), nsq.data_ptr()), "realise_sumsq")
+        _capi.check(lib.realise_clip_scale(st, self._grads.data_ptr(), self._grads.numel(), nsq.data_ptr(), float(max_norm)), "realise_clip_scale")
+        return nsq.sqrt()[0]
 
     # ------------------------------------------------------------------ engine management
     def _stream(self):
@@ -321,6 +323,9 @@ class RealiseModule(nn.Module):
                 raise _capi.RealiseHipError("realise_engine_create rejected the configuration")
             nbytes = lib.realise_engine_shadow_bytes(self._engine)
             self._shadow = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)      # padded rows rely on zero fill
+            # id-range flag in host-mapped pinned memory: the device sets it, the host reads it without a synchronisation
+            self._id_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            lib.realise_engine_set_id_flag(self._engine, self._id_flag.data_ptr())
             self._ws = None
             self._frozen_version = None
         key = (B, S, Tp)
@@ -345,9 +350,27 @@ class RealiseModule(nn.Module):
             _capi.check(lib.realise_engine_refresh_shadows(self._engine, self._stream()), "realise_engine_refresh_shadows")
             self._shadow_version = ver
 
+    def _raise_on_bad_ids(self):
+        """nn.Embedding's IndexError, raised lazily: the engine replaced an out-of-range src_idx / pho_idx by 0 in an earlier
+        step and flagged it (include/realise_hip.h: realise_engine_set_id_flag)"""
+        f = getattr(self, "_id_flag", None)
+        if f is not None and int(f[0]) != 0:
+            f.zero_()
+            raise IndexError("index out of range in self: a src_idx outside [0, %d) or a pho_idx outside [0, %d) reached the "
+                             "model in an earlier forward" % (self.vocab_size, self._ccfg.pho_vocab))
+
+    def check_ids(self):
+        """wait for the queued steps and raise IndexError now if one of them saw an out-of-range id"""
+        torch.cuda.synchronize(self.device)
+        self._raise_on_bad_ids()
+
     def mark_parameters_updated(self):
-        """call after mutating parameters through a path torch's version counter cannot see (raw pointers)"""
+        """call after mutating parameters through a path torch's version counter cannot see: raw pointers, or ``p.data.copy_()``
+        on a parameter view (``.data`` carries its own version counter).  Weight operands are re-derived at the next forward and
+        so is the NHWC image of the frozen glyph table - the one tensor that is NOT refreshed on every forward (65 M floats), so
+        writing ``char_images_multifonts.data`` by hand instead of ``set_glyph_table()`` / ``build_glyce_embed*()`` needs this call."""
         self._shadow_version = None
+        self._frozen_version = None
 
     def tap(self, name):
         """named internal activation of the last forward as a torch tensor (parity tests)"""
@@ -365,6 +388,7 @@ class RealiseModule(nn.Module):
         return t.to(device=self.device, dtype=torch.int64).contiguous()
 
     def forward(self, batch):
+        self._raise_on_bad_ids()
         src = self._dev(batch["src_idx"])
         B, S = src.shape
         masks = self._dev(batch["masks"])
@@ -445,15 +469,19 @@ class RealiseModule(nn.Module):
         self._fwd_gen += 1
         _capi.check(_capi.load().realise_engine_glyph_forward(self._engine, self._stream(), src.data_ptr(), B, S, 1 if training else 0,
                                                               out.data_ptr()), "realise_engine_glyph_forward")
+        self._glyph_fwd_gen = self._fwd_gen if training else None
         self._last = [src]
         return out
 
     def glyph_backward(self, d_res):
         """accumulates the conv / BatchNorm parameter gradients of the last training ``glyph_forward`` for d_res [B, S, 768]"""
+        if getattr(self, "_glyph_fwd_gen", None) != self._fwd_gen:
+            raise RuntimeError("glyph_backward needs the activations of a training glyph_forward; another forward ran since (or none did)")
         d = d_res.to(device=self.device, dtype=_DTYPES[self.compute_dtype][1]).contiguous()
         sentinel = self._views["classifier.bias"][3]
         if sentinel.grad is None:
             self._grads.zero_()
+        self._glyph_fwd_gen = None
         _capi.check(_capi.load().realise_engine_glyph_backward(self._engine, self._stream(), d.data_ptr()), "realise_engine_glyph_backward")
         self._attach_grads()
 
@@ -489,6 +517,7 @@ class RealiseModule(nn.Module):
     def decode(self, batch_or_logits):
         """Arg-max ids [B, S] (int64, on the device) of a batch or of logits already computed: the device-side form of
         ``np.argmax(logits.cpu().numpy(), -1)`` (run.py:262-263); first maximum wins, as in numpy."""
+        self._raise_on_bad_ids()
         logits = batch_or_logits if torch.is_tensor(batch_or_logits) else self(batch_or_logits)[-1]
         if logits.dtype not in (torch.float32, torch.bfloat16) or not logits.is_cuda:
             raise TypeError("decode needs float32 / bfloat16 logits on the GPU")
@@ -508,6 +537,7 @@ class RealiseModule(nn.Module):
 
     def _run_backward(self, grad_out):
         lib = _capi.load()
+        self._raise_on_bad_ids()
         sentinel = self._views["classifier.bias"][3]
         if sentinel.grad is None:          # grads were set to None by an optimizer: start from zero
             self._grads.zero_()
@@ -538,7 +568,21 @@ class RealiseModule(nn.Module):
     def _bucket_comm_order(n):
         """order in which the buckets are all-reduced (the same on every rank).  arch3: output_block first, then the bert groups
         interleaved with the shorter pinyin and glyph branches that run next to them, the embeddings (+ tied classifier) last"""
-        return [0, 3, 2, 4, 1, 5, 6] if n == 7 else list(range(n))
+        if n < 5:
+            return list(range(n))
+        # buckets: 0 output_block | 1 gate + glyph | 2 pinyin | 3 .. n-2 bert groups (top layers first) | n-1 embeddings
+        groups = list(range(3, n - 1))
+        order = [0]
+        for k, g in enumerate(groups):
+            order.append(g)
+            if k == 0:
+                order.append(2)
+            elif k == 1:
+                order.append(1)
+        for b in (2, 1):
+            if b not in order:
+                order.append(b)
+        return order + [n - 1]
 
     def tap_dlogits(self):
         return self.tap("dlogits")

@@ -43,6 +43,25 @@ class FusedAdamW(torch.optim.Optimizer):
             self._ranges = [[by_id[id(p)] for p in g["params"] if id(p) in by_id] for g in self.param_groups]
         return self._ranges
 
+    def _group_map(self, flat_p):
+        """uint8 per 64 arena elements: index of the parameter group that owns them, 255 = none (built once)"""
+        if getattr(self, "_gmap", None) is None:
+            import numpy as np
+            n = flat_p.numel()
+            gmap = np.full((n + 63) // 64, 255, np.uint8)
+            for k, rng in enumerate(self._param_ranges()):
+                for off, cnt in rng:
+                    if off % 64:
+                        raise RuntimeError("arena tensor not on a 64-element boundary")
+                    gmap[off // 64:(off + cnt + 63) // 64] = k
+            self._gmap = torch.from_numpy(gmap).to(flat_p.device)
+        return self._gmap
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._ranges = None
+        self._gmap = None
+
     @torch.no_grad()
     def step(self, closure=None):
         lib = _capi.load()
@@ -65,6 +84,15 @@ class FusedAdamW(torch.optim.Optimizer):
             _capi.check(lib.realise_adamw(st, flat_p.data_ptr(), flat_g.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
                                           flat_p.numel(), g0["lr"], g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"],
                                           self._step, 1 if g0["correct_bias"] else 0, norm_ptr, max_norm), "realise_adamw")
+        elif len(self.param_groups) <= 8:
+            # groups with their own hyper-parameters (a real --weight_decay on the decay group, run.py:146-151): still ONE launch -
+            # a byte per 64 parameters names the group (every tensor of the arena starts on a 64-element boundary)
+            groups = (_capi.AdamwGroup * len(self.param_groups))()
+            for k, g in enumerate(self.param_groups):
+                groups[k] = _capi.AdamwGroup(g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], 1 if g["correct_bias"] else 0)
+            _capi.check(lib.realise_adamw_grouped(st, flat_p.data_ptr(), flat_g.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                                                  flat_p.numel(), self._group_map(flat_p).data_ptr(), groups, len(self.param_groups),
+                                                  self._step, norm_ptr, max_norm), "realise_adamw_grouped")
         else:
             for g, rng in zip(self.param_groups, self._param_ranges()):
                 for off, n in rng:

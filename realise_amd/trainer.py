@@ -97,16 +97,25 @@ def evaluate(model, items, *, batch_size=64, max_seq_length=128, device="cuda", 
     build_batch = build_batch or type(model).build_batch
     model.eval()
     losses, preds, batches = [], [], []
-    for batch in data_helper(items, batch_size, max_seq_length, build_batch, tokenizer, is_eval=True):
-        with torch.no_grad():
-            loss, logits = model(batch)[:2]
-        losses.append(loss.detach())
-        ids = model.decode(logits).cpu()
-        preds.append(ids)
-        if label_path is not None:
-            batch["src_idx"] = batch["src_idx"].cpu().numpy()
-            batch["pred_idx"] = ids.numpy()
-            batches.append(batch)
+    # nothing updates the parameters inside this loop: the operand copies are derived once, not per batch (~8 B / parameter each time)
+    was_static = getattr(model, "static_weights", None)
+    if was_static is not None:
+        model.mark_parameters_updated()
+        model.static_weights = True
+    try:
+        for batch in data_helper(items, batch_size, max_seq_length, build_batch, tokenizer, is_eval=True):
+            with torch.no_grad():
+                loss, logits = model(batch)[:2]
+            losses.append(loss.detach())
+            ids = model.decode(logits).cpu()
+            preds.append(ids)
+            if label_path is not None:
+                batch["src_idx"] = batch["src_idx"].cpu().numpy()
+                batch["pred_idx"] = ids.numpy()
+                batches.append(batch)
+    finally:
+        if was_static is not None:
+            model.static_weights = was_static
     mean_loss = torch.stack(losses).mean().item()
     if label_path is None:
         return mean_loss, torch.cat(preds)
