@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--dump-launches", default=None, help="write the per-launch durations of the first sampled step to this JSON file")
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only measurements")
     ap.add_argument("--no-overlap", action="store_true", help="run the bert / pho / glyph branches serially on one stream")
+    ap.add_argument("--knob", action="append", default=[], help="diagnostic knob as name:key=value, e.g. engine:0=1 (realise_set_engine(0, 1)); names: engine, ln, nt8p")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -276,6 +277,10 @@ def main():
     from realise_amd.optim import FusedAdamW, get_linear_schedule_with_warmup
     lib = _capi.load()
     lib.realise_profile_mode(0 if args.profile_markers else 1)
+    for kn in args.knob:
+        name, kv = kn.split(":")
+        k, v = kv.split("=")
+        getattr(lib, "realise_set_" + name)(int(k), int(v))
 
     cfg = RealiseConfig()                                   # full model: 12 + 4 + 3 layers, 3 fonts, dropout 0.1
     model = SpellBertPho2ResArch3(cfg, compute_dtype=args.dtype, seed=0)

@@ -20,6 +20,8 @@ void realise_set_nt_allow_n96(int on);
 void realise_set_nt_probe(int mode);
 /* Diagnostics: force an experimental NT tile shape for dense bf16 GEMMs (0 = production heuristic). */
 void realise_set_nt_variant(int v);
+/* step engine: key 0 = enqueue order of the three forward branches (0: bert stack first, 1: the shorter pinyin / glyph branches first) */
+void realise_set_engine(int key, int value);
 /* LayerNorm backward exactly as the engine calls it (bf16): optional second output dx_drop = dx * dropout mask, per-workgroup
  * [dgamma | dbeta] records in `slots` (8 MiB scratch) folded in a fixed order.  tools/ln_probe.py times it. */
 int realise_layernorm_bwd_ex(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,

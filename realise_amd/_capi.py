@@ -69,6 +69,7 @@ SYMBOLS = {
     "realise_set_nt_group_m": (None, [_I]),
     "realise_set_nt8p": (None, [_I, _I]),
     "realise_set_ln": (None, [_I, _I]),
+    "realise_set_engine": (None, [_I, _I]),
     "realise_layernorm_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_float, _P, _P, _P, _I, _I]),
     "realise_set_tn_probe": (None, [_I]),
     "realise_set_tn_split": (None, [_I]),

@@ -127,6 +127,7 @@ void realise_set_nt_probe(int mode) { set_nt_probe(mode); }
 void realise_set_nt_variant(int v) { set_nt_variant(v); }
 void realise_set_nt_group_m(int g) { set_nt8_group_m(g); }
 void realise_set_ln(int key, int value) { if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); }
+void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); }
 void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }

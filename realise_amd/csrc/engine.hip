@@ -41,6 +41,8 @@ void set_dgrad_parity(int on) { g_dgrad_parity = on; }
 // Results are identical to the serial order (the branches touch disjoint tensors and scratch).
 static int g_branch_overlap = 1;
 void set_branch_overlap(int on) { g_branch_overlap = on; }
+static int g_fwd_order = 0;
+void set_fwd_order(int o) { g_fwd_order = o; }
 
 #define RL_TRY(expr) do { const int _rc = (expr); if (_rc != RL_OK) { fprintf(stderr, "[realise_hip] %s failed (%d) at %s:%d\n", #expr, _rc, __FILE__, __LINE__); return _rc; } } while (0)
 
@@ -143,6 +145,7 @@ template <typename T> struct Engine : EngineBase {
       (void)hipStreamDestroy(side);
     }
     for (hipEvent_t e : ev_sig) if (e != nullptr) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; ++k) if (ev_shadow[k] != nullptr) (void)hipEventDestroy(ev_shadow[k]);
   }
   // branch overlap: two engine-owned streams next to the caller's, fork / join events
   hipStream_t bst[2] = {nullptr, nullptr};
@@ -246,6 +249,8 @@ template <typename T> struct Engine : EngineBase {
         }
       };
       add_stack(L.bert, sh_bert);
+      n_descs_a = (int)d.size(); desc_tiles_a = tiles;
+      tiles = 0;                                   // second group: its own launch, tile ids restart
       add(L.cls_w, V, H, sh_cls_w, sh_cls_wT, Vp);
       if (cfg.model_type == 1) {
         add_stack(L.pho, sh_pho);
@@ -256,27 +261,56 @@ template <typename T> struct Engine : EngineBase {
       if (hipMemcpyAsync(sh + sh_descs, d.data(), d.size() * sizeof(CastDesc), hipMemcpyHostToDevice, st) != hipSuccess) return RL_ERR_LAUNCH;
       n_descs = (int)d.size(); desc_tiles = tiles; descs_built = true;
     }
-    RL_TRY(cast_transpose_multi<T>(st, (const CastDesc*)(sh + sh_descs), n_descs, desc_tiles));
+    // Three independent pieces on three streams (when the branch streams exist): the bert stack's copies on the caller's stream -
+    // the forward that follows needs nothing else for its first 12 layers -, classifier + pinyin / output stacks + GRU on the pinyin
+    // stream, the 20 small conv-weight launches (+ the glyph table when it changed) on the glyph stream, where the glyph branch of the
+    // forward queues up behind them by itself.  ev_shadow[k] orders any OTHER consumer (a forward without branch streams, the
+    // glyph-only entry points): wait_shadows().
+    const bool ovl = cfg.model_type == 1 && g_branch_overlap && branches_ok() && shadow_events_ok();
+    hipStream_t s_b = ovl ? bst[0] : st, s_c = ovl ? bst[1] : st;
+    if (ovl) RL_TRY(fork(st));
+    const CastDesc* dd = (const CastDesc*)(sh + sh_descs);
+    RL_TRY(cast_transpose_multi<T>(st, dd, n_descs_a, desc_tiles_a));
+    RL_TRY(cast_transpose_multi<T>(s_b, dd + n_descs_a, n_descs - n_descs_a, desc_tiles));
     if (cfg.model_type == 1) {
       for (int k = 0; k < 5; ++k) {
         const BlockOff& o = L.blocks[k];
         const BlockSh& s = sh_blk[k];
-        RL_TRY(conv_weight_shadow<T>(st, pp(o.w1), o.cout, o.cin, 9, s.cin_pad, s.cin_pad, sp<T>(s.w1f), sp<T>(s.w1d)));
+        RL_TRY(conv_weight_shadow<T>(s_c, pp(o.w1), o.cout, o.cin, 9, s.cin_pad, s.cin_pad, sp<T>(s.w1f), sp<T>(s.w1d)));
         {   // second data-gradient copy of the stride-2 conv with its taps stored parity class by parity class
           TapOrder ord; ord.n = 9; int first = 0;
           (void)conv_s2_class(3, 3, 1, 0, &first, ord.t);
-          RL_TRY(conv_weight_shadow<T>(st, pp(o.w1), o.cout, o.cin, 9, s.cin_pad, s.cin_pad, (T*)nullptr, sp<T>(s.w1p), ord));
+          RL_TRY(conv_weight_shadow<T>(s_c, pp(o.w1), o.cout, o.cin, 9, s.cin_pad, s.cin_pad, (T*)nullptr, sp<T>(s.w1p), ord));
         }
-        RL_TRY(conv_weight_shadow<T>(st, pp(o.w2), o.cout, o.cout, 9, o.cout, o.cout, sp<T>(s.w2f), sp<T>(s.w2d)));
-        RL_TRY(conv_weight_shadow<T>(st, pp(o.ws), o.cout, o.cin, 1, s.cin_pad, s.cin_pad, sp<T>(s.wsf), sp<T>(s.wsd)));
+        RL_TRY(conv_weight_shadow<T>(s_c, pp(o.w2), o.cout, o.cout, 9, o.cout, o.cout, sp<T>(s.w2f), sp<T>(s.w2d)));
+        RL_TRY(conv_weight_shadow<T>(s_c, pp(o.ws), o.cout, o.cin, 1, s.cin_pad, s.cin_pad, sp<T>(s.wsf), sp<T>(s.wsd)));
       }
       // the glyph table is frozen (requires_grad=False, models.py:679): its NHWC image is rebuilt only after
       // invalidate_frozen() (load_state_dict / build_glyce_embed*)
       if (!glyph_built) {
-        RL_TRY(glyph_shadow<T>(st, FZ + L.glyph, V, cfg.num_fonts, cfg.glyph_size * cfg.glyph_size, 8, sp<T>(sh_glyph)));
+        RL_TRY(glyph_shadow<T>(s_c, FZ + L.glyph, V, cfg.num_fonts, cfg.glyph_size * cfg.glyph_size, 8, sp<T>(sh_glyph)));
         glyph_built = true;
       }
     }
+    shadows_pending = false;
+    if (ovl) {
+      for (int k = 0; k < 2; ++k) if (hipEventRecord(ev_shadow[k], bst[k]) != hipSuccess) return RL_ERR_LAUNCH;
+      shadows_pending = true;
+    }
+    return RL_OK;
+  }
+  // operand copies refreshed on the branch streams: order `s` behind them (no-op when they ran on the caller's stream)
+  hipEvent_t ev_shadow[2] = {nullptr, nullptr};
+  bool shadows_pending = false;
+  int n_descs_a = 0, desc_tiles_a = 0;
+  bool shadow_events_ok() {
+    for (int k = 0; k < 2; ++k)
+      if (ev_shadow[k] == nullptr && hipEventCreateWithFlags(&ev_shadow[k], hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+  }
+  int wait_shadows(hipStream_t s) {
+    if (!shadows_pending) return RL_OK;
+    for (int k = 0; k < 2; ++k) if (hipStreamWaitEvent(s, ev_shadow[k], 0) != hipSuccess) return RL_ERR_LAUNCH;
     return RL_OK;
   }
 
@@ -855,8 +889,13 @@ template <typename T> struct Engine : EngineBase {
     const T* bert_h = nullptr;
     const bool ovl = cfg.model_type == 1 && g_branch_overlap && branches_ok();
     hipStream_t s_pho = ovl ? bst[0] : st, s_glyph = ovl ? bst[1] : st;
+    // operand copies refreshed on the branch streams (refresh_shadows): with the branch streams in use below, each branch is already
+    // ordered behind its own copies and the caller's stream meets the classifier / output-stack copies at the join; otherwise wait here
+    if (!ovl) RL_TRY(wait_shadows(st));
     if (ovl) RL_TRY(fork(st));                                    // bert | pinyin GRU + pho_model | glyph ResNet
-    RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, last.src_idx, nullptr, 0, &bert_h));
+    // Enqueue order (g_fwd_order): the host needs ~0.6 ms to enqueue the 150 launches of the bert stack; enqueued first (0) the two
+    // shorter branches reach the GPU only after that, enqueued last (1) they start at once and bert joins them ~0.4 ms later.
+    if (!(ovl && g_fwd_order == 1)) RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, last.src_idx, nullptr, 0, &bert_h));
     const T* top = bert_h;
     if (cfg.model_type == 1) {
       RL_TRY(gru_forward(s_pho));
@@ -870,6 +909,7 @@ template <typename T> struct Engine : EngineBase {
         ln.y = wp<T>(pl.res_h); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
         RL_TRY(ln_fwd<T>(s_glyph, ln));
       }
+      if (ovl && g_fwd_order == 1) { RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, last.src_idx, nullptr, 0, &bert_h)); top = bert_h; }
       if (ovl) RL_TRY(join(st));
       RL_TRY(gate_fwd<T>(st, gate_args()));
       RL_TRY(stack_forward(st, 2, L.outb, sh_out, pl.outb, nullptr, wp<T>(pl.fused), 1, &top));
@@ -901,6 +941,7 @@ template <typename T> struct Engine : EngineBase {
     }
     last = realise_batch();
     last.B = B; last.S = S; last.Tp = 1; last.training = training;
+    RL_TRY(wait_shadows(st));
     RL_TRY(sanitize_ids(st, ids, (int64_t)B * S, V, wp<int64_t>(pl.ids_clean), id_flag));
     last.src_idx = wp<int64_t>(pl.ids_clean);
     have_fwd = false; have_glyph_fwd = false;

@@ -292,8 +292,13 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
 struct LnRow16 { uint4 dy[2], xh[2]; };
 template <bool DROP>
 __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
-  __shared__ float red[2][4][1024];
-  __shared__ float gsm[1024];
+  // LDS: gamma [H] + one [4 waves][H] reduction buffer used twice (dgamma, then dbeta): 15 KB at H = 768.  The footprint matters
+  // beyond occupancy: in a training step this kernel runs NEXT TO the grouped weight-gradient GEMM of the side stream, whose two
+  // 64 KB workgroups leave 32 KB of a CU's LDS - with a 36 KB footprint these workgroups queued behind it (58 us per call under
+  // overlap against 33 alone).
+  extern __shared__ float ln_lds[];
+  float* gsm = ln_lds;                 // [H]
+  float* red = ln_lds + a.H;           // [4][H]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int H = a.H, HH = H >> 1;
   const bool active = lane * 16 < H;
@@ -367,23 +372,24 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
     process(row, rb);
     row += stride;
   }
-  if (active) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = i ? c1 : c0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { red[0][wave][c + j] = dg[i][j]; red[1][wave][c + j] = db[i][j]; }
-    }
-  }
-  __syncthreads();
   float* rec = a.slots != nullptr ? a.slots + (int64_t)blockIdx.x * 2 * H : nullptr;
-  for (int c = threadIdx.x; c < H; c += 256) {
-    const float g = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-    const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    if (rec != nullptr) { rec[c] = g; rec[H + c] = b; }
-    else {
-      if (a.dgamma != nullptr) atomicAdd(a.dgamma + c, g);
-      if (a.dbeta != nullptr) atomicAdd(a.dbeta + c, b);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();                   // (pass 0: the gamma reads of the row loop are done; pass 1: pass 0's sums are read)
+    if (active) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = i ? c1 : c0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[wave * H + c + j] = pass ? db[i][j] : dg[i][j];
+      }
+    }
+    __syncthreads();
+    float* out = pass ? a.dbeta : a.dgamma;
+    for (int c = threadIdx.x; c < H; c += 256) {
+      const float v = red[c] + red[H + c] + red[2 * H + c] + red[3 * H + c];
+      if (rec != nullptr) rec[pass * H + c] = v;
+      else if (out != nullptr) atomicAdd(out + c, v);
     }
   }
 }
@@ -422,8 +428,9 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
       const int groups = (a.rows + 3) / 4;
       blocks = groups < g_ln_bwd_blocks ? groups : g_ln_bwd_blocks;
       if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr; else b.slots = a.slots;
-      if (a.out_drop.thresh != 0u) hipLaunchKernelGGL((ln_bwd16_kernel<true>), dim3(blocks), dim3(256), 0, st, b);
-      else hipLaunchKernelGGL((ln_bwd16_kernel<false>), dim3(blocks), dim3(256), 0, st, b);
+      const size_t lds = (size_t)5 * a.H * sizeof(float);
+      if (a.out_drop.thresh != 0u) hipLaunchKernelGGL((ln_bwd16_kernel<true>), dim3(blocks), dim3(256), lds, st, b);
+      else hipLaunchKernelGGL((ln_bwd16_kernel<false>), dim3(blocks), dim3(256), lds, st, b);
       if (b.slots != nullptr) hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * a.H / 4 + 3) / 4), dim3(256), 0, st, b.slots, blocks, a.H, a.dgamma, a.dbeta);
       return RL_LAUNCH_CHECK();
     }

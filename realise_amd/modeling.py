@@ -364,13 +364,15 @@ class RealiseModule(nn.Module):
         torch.cuda.synchronize(self.device)
         self._raise_on_bad_ids()
 
-    def mark_parameters_updated(self):
+    def mark_parameters_updated(self, frozen=True):
         """call after mutating parameters through a path torch's version counter cannot see: raw pointers, or ``p.data.copy_()``
         on a parameter view (``.data`` carries its own version counter).  Weight operands are re-derived at the next forward and
         so is the NHWC image of the frozen glyph table - the one tensor that is NOT refreshed on every forward (65 M floats), so
-        writing ``char_images_multifonts.data`` by hand instead of ``set_glyph_table()`` / ``build_glyce_embed*()`` needs this call."""
+        writing ``char_images_multifonts.data`` by hand instead of ``set_glyph_table()`` / ``build_glyce_embed*()`` needs this call.
+        ``frozen=False`` (what FusedAdamW passes every step) leaves the glyph table's image alone: an optimizer never writes it."""
         self._shadow_version = None
-        self._frozen_version = None
+        if frozen:
+            self._frozen_version = None
 
     def tap(self, name):
         """named internal activation of the last forward as a torch tensor (parity tests)"""

@@ -100,7 +100,7 @@ class FusedAdamW(torch.optim.Optimizer):
                                                   self._m.data_ptr() + 4 * off, self._v.data_ptr() + 4 * off, n, g["lr"],
                                                   g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._step,
                                                   1 if g["correct_bias"] else 0, norm_ptr, max_norm), "realise_adamw")
-        mod.mark_parameters_updated()
+        mod.mark_parameters_updated(frozen=False)
 
     def state_dict(self):
         """torch's param_groups plus the flat first / second moments and the step count (they live outside ``self.state``)"""
