@@ -110,6 +110,52 @@ int realise_layernorm_bwd(void* stream, int dtype, const void* dy, const void* x
 int realise_masked_ce(void* stream, int dtype, const void* logits, int64_t ld, const int64_t* labels,
                       const int64_t* loss_mask, int rows, int V, float* loss_out, float* count_scratch, void* dlogits);
 
+/* One time step of the pinyin GRU (nn.GRU over pack_padded_sequence, src/models.py:818-826) on the n_alive longest sequences
+ * (tokens sorted by decreasing length: perm[i] = original token of sorted row i, lens[i] its length).  The input projection is a
+ * table [33][3H] = W_ih Emb^T + b_ih (fp32); gh = h_prev W_hh^T + b_hh comes from realise_gemm_nt (NULL at t == 0: gh = b_hh,
+ * h_prev = 0).  Forward: r, z, n gates -> h_new (sorted rows), rzn saved, out[perm[i]] = h when the sequence ends at this step.
+ * Backward (one BPTT step): dh (sorted, in/out: running dL/dh; rows that end here start from dout[perm[i]]) -> dgi / dgh
+ * [n_alive][3H] for the table / W_hh gradients, onehot[n_alive][64] of the step's pinyin id. */
+typedef struct {
+  int32_t n_alive, H, Tp, t;
+  const float* table; const int64_t* pho_idx; const int32_t* perm; const int32_t* lens;
+  const void* gh; const float* b_hh; const void* h_prev; void* h_new; void* rzn; void* out;
+  const void* dout; void* dh; void* dgi; void* dgh; void* onehot;
+} realise_gru_step;
+int realise_gru_step_fwd(void* stream, int dtype, const realise_gru_step* a);
+int realise_gru_step_bwd(void* stream, int dtype, const realise_gru_step* a);
+/* Gated fusion (src/models.py:840-850): masked mean of the bert states per sentence, three sigmoid gates from
+ * [bert | pho | res | mean] . W[3][4H] + bias, fused = g0 bert + g1 pho + g2 res.  Backward fills dbert / dpho / dres and
+ * accumulates dW [3][4H], dbias [3]; mean [B][H], msum [B], g [B*S][4] are saved by the forward, dz [B*S][4] is scratch. */
+typedef struct {
+  int32_t B, S, H;
+  const void* bert; const void* pho; const void* res; const int64_t* masks; const float* W; const float* bias;
+  float* mean; float* msum; float* g; void* fused;
+  const void* dfused; void* dbert; void* dpho; void* dres; float* dz; float* dW; float* dbias;
+} realise_gate;
+int realise_gate_fwd(void* stream, int dtype, const realise_gate* a);
+int realise_gate_bwd(void* stream, int dtype, const realise_gate* a);
+/* nn.BatchNorm2d over an NHWC activation viewed as [P = N*H*W][C] (src/char_cnn.py:17-28), optional fused ReLU.  training:
+ * batch statistics (two passes: mean, then centred squares), running statistics updated with the unbiased variance and
+ * `momentum`, num_batches_tracked += 1 (nullable), save_mean / save_rstd [C] for the backward.  scratch: 4*C floats.
+ * Backward: relu_src = the forward's y when ReLU was fused (NULL otherwise); dgamma / dbeta are ACCUMULATED; scratch 2*C floats. */
+int realise_batchnorm_fwd(void* stream, int dtype, const void* x, int P, int C, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, int training, int relu, void* y,
+                          float* save_mean, float* save_rstd, float* scratch);
+int realise_batchnorm_bwd(void* stream, int dtype, const void* dy, const void* relu_src, const void* x, const float* save_mean, const float* save_rstd,
+                          const float* gamma, int P, int C, void* dx, float* dgamma, float* dbeta, float* scratch);
+/* Gradient of BertEmbeddings' three table lookups (modeling_bert.py:183-190) from de = d(word + position + type sum) [B*S][H]:
+ * word_grad[ids[t]] += de[t] (nullable), pos_grad[s] += sum_b de[b, s] (pos_zero: everything into row 0), type_grad[0] += sum_t de[t]. */
+int realise_embedding_bwd(void* stream, int dtype, const void* de, const int64_t* ids, int B, int S, int H, float* word_grad, float* pos_grad,
+                          int pos_zero, float* type_grad);
+/* Glyph dedup bookkeeping (no reference counterpart: char_images_multifonts.index_select(0, ids) depends on the id only): the distinct
+ * ids in order of first occurrence (uniq_ids), their multiplicities (counts), inv[t] = slot of token t, bounds[0] = #distinct,
+ * bounds[1 + k] = #distinct * hw[k].  first_scratch: V ints, flag_scratch: T ints.  realise_segment_sum: out[u] = sum over tokens
+ * with inv[t] == u of x[t] (acc: T*C floats of scratch; rows >= *nuniq_dev untouched). */
+int realise_glyph_unique(void* stream, const int64_t* ids, int T, int V, int32_t* first_scratch, int32_t* flag_scratch, int64_t* uniq_ids, float* counts,
+                         int32_t* inv, int32_t* bounds, int nhw, const int32_t* hw);
+int realise_segment_sum(void* stream, int dtype, const void* x, const int32_t* inv, int T, int C, float* acc, void* out, const int32_t* nuniq_dev);
+
 /* Eval decode: ids[row] = argmax over the V logits of the row, first maximum wins - replaces
  * `logits.detach().cpu().numpy()` + `np.argmax(preds, axis=-1)` (src/run.py:262-263): only the ids cross PCIe. */
 int realise_argmax(void* stream, int dtype, const void* logits, int64_t ld, int rows, int V, int64_t* ids);

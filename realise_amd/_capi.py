@@ -14,6 +14,21 @@ F32, BF16 = 0, 1
 EPI_STORE, EPI_GELU, EPI_DROP_RESID, EPI_GELU_BWD = 0, 1, 2, 4
 
 
+class GruStep(C.Structure):
+    _fields_ = [("n_alive", C.c_int32), ("H", C.c_int32), ("Tp", C.c_int32), ("t", C.c_int32),
+                ("table", C.c_void_p), ("pho_idx", C.c_void_p), ("perm", C.c_void_p), ("lens", C.c_void_p),
+                ("gh", C.c_void_p), ("b_hh", C.c_void_p), ("h_prev", C.c_void_p), ("h_new", C.c_void_p), ("rzn", C.c_void_p), ("out", C.c_void_p),
+                ("dout", C.c_void_p), ("dh", C.c_void_p), ("dgi", C.c_void_p), ("dgh", C.c_void_p), ("onehot", C.c_void_p)]
+
+
+class Gate(C.Structure):
+    _fields_ = [("B", C.c_int32), ("S", C.c_int32), ("H", C.c_int32),
+                ("bert", C.c_void_p), ("pho", C.c_void_p), ("res", C.c_void_p), ("masks", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p),
+                ("mean", C.c_void_p), ("msum", C.c_void_p), ("g", C.c_void_p), ("fused", C.c_void_p),
+                ("dfused", C.c_void_p), ("dbert", C.c_void_p), ("dpho", C.c_void_p), ("dres", C.c_void_p), ("dz", C.c_void_p), ("dW", C.c_void_p),
+                ("dbias", C.c_void_p)]
+
+
 class AdamwGroup(C.Structure):
     _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
                 ("correct_bias", C.c_int32)]
@@ -89,6 +104,15 @@ SYMBOLS = {
     "realise_layernorm_fwd": (_I, [_P, _I, _P, _P, _P, _F, _P, _P, _P, _I, _I]),
     "realise_layernorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I]),
     "realise_masked_ce": (_I, [_P, _I, _P, _L, _P, _P, _I, _I, _P, _P, _P]),
+    "realise_gru_step_fwd": (_I, [_P, _I, C.POINTER(GruStep)]),
+    "realise_gru_step_bwd": (_I, [_P, _I, C.POINTER(GruStep)]),
+    "realise_gate_fwd": (_I, [_P, _I, C.POINTER(Gate)]),
+    "realise_gate_bwd": (_I, [_P, _I, C.POINTER(Gate)]),
+    "realise_batchnorm_fwd": (_I, [_P, _I, _P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "realise_batchnorm_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P]),
+    "realise_embedding_bwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "realise_glyph_unique": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "realise_segment_sum": (_I, [_P, _I, _P, _P, _I, _I, _P, _P, _P]),
     "realise_argmax": (_I, [_P, _I, _P, _L, _I, _I, _P]),
     "realise_build_pho": (_I, [_P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P]),
     "realise_layout_count": (_I, [C.POINTER(Config)]),

@@ -11,6 +11,7 @@
 #include "../../include/realise_hip_debug.h"
 
 using namespace rl;
+#define RL_TRY(expr) do { const int _rc = (expr); if (_rc != RL_OK) return _rc; } while (0)
 
 struct realise_engine { EngineBase* impl; };
 
@@ -228,6 +229,100 @@ int realise_masked_ce(void* stream, int dtype, const void* logits, int64_t ld, c
   if (dtype == REALISE_F32)
     return ce_loss<float>(st, (const float*)logits, ld, labels, loss_mask, rows, V, loss_out, count_scratch, (float*)dlogits);
   return RL_ERR_ARG;
+}
+
+// ---- remaining fine-grained operators of the path (per-op parity tests call these) ------------------------------------------------
+}  // extern "C"
+namespace {
+template <typename T> GruStepArgs<T> to_gru(const realise_gru_step* g) {
+  GruStepArgs<T> a;
+  a.n_alive = g->n_alive; a.H = g->H; a.Tp = g->Tp; a.t = g->t; a.table = g->table; a.pho_idx = g->pho_idx; a.perm = g->perm; a.lens = g->lens;
+  a.gh = (const T*)g->gh; a.b_hh = g->b_hh; a.h_prev = (const T*)g->h_prev; a.h_new = (T*)g->h_new; a.rzn = (T*)g->rzn; a.out = (T*)g->out;
+  a.dout = (const T*)g->dout; a.dh = (T*)g->dh; a.dgi = (T*)g->dgi; a.dgh = (T*)g->dgh; a.onehot = (T*)g->onehot;
+  return a;
+}
+template <typename T> GateArgs<T> to_gate(const realise_gate* g) {
+  GateArgs<T> a;
+  a.B = g->B; a.S = g->S; a.H = g->H; a.bert = (const T*)g->bert; a.pho = (const T*)g->pho; a.res = (const T*)g->res; a.masks = g->masks;
+  a.W = g->W; a.bias = g->bias; a.mean = g->mean; a.msum = g->msum; a.g = g->g; a.fused = (T*)g->fused; a.dfused = (const T*)g->dfused;
+  a.dbert = (T*)g->dbert; a.dpho = (T*)g->dpho; a.dres = (T*)g->dres; a.dz = g->dz; a.dW = g->dW; a.dbias = g->dbias;
+  return a;
+}
+template <typename T>
+int bn_fwd_t(hipStream_t st, const T* x, int P, int C, const float* gamma, const float* beta, float eps, float momentum, float* rmean, float* rvar,
+             int64_t* nbt, int training, int relu, T* y, float* save_mean, float* save_rstd, float* scratch) {
+  float* sums = scratch; float* sq = scratch + C; float* scale = scratch + 2 * C; float* shift = scratch + 3 * C;
+  if (training) {
+    RL_TRY(fill_f32(st, scratch, 0.0f, 2 * C));
+    RL_TRY(col_sum<T>(st, x, P, C, sums));
+    RL_TRY(bn_finalize_mean(st, sums, C, P, save_mean));
+    RL_TRY(col_sumsq_centered<T>(st, x, P, C, save_mean, sq));
+    RL_TRY(bn_finalize_train(st, save_mean, sq, C, P, gamma, beta, eps, momentum, rmean, rvar, save_rstd, scale, shift, nbt));
+  } else {
+    RL_TRY(bn_finalize_eval(st, C, gamma, beta, eps, rmean, rvar, scale, shift));
+  }
+  return bn_apply<T>(st, x, scale, shift, (const T*)nullptr, nullptr, nullptr, y, P, C, relu);
+}
+template <typename T>
+int bn_bwd_t(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd, const float* gamma, int P, int C,
+             T* dx, float* dgamma, float* dbeta, float* scratch) {
+  RL_TRY(fill_f32(st, scratch, 0.0f, 2 * C));
+  RL_TRY(bn_bwd_reduce<T>(st, dy, relu_src, x, mean, rstd, P, C, scratch));
+  return bn_bwd_apply<T>(st, dy, relu_src, x, mean, rstd, gamma, scratch, P, C, dx, dgamma, dbeta);
+}
+}  // namespace
+extern "C" {
+#define RL_BY_DTYPE(expr_bf16, expr_f32) do { if (dtype == REALISE_BF16) return (expr_bf16); if (dtype == REALISE_F32) return (expr_f32); return RL_ERR_ARG; } while (0)
+int realise_gru_step_fwd(void* stream, int dtype, const realise_gru_step* a) {
+  if (!a) return RL_ERR_ARG;
+  RL_BY_DTYPE(gru_step_fwd<bf16_t>((hipStream_t)stream, to_gru<bf16_t>(a)), gru_step_fwd<float>((hipStream_t)stream, to_gru<float>(a)));
+}
+int realise_gru_step_bwd(void* stream, int dtype, const realise_gru_step* a) {
+  if (!a) return RL_ERR_ARG;
+  RL_BY_DTYPE(gru_step_bwd<bf16_t>((hipStream_t)stream, to_gru<bf16_t>(a)), gru_step_bwd<float>((hipStream_t)stream, to_gru<float>(a)));
+}
+int realise_gate_fwd(void* stream, int dtype, const realise_gate* a) {
+  if (!a) return RL_ERR_ARG;
+  RL_BY_DTYPE(gate_fwd<bf16_t>((hipStream_t)stream, to_gate<bf16_t>(a)), gate_fwd<float>((hipStream_t)stream, to_gate<float>(a)));
+}
+int realise_gate_bwd(void* stream, int dtype, const realise_gate* a) {
+  if (!a) return RL_ERR_ARG;
+  RL_BY_DTYPE(gate_bwd<bf16_t>((hipStream_t)stream, to_gate<bf16_t>(a)), gate_bwd<float>((hipStream_t)stream, to_gate<float>(a)));
+}
+int realise_batchnorm_fwd(void* stream, int dtype, const void* x, int P, int C, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, int training, int relu, void* y,
+                          float* save_mean, float* save_rstd, float* scratch) {
+  if (!x || !y || !scratch || P < 1 || C < 4 || (C & 3)) return RL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RL_BY_DTYPE(bn_fwd_t<bf16_t>(st, (const bf16_t*)x, P, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, training, relu,
+                               (bf16_t*)y, save_mean, save_rstd, scratch),
+              bn_fwd_t<float>(st, (const float*)x, P, C, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, training, relu,
+                              (float*)y, save_mean, save_rstd, scratch));
+}
+int realise_batchnorm_bwd(void* stream, int dtype, const void* dy, const void* relu_src, const void* x, const float* save_mean, const float* save_rstd,
+                          const float* gamma, int P, int C, void* dx, float* dgamma, float* dbeta, float* scratch) {
+  if (!dy || !x || !dx || !scratch || P < 1 || C < 4 || (C & 3)) return RL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RL_BY_DTYPE(bn_bwd_t<bf16_t>(st, (const bf16_t*)dy, (const bf16_t*)relu_src, (const bf16_t*)x, save_mean, save_rstd, gamma, P, C, (bf16_t*)dx, dgamma, dbeta, scratch),
+              bn_bwd_t<float>(st, (const float*)dy, (const float*)relu_src, (const float*)x, save_mean, save_rstd, gamma, P, C, (float*)dx, dgamma, dbeta, scratch));
+}
+int realise_embedding_bwd(void* stream, int dtype, const void* de, const int64_t* ids, int B, int S, int H, float* word_grad, float* pos_grad,
+                          int pos_zero, float* type_grad) {
+  hipStream_t st = (hipStream_t)stream;
+  RL_BY_DTYPE(embed_bwd<bf16_t>(st, (const bf16_t*)de, ids, B, S, H, word_grad, pos_grad, pos_zero, type_grad),
+              embed_bwd<float>(st, (const float*)de, ids, B, S, H, word_grad, pos_grad, pos_zero, type_grad));
+}
+int realise_glyph_unique(void* stream, const int64_t* ids, int T, int V, int32_t* first_scratch, int32_t* flag_scratch, int64_t* uniq_ids, float* counts,
+                         int32_t* inv, int32_t* bounds, int nhw, const int32_t* hw) {
+  if (!ids || T < 1 || V < 1 || nhw < 0 || nhw > 8 || (nhw > 0 && !hw)) return RL_ERR_ARG;
+  HwList h; h.n = nhw;
+  for (int k = 0; k < nhw; ++k) h.v[k] = hw[k];
+  return glyph_unique((hipStream_t)stream, ids, T, V, (int*)first_scratch, (int*)flag_scratch, uniq_ids, counts, (int*)inv, (int*)bounds, h);
+}
+int realise_segment_sum(void* stream, int dtype, const void* x, const int32_t* inv, int T, int C, float* acc, void* out, const int32_t* nuniq_dev) {
+  hipStream_t st = (hipStream_t)stream;
+  RL_BY_DTYPE(segment_sum<bf16_t>(st, (const bf16_t*)x, (const int*)inv, T, C, acc, (bf16_t*)out, (const int*)nuniq_dev),
+              segment_sum<float>(st, (const float*)x, (const int*)inv, T, C, acc, (float*)out, (const int*)nuniq_dev));
 }
 
 // ---- layout --------------------------------------------------------------------------------------

@@ -1,0 +1,363 @@
+"""Per-operator parity tests through the C ABI for the kernels that round 2 only covered inside whole-model runs (VERDICT.md round 2,
+"Next round" item 2): BatchNorm forward / backward, one GRU time step forward / backward, the gated fusion, the embedding-table
+gradient scatter, the glyph dedup bookkeeping + segment sum, and the LDS-resident 64-channel convolution kernels on a multi-image
+batch (>= 4096 images, several images per workgroup) against F.conv2d and, bit for bit, against the implicit-GEMM kernel.
+Every reference is plain PyTorch fp32 of the same operator (src/char_cnn.py:17-28, src/models.py:818-826,840-850,
+transformers/modeling_bert.py:183-190)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from realise_amd import _capi
+
+pytestmark = pytest.mark.gpu
+DT = {"fp32": (_capi.F32, torch.float32), "bf16": (_capi.BF16, torch.bfloat16)}
+
+
+def st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_KEEP = []
+
+
+def p(t):
+    """device pointer of t; the tensor is kept alive until the end of the test (a temporary passed inline would be freed - and its
+    block handed to the next allocation - before the kernel that reads it runs)"""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    return C.c_void_p(t.data_ptr())
+
+
+@pytest.fixture(autouse=True)
+def _release_kept_tensors():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
+def dev(x, dt=torch.float32):
+    return x.to("cuda", dt).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------ BatchNorm
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("relu", [0, 1])
+def test_batchnorm_forward_backward_match_torch(dtype, relu):
+    """nn.BatchNorm2d (train mode) over NHWC viewed as [P, C]: y, saved statistics, running buffers (unbiased variance, momentum 0.1),
+    num_batches_tracked, then dx / dgamma / dbeta through the fused ReLU - against F.batch_norm + autograd in fp32."""
+    lib = _capi.load()
+    code, tdt = DT[dtype]
+    g = torch.Generator().manual_seed(3)
+    N, Hh, Cc = 96, 8, 64
+    P = N * Hh * Hh
+    x = (torch.randn(P, Cc, generator=g) * 1.7 + torch.linspace(-2, 2, Cc)).to(tdt)
+    gamma = torch.rand(Cc, generator=g) + 0.5
+    beta = torch.randn(Cc, generator=g) * 0.3
+    rm0, rv0 = torch.randn(Cc, generator=g) * 0.1, torch.rand(Cc, generator=g) + 0.5
+    dy = torch.randn(P, Cc, generator=g).to(tdt)
+    # reference (fp32 on the rounded inputs)
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    yr = F.batch_norm(xr.t().reshape(1, Cc, P), rm, rv, gr, br, True, 0.1, 1e-5).reshape(Cc, P).t()
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy.float())
+    # ours
+    xd, yd = dev(x, tdt), torch.empty(P, Cc, device="cuda", dtype=tdt)
+    rmd, rvd = dev(rm0), dev(rv0)
+    nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    sm, sr = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    scratch = torch.empty(4 * Cc, device="cuda")
+    _capi.check(lib.realise_batchnorm_fwd(st(), code, p(xd), P, Cc, p(dev(gamma)), p(dev(beta)), C.c_float(1e-5), C.c_float(0.1), p(rmd), p(rvd),
+                                          p(nbt), 1, relu, p(yd), p(sm), p(sr), p(scratch)), "bn fwd")
+    tol = 1e-4 if dtype == "fp32" else 3e-2
+    assert (yd.float().cpu() - yr.detach()).abs().max().item() < tol
+    assert (rmd.cpu() - rm).abs().max().item() < 1e-5 and (rvd.cpu() - rv).abs().max().item() < 1e-4
+    assert int(nbt.item()) == 1
+    mean_ref = x.float().mean(0)
+    assert (sm.cpu() - mean_ref).abs().max().item() < 1e-4
+    dxd = torch.empty(P, Cc, device="cuda", dtype=tdt)
+    dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    _capi.check(lib.realise_batchnorm_bwd(st(), code, p(dev(dy, tdt)), p(yd) if relu else None, p(xd), p(sm), p(sr), p(dev(gamma)), P, Cc, p(dxd),
+                                          p(dg), p(db), p(scratch)), "bn bwd")
+    torch.cuda.synchronize()
+    if dtype == "fp32":
+        # the ReLU mask is read from OUR y: elements within rounding of zero may sit on the other side than in the reference
+        flips = ((yd.cpu() > 0) != (yr.detach() > 0)).sum().item() if relu else 0
+        assert flips <= 2
+        assert (dxd.cpu() - xr.grad).abs().max().item() < (2e-4 if flips == 0 else 5e-2)
+        assert (dg.cpu() - gr.grad).abs().max().item() < 2e-2 and (db.cpu() - br.grad).abs().max().item() < 2e-2
+        assert (dg.cpu() - gr.grad).abs().max().item() < 2e-4 * gr.grad.abs().max().item() + 1e-3
+    else:
+        cos = F.cosine_similarity(dxd.float().cpu().reshape(-1), xr.grad.reshape(-1), dim=0).item()
+        assert cos > 0.995
+        assert F.cosine_similarity(dg.cpu(), gr.grad, dim=0).item() > 0.999 and F.cosine_similarity(db.cpu(), br.grad, dim=0).item() > 0.999
+
+
+def test_batchnorm_eval_uses_running_statistics():
+    lib = _capi.load()
+    P, Cc = 4096, 128
+    x = torch.randn(P, Cc)
+    gamma, beta, rm, rv = torch.rand(Cc) + 0.5, torch.randn(Cc), torch.randn(Cc) * 0.2, torch.rand(Cc) + 0.3
+    ref = F.batch_norm(x.t().reshape(1, Cc, P), rm.clone(), rv.clone(), gamma, beta, False, 0.1, 1e-5).reshape(Cc, P).t()
+    yd = torch.empty(P, Cc, device="cuda")
+    rmd, rvd = dev(rm), dev(rv)
+    _capi.check(lib.realise_batchnorm_fwd(st(), _capi.F32, p(dev(x)), P, Cc, p(dev(gamma)), p(dev(beta)), C.c_float(1e-5), C.c_float(0.1), p(rmd), p(rvd),
+                                          None, 0, 0, p(yd), None, None, p(torch.empty(4 * Cc, device="cuda"))), "bn eval")
+    assert (yd.cpu() - ref).abs().max().item() < 1e-5
+    assert torch.equal(rmd.cpu(), rm) and torch.equal(rvd.cpu(), rv)              # eval leaves the buffers alone
+
+
+# ------------------------------------------------------------------------------------------------------------ GRU step
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gru_time_steps_match_torch_gru_cell(dtype):
+    """Three steps of the length-sorted pinyin GRU (models.py:818-826): every step's gates / new hidden state against nn.GRUCell on
+    the rows still alive, the per-token output written when a sequence ends, and one BPTT step against autograd."""
+    lib = _capi.load()
+    code, tdt = DT[dtype]
+    gen = torch.Generator().manual_seed(5)
+    H, V, N, Tp = 768, 33, 40, 3
+    lens_tok = torch.randint(1, Tp + 1, (N,), generator=gen)
+    order = torch.argsort(-lens_tok, stable=True)
+    lens_sorted = lens_tok[order].to(torch.int32)
+    pho_idx = torch.randint(1, V, (N, Tp), generator=gen)
+    cell = torch.nn.GRUCell(H, H)
+    emb = torch.randn(V, H, generator=gen) * 0.5
+    with torch.no_grad():
+        for w in cell.parameters():
+            w.copy_(torch.randn(w.shape, generator=gen) * 0.05)
+        table = emb @ cell.weight_ih.t() + cell.bias_ih                              # [V][3H]
+    h_prev = torch.zeros(N, H)
+    out_ref = torch.zeros(N, H)
+    out_d = torch.zeros(N, H, device="cuda", dtype=tdt)
+    tab_d, perm_d, lens_d, idx_d = dev(table), dev(order, torch.int32), dev(lens_sorted, torch.int32), dev(pho_idx, torch.int64)
+    bhh_d = dev(cell.bias_hh.detach())
+    hp_d = None
+    tol = 2e-5 if dtype == "fp32" else 2e-2
+    for t in range(Tp):
+        n_alive = int((lens_sorted > t).sum())
+        xs = emb[pho_idx[order[:n_alive], t]]
+        with torch.no_grad():
+            h_new_ref = cell(xs, h_prev[:n_alive])
+            gh = h_prev[:n_alive] @ cell.weight_hh.t() + cell.bias_hh
+        a = _capi.GruStep()
+        a.n_alive, a.H, a.Tp, a.t = n_alive, H, Tp, t
+        a.table, a.pho_idx, a.perm, a.lens = tab_d.data_ptr(), idx_d.data_ptr(), perm_d.data_ptr(), lens_d.data_ptr()
+        gh_d = dev(gh, tdt) if t > 0 else None
+        a.gh = gh_d.data_ptr() if gh_d is not None else None
+        a.b_hh = bhh_d.data_ptr()
+        a.h_prev = hp_d.data_ptr() if hp_d is not None else None
+        hn_d = torch.zeros(N, H, device="cuda", dtype=tdt)
+        rzn_d = torch.zeros(N, 3 * H, device="cuda", dtype=tdt)
+        a.h_new, a.rzn, a.out = hn_d.data_ptr(), rzn_d.data_ptr(), out_d.data_ptr()
+        _capi.check(lib.realise_gru_step_fwd(st(), code, C.byref(a)), "gru fwd")
+        torch.cuda.synchronize()
+        assert (hn_d[:n_alive].float().cpu() - h_new_ref).abs().max().item() < tol, t
+        ends = (lens_sorted[:n_alive] == t + 1)
+        out_ref[order[:n_alive][ends]] = h_new_ref[ends]
+        h_prev = torch.zeros(N, H)
+        h_prev[:n_alive] = hn_d[:n_alive].float().cpu() if dtype == "bf16" else h_new_ref
+        hp_d = hn_d
+    assert (out_d.float().cpu() - out_ref).abs().max().item() < tol
+    # one BPTT step at t = 1 (rows with length >= 2), fp32 only: dgi / dgh / dh against autograd of the cell
+    if dtype == "fp32":
+        t = 1
+        n_alive = int((lens_sorted > t).sum())
+        xs = emb[pho_idx[order[:n_alive], t]].clone()
+        h0 = (torch.randn(n_alive, H, generator=gen) * 0.3).requires_grad_(True)
+        gi = (xs @ cell.weight_ih.t() + cell.bias_ih).detach().requires_grad_(True)
+        gh = (h0 @ cell.weight_hh.t() + cell.bias_hh)
+        gh_leaf = gh.detach().requires_grad_(True)
+        ir, iz, inn = gi.chunk(3, 1)
+        hr, hz, hn = gh_leaf.chunk(3, 1)
+        r, z = torch.sigmoid(ir + hr), torch.sigmoid(iz + hz)
+        n = torch.tanh(inn + r * hn)
+        hnew = (1 - z) * n + z * h0.detach()
+        dh_in = torch.randn(n_alive, H, generator=gen)
+        dout = torch.randn(N, H, generator=gen)
+        ends = lens_sorted[:n_alive] == t + 1
+        upstream = torch.where(ends[:, None], dout[order[:n_alive]], dh_in)
+        hnew.backward(upstream)
+        a = _capi.GruStep()
+        a.n_alive, a.H, a.Tp, a.t = n_alive, H, Tp, t
+        a.table, a.pho_idx, a.perm, a.lens = tab_d.data_ptr(), idx_d.data_ptr(), perm_d.data_ptr(), lens_d.data_ptr()
+        rzn = dev(torch.cat([r, z, n], 1).detach())
+        gh_dd, hp_dd, dout_d = dev(gh.detach()), dev(h0.detach()), dev(dout)
+        dh_d = dev(torch.cat([dh_in, torch.zeros(N - n_alive, H)], 0))
+        dgi_d, dgh_d = torch.zeros(N, 3 * H, device="cuda"), torch.zeros(N, 3 * H, device="cuda")
+        oh_d = torch.zeros(N, 64, device="cuda")
+        a.gh, a.b_hh, a.h_prev, a.rzn = gh_dd.data_ptr(), bhh_d.data_ptr(), hp_dd.data_ptr(), rzn.data_ptr()
+        a.dout, a.dh, a.dgi, a.dgh, a.onehot = dout_d.data_ptr(), dh_d.data_ptr(), dgi_d.data_ptr(), dgh_d.data_ptr(), oh_d.data_ptr()
+        _capi.check(lib.realise_gru_step_bwd(st(), code, C.byref(a)), "gru bwd")
+        torch.cuda.synchronize()
+        assert (dgi_d[:n_alive].cpu() - gi.grad).abs().max().item() < 2e-5
+        assert (dgh_d[:n_alive].cpu() - gh_leaf.grad).abs().max().item() < 2e-5
+        # dL/dh_prev through the z path only (the W_hh path is the caller's GEMM on dgh)
+        assert (dh_d[:n_alive].cpu() - upstream * z.detach()).abs().max().item() < 2e-5
+        assert torch.equal(oh_d[:n_alive].cpu().argmax(1), pho_idx[order[:n_alive], t])
+
+
+# ------------------------------------------------------------------------------------------------------------ gate
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gate_fusion_forward_backward_match_torch(dtype):
+    lib = _capi.load()
+    code, tdt = DT[dtype]
+    gen = torch.Generator().manual_seed(7)
+    B, S, H = 6, 32, 768
+    bert, pho, res = [(torch.randn(B, S, H, generator=gen) * 0.7).to(tdt) for _ in range(3)]
+    masks = torch.zeros(B, S, dtype=torch.int64)
+    for b in range(B):
+        masks[b, :int(torch.randint(4, S + 1, (1,), generator=gen))] = 1
+    W = torch.randn(3, 4 * H, generator=gen) * 0.03
+    bias = torch.randn(3, generator=gen) * 0.1
+    dfused = torch.randn(B, S, H, generator=gen).to(tdt)
+    xb, xp, xr = [t.float().clone().requires_grad_(True) for t in (bert, pho, res)]
+    Wr, br = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    m = masks.float()
+    mean = (xb * m[..., None]).sum(1) / m.sum(1, keepdim=True)                      # models.py:842-843
+    cat = torch.cat([xb, xp, xr, mean[:, None, :].expand(-1, S, -1)], -1)           # :844-846
+    gates = torch.sigmoid(cat @ Wr.t() + br)                                        # :847
+    fused = gates[..., 0:1] * xb + gates[..., 1:2] * xp + gates[..., 2:3] * xr      # :848-850
+    fused.backward(dfused.float())
+    a = _capi.Gate()
+    a.B, a.S, a.H = B, S, H
+    keep = [dev(bert, tdt), dev(pho, tdt), dev(res, tdt), dev(masks, torch.int64), dev(W), dev(bias), torch.empty(B, H, device="cuda"),
+            torch.empty(B, device="cuda"), torch.empty(B * S, 4, device="cuda"), torch.empty(B, S, H, device="cuda", dtype=tdt), dev(dfused, tdt),
+            torch.zeros(B, S, H, device="cuda", dtype=tdt), torch.zeros(B, S, H, device="cuda", dtype=tdt), torch.zeros(B, S, H, device="cuda", dtype=tdt),
+            torch.empty(B * S, 4, device="cuda"), torch.zeros(3, 4 * H, device="cuda"), torch.zeros(3, device="cuda")]
+    (a.bert, a.pho, a.res, a.masks, a.W, a.bias, a.mean, a.msum, a.g, a.fused, a.dfused, a.dbert, a.dpho, a.dres, a.dz, a.dW, a.dbias) = [t.data_ptr() for t in keep]
+    _capi.check(lib.realise_gate_fwd(st(), code, C.byref(a)), "gate fwd")
+    _capi.check(lib.realise_gate_bwd(st(), code, C.byref(a)), "gate bwd")
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == "fp32" else 3e-2
+    assert (keep[9].float().cpu() - fused.detach()).abs().max().item() < tol
+    if dtype == "fp32":
+        for ours, ref in ((keep[11], xb.grad), (keep[12], xp.grad), (keep[13], xr.grad)):
+            assert (ours.cpu() - ref).abs().max().item() < 5e-5
+        assert (keep[15].cpu() - Wr.grad).abs().max().item() < 2e-4 and (keep[16].cpu() - br.grad).abs().max().item() < 2e-4
+    else:
+        for ours, ref in ((keep[11], xb.grad), (keep[12], xp.grad), (keep[13], xr.grad)):
+            assert F.cosine_similarity(ours.float().cpu().reshape(-1), ref.reshape(-1), dim=0).item() > 0.999
+        assert F.cosine_similarity(keep[15].cpu().reshape(-1), Wr.grad.reshape(-1), dim=0).item() > 0.999
+
+
+# ------------------------------------------------------------------------------------------------------------ embeddings
+@pytest.mark.parametrize("pos_zero", [0, 1])
+def test_embedding_table_gradients_match_index_add(pos_zero):
+    lib = _capi.load()
+    gen = torch.Generator().manual_seed(9)
+    B, S, H, V = 8, 24, 768, 300
+    ids = torch.randint(1, V, (B, S), generator=gen)
+    de = torch.randn(B, S, H, generator=gen)
+    de[:, S - 5:, :] = 0.0                                   # padded positions: exactly-zero gradients, all on id 0
+    ids[:, S - 5:] = 0
+    word = torch.zeros(V, H).index_add_(0, ids.reshape(-1), de.reshape(-1, H))
+    pos = torch.zeros(S, H)
+    if pos_zero:
+        pos[0] = de.sum((0, 1))
+    else:
+        pos = de.sum(0)
+    typ = de.sum((0, 1))
+    wd, pd, td = torch.zeros(V, H, device="cuda"), torch.zeros(S, H, device="cuda"), torch.zeros(2, H, device="cuda")
+    _capi.check(lib.realise_embedding_bwd(st(), _capi.F32, p(dev(de)), p(dev(ids, torch.int64)), B, S, H, p(wd), p(pd), pos_zero, p(td)), "embed bwd")
+    torch.cuda.synchronize()
+    assert (wd.cpu() - word).abs().max().item() < 1e-4
+    assert (pd.cpu() - pos).abs().max().item() < 2e-4
+    assert (td[0].cpu() - typ).abs().max().item() < 2e-4 and float(td[1].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------ glyph dedup
+def test_glyph_unique_and_segment_sum():
+    lib = _capi.load()
+    gen = torch.Generator().manual_seed(11)
+    T_, V, Cc = 5000, 900, 64
+    ids = torch.randint(0, V, (T_,), generator=gen)
+    ids[::3] = 0                                             # a heavy PAD class
+    ids_d = dev(ids, torch.int64)
+    first, flag = torch.empty(V, dtype=torch.int32, device="cuda"), torch.empty(T_, dtype=torch.int32, device="cuda")
+    uniq, counts = torch.zeros(T_, dtype=torch.int64, device="cuda"), torch.zeros(T_, device="cuda")
+    inv, bounds = torch.zeros(T_, dtype=torch.int32, device="cuda"), torch.zeros(4, dtype=torch.int32, device="cuda")
+    hw = torch.tensor([256, 64], dtype=torch.int32)
+    _capi.check(lib.realise_glyph_unique(st(), p(ids_d), T_, V, p(first), p(flag), p(uniq), p(counts), p(inv), p(bounds), 2, hw.data_ptr()), "glyph_unique")
+    torch.cuda.synchronize()
+    # reference: distinct ids in order of first occurrence
+    seen, order = {}, []
+    for t, v in enumerate(ids.tolist()):
+        if v not in seen:
+            seen[v] = len(order)
+            order.append(v)
+    U = len(order)
+    assert bounds.cpu().tolist()[:3] == [U, U * 256, U * 64]
+    assert uniq[:U].cpu().tolist() == order
+    assert inv.cpu().tolist() == [seen[v] for v in ids.tolist()]
+    cnt = torch.bincount(torch.tensor([seen[v] for v in ids.tolist()]), minlength=U).float()
+    assert torch.equal(counts[:U].cpu(), cnt)
+    x = torch.randn(T_, Cc, generator=gen)
+    acc, out = torch.empty(T_ * Cc, device="cuda"), torch.full((T_, Cc), -7.0, device="cuda")
+    _capi.check(lib.realise_segment_sum(st(), _capi.F32, p(dev(x)), p(inv), T_, Cc, p(acc), p(out), p(bounds)), "segment_sum")
+    torch.cuda.synchronize()
+    ref = torch.zeros(U, Cc).index_add_(0, inv.cpu().long(), x)
+    assert (out[:U].cpu() - ref).abs().max().item() < 1e-3
+    assert float((out[U:] + 7.0).abs().max()) == 0.0        # rows beyond the distinct count untouched
+
+
+# ------------------------------------------------------------------------------------------------------------ 64-channel LDS-resident convolutions
+def _geom(src, rows, Hr, Hs, Cc, k, stride, pad, mode):
+    g = _capi.ConvGeom()
+    g.src = src.data_ptr(); g.img_index = None
+    g.rows, g.Hr, g.Wr, g.Hs, g.Ws, g.C, g.KH, g.KW, g.stride, g.pad, g.mode = rows, Hr, Hr, Hs, Hs, Cc, k, k, stride, pad, mode
+    return g
+
+
+def test_conv_c64_kernels_on_a_multi_image_batch_match_conv2d_and_the_generic_kernel():
+    """block 1's 64 -> 64 channel 3x3 convolution on 16 x 16 maps over 4352 images (17 per workgroup slot: the double-buffered walk
+    over images of conv_c64_nt, the pixel-range split + fold of conv_wgrad_c64): forward, input gradient and weight gradient against
+    F.conv2d in fp32 on the same bf16 inputs, and BIT-IDENTICAL to the implicit-GEMM kernels (realise_set_conv_c64(0))."""
+    lib = _capi.load()
+    gen = torch.Generator().manual_seed(13)
+    Nimg, Hh, Cc = 4352, 16, 64
+    x = (torch.randn(Nimg, Hh, Hh, Cc, generator=gen) * 0.5).bfloat16()
+    w = (torch.randn(Cc, Cc, 3, 3, generator=gen) * 0.05)
+    dy = (torch.randn(Nimg, Hh, Hh, Cc, generator=gen) * 0.5).bfloat16()
+    rows = Nimg * Hh * Hh
+    xd, dyd = x.cuda(), dy.cuda()
+    wf = w.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc).bfloat16().cuda().contiguous()                 # [co][tap][ci]
+    wdg = w.permute(1, 2, 3, 0).reshape(Cc, 9 * Cc).bfloat16().cuda().contiguous()                # [ci][tap][co]
+    res = {}
+    try:
+        for fast in (1, 0):
+            lib.realise_set_conv_c64(fast)
+            y = torch.empty(rows, Cc, device="cuda", dtype=torch.bfloat16)
+            dx = torch.empty(rows, Cc, device="cuda", dtype=torch.bfloat16)
+            ep = _capi.Epilogue()
+            ep.mode, ep.out, ep.ldo, ep.alpha, ep.drop_scale = 0, y.data_ptr(), Cc, 1.0, 1.0
+            ga = _geom(xd, rows, Hh, Hh, Cc, 3, 1, 1, 0)
+            _capi.check(lib.realise_conv_nt(st(), _capi.BF16, C.byref(ga), p(wf), 9 * Cc, rows, Cc, 9 * Cc, C.byref(ep)), "conv fwd")
+            ep.out = dx.data_ptr()
+            gb = _geom(dyd, rows, Hh, Hh, Cc, 3, 1, 1, 1)
+            _capi.check(lib.realise_conv_nt(st(), _capi.BF16, C.byref(gb), p(wdg), 9 * Cc, rows, Cc, 9 * Cc, C.byref(ep)), "conv dgrad")
+            dw = torch.zeros(Cc, Cc, 3, 3, device="cuda")
+            scratch = torch.empty(16 << 20, device="cuda")
+            gc = _geom(xd, rows, Hh, Hh, Cc, 3, 1, 1, 0)
+            _capi.check(lib.realise_conv_tn(st(), _capi.BF16, p(dyd), Cc, C.byref(gc), rows, Cc, Cc, p(dw), p(scratch), scratch.numel()), "conv wgrad")
+            torch.cuda.synchronize()
+            res[fast] = (y.clone(), dx.clone(), dw.clone())
+    finally:
+        lib.realise_set_conv_c64(1)
+    assert torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][1], res[0][1])          # forward / input gradient: bit-identical
+    assert (res[1][2] - res[0][2]).abs().max().item() < 1e-3 * res[0][2].abs().max().item() # weight gradient: other reduction order
+    xr = x.float().permute(0, 3, 1, 2).cuda().requires_grad_(True)
+    wr = w.bfloat16().float().cuda().requires_grad_(True)
+    yr = F.conv2d(xr, wr, padding=1)
+    yr.backward(dy.float().permute(0, 3, 1, 2).cuda())
+    yo = res[1][0].float().reshape(Nimg, Hh, Hh, Cc).permute(0, 3, 1, 2)
+    assert (yo - yr.detach()).abs().max().item() < 3e-2 and (yo - yr.detach()).abs().mean().item() < 2e-3
+    dxo = res[1][1].float().reshape(Nimg, Hh, Hh, Cc).permute(0, 3, 1, 2)
+    assert (dxo - xr.grad).abs().max().item() < 3e-2
+    assert (res[1][2] - wr.grad).abs().max().item() < 2e-3 * wr.grad.abs().max().item() + 1e-2
