@@ -165,11 +165,14 @@ def load():
     # resolve to ONE HIP runtime (loading /opt/rocm's copy first and torch's second gives two runtimes whose
     # streams / kernels do not mix: every launch on a torch stream then fails).
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    if os.environ.get("REALISE_HIP_PROBES") == "1":      # measurement sessions: the probe build (python -m realise_amd.build --probes)
+        path = LIB_PATH.replace(".so", "_probes.so")
+    if not os.path.exists(path):
         raise RealiseHipError(
-            "librealise_hip.so is missing (%s). Build it with `python -m realise_amd.build` "
-            "(or __graft_entry__.build()); the HIP path has no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "%s is missing. Build it with `python -m realise_amd.build` "
+            "(or __graft_entry__.build()); the HIP path has no CPU fallback." % path)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError here == header / library mismatch
         fn.restype = res

@@ -71,7 +71,7 @@ static int tn_grouped(hipStream_t st, int n, const realise_tn_problem* pr, int P
 
 extern "C" {
 
-const char* realise_version(void) { return "realise_hip 0.1 (gfx950)"; }
+const char* realise_version(void) { return RL_PROBES ? "realise_hip 0.3 (gfx950) +probes" : "realise_hip 0.3 (gfx950)"; }
 
 int realise_gemm_nt(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
                     const realise_epilogue* ep) {

@@ -196,6 +196,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 
 }  // namespace rl
 
+// Probe build (python -m realise_amd.build --probes -> librealise_hip_probes.so): the measured-and-rejected kernel variants
+// (realise_set_nt_variant 1..8 / 11..44, realise_set_tn_variant 8) and the "no fetch / no MFMA" probe modes of the production kernels.
+// The production library compiles them out: its kernels carry no probe branches.
+#ifndef RL_PROBES
+#define RL_PROBES 0
+#endif
+
 #define RL_OK 0
 #define RL_ERR_ARG 1
 #define RL_ERR_LAUNCH 2

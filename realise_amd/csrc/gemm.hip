@@ -78,7 +78,7 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
   constexpr bool kDenseA = sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
   typename ALoader::Ctx actx[kDenseA ? NA : 1];
   typename DenseLoader<T>::Ctx bctx[NB];
-  const int m0f = ep.probe == 1 ? 0 : m0, n0f = ep.probe == 1 ? 0 : n0;
+  const int m0f = (RL_PROBES && ep.probe == 1) ? 0 : m0, n0f = (RL_PROBES && ep.probe == 1) ? 0 : n0;
   if constexpr (kDenseA) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) actx[j] = la.prepare(m0f + (wave * NA + j) * 8 + lrow);
@@ -122,7 +122,7 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
     for (int j = 0; j < NF; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   auto issue = [&](int stage) {                      // fetch the next K-tile, then advance the positions
-    if (ep.probe == 2) return;
+    if (RL_PROBES && ep.probe == 2) return;
     char* base = smem + stage * STAGE;
     const bool f = kt_issue < nfast;                 // this tile is addressed by pointer stepping
     if constexpr (!kDenseA) {
@@ -181,11 +181,11 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
     const bool more = kt + NSTAGE - 1 < nk;
     const int nstage = (kt + NSTAGE - 1) % NSTAGE;
     constexpr bool kSpread = SPREAD && kDenseA && sizeof(T) == 2;
-    const bool spread = kSpread && fast_all && ep.probe == 0;
+    const bool spread = kSpread && fast_all && (!RL_PROBES || ep.probe == 0);
     if (more && !spread) issue(nstage);
     const char* As = smem + (kt % NSTAGE) * STAGE;
     const char* Bs = As + A_BYTES;
-    if (ep.probe == 3) continue;
+    if (RL_PROBES && ep.probe == 3) continue;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
       typename Mma::Frag a[4], b[NF];
@@ -238,14 +238,15 @@ void set_nt_allow_n96(int on) { g_nt_n96 = on; }
 static int g_nt_probe = 0, g_nt_wide = 1, g_nt_variant = 0;
 static int g_conv_c64 = 1;          // block-1 conv2 (64 channels, 16x16 maps) through the LDS-resident kernels conv_c64_nt.hip / conv_wgrad_c64.hip
 void set_conv_c64(int on) { g_conv_c64 = on; }
-void set_nt_variant(int v) { g_nt_variant = v; }
+void set_nt_variant(int v) { g_nt_variant = (RL_PROBES || v == 0 || v == 9 || v == 12 || v == 16 || v >= 50) ? v : 0; }     // production: 0, 9 (4-wave), 12 / 16 (the two shipped 8-wave tiles), 50 / 51 (persistent on / off)
 static int g_tn_probe = 0, g_tn_split = 0;
 void set_tn_split(int n) { g_tn_split = n; }
-void set_tn_probe(int mode) { g_tn_probe = mode; }
+void set_tn_probe(int mode) { g_tn_probe = RL_PROBES ? mode : 0; }
 void set_nt_wide_epilogue(int on) { g_nt_wide = on; }
-void set_nt_probe(int mode) { g_nt_probe = mode; set_nt8_probe(mode); }
+void set_nt_probe(int mode) { g_nt_probe = RL_PROBES ? mode : 0; set_nt8_probe(RL_PROBES ? mode : 0); }
 
 
+#if RL_PROBES
 // =================================================================================================
 // Phase-shifted 8-wave NT kernel (EXPERIMENTAL, variant 8 of realise_set_nt_variant): 256 x 128 tile, waves
 // 0-3 (group A) and 4-7 (group B) share the SIMDs pairwise and run half a K-tile out of phase - one group's MFMA phase
@@ -387,6 +388,8 @@ static int launch_nt_pp(hipStream_t st, const DenseLoader<bf16_t>& la, const Den
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
+#endif  // RL_PROBES
+
 template <typename T, typename ALoader, int WM, int WN, int NSTAGE = 2, int NF = 4, bool SPREAD = false>
 static int launch_nt_tile(hipStream_t st, const ALoader& la, const DenseLoader<T>& lb, int M, int N, int K, const EpiParams<T>& ep) {
   constexpr int BM_ = 64 * WM, BN_ = 16 * NF * WN;
@@ -434,6 +437,7 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
     if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 44) || g_nt_variant >= 50)) {
       if (nt8_supported(M, N, K, ep, la.ld, ldb)) return gemm_nt8(st, la.base, la.ld, B, ldb, M, N, K, ep, (g_nt_variant >= 10 && g_nt_variant < 50) ? g_nt_variant - 10 : 0);
     }
+#if RL_PROBES
     switch (g_nt_variant) {       // experimental tile shapes (tools/nt_probe.cpp)
       case 1: return launch_nt_tile<T, ALoader, 2, 4, 2, 3>(st, la, lb, M, N, K, ep);     // 128 x 192, 8 waves, 2 stages
       case 2: return launch_nt_tile<T, ALoader, 2, 4, 3, 3>(st, la, lb, M, N, K, ep);     // 128 x 192, 3 stages
@@ -447,6 +451,7 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
               break;
       default: break;
     }
+#endif
     // very wide outputs (the 21128-column classifier: > 20 rounds of 128x128 tiles): 8-wave 256x128 tiles cut the
     // operand traffic per flop by a third; three stages and the fetches spread between the MFMA groups keep the single
     // resident workgroup fed (730 vs 644 TF, tools/nt_probe.cpp).  Below ~8 rounds the 4-wave tiles win.
@@ -622,7 +627,7 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
     }
   }
   auto issue = [&](int pt, int stage) {
-    if (ep.probe == 2) return;
+    if (RL_PROBES && ep.probe == 2) return;
     char* base = smem + stage * STAGE;
     const bool full = pt + BP <= p_end;
 #pragma unroll
@@ -669,7 +674,7 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
     const int cur = t % NST;
     const char* At = smem + cur * STAGE;
     const char* Bt = At + A_BYTES;
-    if (ep.probe == 3) continue;
+    if (RL_PROBES && ep.probe == 3) continue;
 #pragma unroll
     for (int ks = 0; ks < KST; ++ks) {
       typename Mma::Frag a[4], b[4];
@@ -893,7 +898,7 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb,
 }
 
 static int g_tn_variant = 0;      // 0 production (the 4-wave kernel), 8 the experimental 8-wave ping-pong kernel (gemm_tn8.hip: correct, 7-16 % slower)
-void set_tn_variant(int v) { g_tn_variant = v; }
+void set_tn_variant(int v) { g_tn_variant = RL_PROBES ? v : 0; }
 
 static int g_tn_group_ring = 0;      // measured: 4 x 32-row stages 3.76 ms/step vs 3.39 for 2 x 64-row stages (more barriers, smaller DMA batches)
 void set_tn_group_ring(int on) { g_tn_group_ring = on; }
@@ -940,8 +945,10 @@ int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, in
             const int* rows_dev) {
   if (ldb % TnGeo<T>::VEC) return RL_ERR_ARG;
   if constexpr (sizeof(T) == 2) {
+#if RL_PROBES
     if (rows_dev == nullptr && g_tn_variant == 8 && g_tn_probe == 0 && tn8_supported(lda, ldb, P, I, J, ep))
       return gemm_tn8(st, A, lda, B, ldb, P, I, J, ep, g_tn_split);
+#endif
   }
   DenseLoader<T> lb{B, ldb, P, J};
   lb.rows_dev = rows_dev;

@@ -230,22 +230,27 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<C, 0, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+#if RL_PROBES
     if constexpr (!KTAIL) {
       (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
       (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<C, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     }
+#endif
     attr_set = true;
   }
   ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
+#if RL_PROBES
   if constexpr (!KTAIL) {
     if (g_nt8_probe == 2) { RL_LAUNCH((gemm_nt8_kernel<C, 2>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
     if (g_nt8_probe == 3) { RL_LAUNCH((gemm_nt8_kernel<C, 3>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
   }
+#endif
   RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
 
+#if RL_PROBES
 // =================================================================================================
 // Warp-specialised form: 8 consumer waves + 4 LOADER waves (768 threads, 3 waves per SIMD, <= 168 VGPRs).
 // tools/clock_probe.cpp measured why: a wave that both fetches and multiplies serialises the two in its in-order stream (LDS-DMA
@@ -467,6 +472,8 @@ static int launch_nt8ws_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const 
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
+#endif  // RL_PROBES
+
 //             BM   BN  WM WN hold_B SQ NS LEAD issue_in_MFMA_segment
 typedef Nt8Cfg<256, 256, 2, 4, true, 2, 2, 5> Cfg256x256;      // wave 128 x 64, 4 phases of 16 MFMAs
 typedef Nt8Cfg<256, 192, 4, 2, false, 2, 2, 4> Cfg256x192;     // wave  64 x 96, 3 phases of 16 MFMAs
@@ -507,8 +514,11 @@ int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int6
     // K = 2304 / 3072 shapes equal (tools/nt8_probe.cpp ws, profiles/round2_nt8_probe.log)
     tile = 6;
   }
+#if !RL_PROBES
+  if (tile == 0) tile = 2;               // wide outputs the persistent kernel does not take: 256 x 192, one workgroup per CU
+#endif
   if (tile == 0) {
-    // chip fill: rounds of 256 one-per-CU workgroups; among the shapes pick the least (rounds x MFMA time of one tile), ties to
+    // (probe build) chip fill: rounds of 256 one-per-CU workgroups; among the shapes pick the least (rounds x MFMA time of one tile), ties to
     // the larger tile (fewer fetched bytes per flop).  The classifier (N = 21128) lands on 256x192: 303 us against 340 for the
     // two-per-CU shape, which is fetch-bound there.
     struct Cand { int id, bm, bn; } cands[4] = {{1, 256, 256}, {2, 256, 192}, {3, 256, 128}, {4, 128, 192}};
@@ -522,8 +532,10 @@ int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int6
     }
   }
   switch (tile + flavour) {
-    case 1: return launch_nt8_cfg<Cfg256x256>(st, A, lda, B, ldb, M, N, K, ep);
     case 2: return launch_nt8_cfg<Cfg256x192>(st, A, lda, B, ldb, M, N, K, ep);
+    case 6: return launch_nt8_cfg<Cfg128x192q>(st, A, lda, B, ldb, M, N, K, ep);
+#if RL_PROBES
+    case 1: return launch_nt8_cfg<Cfg256x256>(st, A, lda, B, ldb, M, N, K, ep);
     case 3: return launch_nt8_cfg<Cfg256x128>(st, A, lda, B, ldb, M, N, K, ep);
     case 4: return launch_nt8_cfg<Cfg128x192>(st, A, lda, B, ldb, M, N, K, ep);
     case 11: return launch_nt8_cfg<Cfg256x256c>(st, A, lda, B, ldb, M, N, K, ep);
@@ -535,10 +547,10 @@ int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int6
     case 23: return launch_nt8_cfg<Cfg256x128f>(st, A, lda, B, ldb, M, N, K, ep);
     case 24: return launch_nt8_cfg<Cfg128x192f>(st, A, lda, B, ldb, M, N, K, ep);
     case 5: return launch_nt8_cfg<Cfg128x192p>(st, A, lda, B, ldb, M, N, K, ep);
-    case 6: return launch_nt8_cfg<Cfg128x192q>(st, A, lda, B, ldb, M, N, K, ep);
     case 32: return launch_nt8ws_cfg<Cfg256x192w>(st, A, lda, B, ldb, M, N, K, ep);
     case 33: return launch_nt8ws_cfg<Cfg256x128w>(st, A, lda, B, ldb, M, N, K, ep);
     case 34: return launch_nt8ws_cfg<Cfg128x192w>(st, A, lda, B, ldb, M, N, K, ep);
+#endif
     default: return RL_ERR_ARG;
   }
 }
