@@ -200,6 +200,11 @@ int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_
 int realise_engine_refresh_shadows(realise_engine* e, void* stream);
 /* the frozen glyph table (arena 2) changed: rebuild its NHWC operand image at the next refresh */
 void realise_engine_invalidate_frozen(realise_engine* e);
+/* zero_grad() without the memset: fresh != 0 tells the engine that the gradient arena holds nothing the caller wants kept - the
+ * next backward (or glyph backward) then zero-fills only what it accumulates into (one launch) and STORES the Linear weight
+ * gradients of the transformer layers (80 % of the arena) instead of adding to them.  The flag clears itself at that backward;
+ * without it gradients are accumulated into the arena as autograd does (run.py:200 under gradient_accumulation_steps). */
+void realise_engine_set_grads_fresh(realise_engine* e, int fresh);
 /* Token-id range errors.  nn.Embedding raises IndexError for an id outside its table (modeling_bert.py:183-186 word ids,
  * models.py:818 pinyin ids, :831 glyph lookup).  The engine never indexes with a caller's id: every forward first copies src_idx /
  * pho_idx into its workspace with out-of-range ids replaced by 0 and sets *flag = 1 (sticky; device memory or host-mapped pinned

@@ -129,6 +129,7 @@ SYMBOLS = {
     "realise_engine_refresh_shadows": (_I, [_P, _P]),
     "realise_engine_invalidate_frozen": (None, [_P]),
     "realise_engine_set_id_flag": (None, [_P, _P]),
+    "realise_engine_set_grads_fresh": (None, [_P, _I]),
     "realise_engine_forward": (_I, [_P, _P, C.POINTER(Batch)]),
     "realise_engine_backward": (_I, [_P, _P, _I, _I]),
     "realise_engine_backward_signalled": (_I, [_P, _P, C.POINTER(C.c_void_p), _I]),

@@ -370,6 +370,7 @@ int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_
 }
 int realise_engine_refresh_shadows(realise_engine* e, void* stream) { return e ? e->impl->refresh_shadows((hipStream_t)stream) : RL_ERR_ARG; }
 void realise_engine_invalidate_frozen(realise_engine* e) { if (e) e->impl->invalidate_frozen(); }
+void realise_engine_set_grads_fresh(realise_engine* e, int fresh) { if (e) e->impl->set_grads_fresh(fresh); }
 void realise_engine_set_id_flag(realise_engine* e, int32_t* flag) { if (e) e->impl->set_id_flag((int*)flag); }
 int realise_engine_forward(realise_engine* e, void* stream, const realise_batch* batch) {
   return (e && batch) ? e->impl->forward((hipStream_t)stream, *batch) : RL_ERR_ARG;

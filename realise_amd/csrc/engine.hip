@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -79,7 +80,8 @@ template <typename T> struct Engine : EngineBase {
   int64_t sh_cls_w = 0, sh_cls_wT = 0, sh_gru_hh = 0, sh_gru_hhT = 0, sh_glyph = 0;
   int64_t shadow_total = 0;
   bool glyph_built = false, descs_built = false;
-  int64_t sh_descs = 0;
+  int64_t sh_descs = 0, sh_fill = 0;
+  static constexpr int FILL_MAX = 2048;
   int n_descs = 0, desc_tiles = 0;
   std::vector<CastDesc> desc_host;
 
@@ -221,6 +223,7 @@ template <typename T> struct Engine : EngineBase {
       sh_glyph = b.take((int64_t)V * gs * gs * 8 * e);
     }
     sh_descs = b.take(256 * (int64_t)sizeof(CastDesc));      // device table for the one-launch refresh of the Linear weights
+    sh_fill = b.take(FILL_MAX * (int64_t)sizeof(FillChunk));  // chunk table of the fresh-gradient zero fill
     shadow_total = b.off;
   }
 
@@ -611,7 +614,7 @@ template <typename T> struct Engine : EngineBase {
           if (hipEventRecord(ev_ready[p][3], st) != hipSuccess || hipStreamWaitEvent(side, ev_ready[p][3], 0) != hipSuccess) return RL_ERR_LAUNCH;
           ws_ = side;
         }
-        RL_TRY(gemm_tn_group<T>(ws_, 4, gp4, Tk));
+        RL_TRY(gemm_tn_group<T>(ws_, 4, gp4, Tk, 1.0f, pass_overwrite ? 1 : 0));
       }
       {  // d x_in = d s1 + d qkv . W_qkv
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H; ep.accumulate = 1;
@@ -954,11 +957,54 @@ template <typename T> struct Engine : EngineBase {
   // accumulates the gradients of the 15 conv / BatchNorm parameter tensors for d_res [B*S, 768] (per token)
   int glyph_backward(hipStream_t st, const void* d_res) override {
     if (!have_glyph_fwd || !d_res) { fprintf(stderr, "[realise_hip] glyph_backward without a training glyph_forward\n"); return RL_ERR_ARG; }
+    RL_TRY(begin_gradient_pass(st, true));
     const int Tk = pl.B * pl.S;
     RL_TRY(segment_sum<T>(st, (const T*)d_res, wp<int>(pl.gu_inv), Tk, H, wp<float>(pl.seg_acc), wp<T>(pl.r_dout), wp<int>(pl.gu_bounds)));
     RL_TRY(resnet_backward(st, wp<T>(pl.r_dout)));
     return RL_OK;
   }
+
+  // ---------------------------------------------------------------- fresh gradients (zero_grad() without a 680 MB memset)
+  // After zero_grad() the module only tells the engine that the gradient arena holds nothing (set_grads_fresh).  The next
+  // backward then (a) zero-fills, in ONE launch, everything EXCEPT the Linear weight gradients of the transformer layers - 80 % of
+  // the arena -, and (b) lets the grouped weight-gradient GEMM store those instead of adding to them: no fill of those bytes and no
+  // read-modify-write in its epilogue.  Accumulating backwards (no zero_grad() in between) run exactly as before.
+  bool grads_fresh = false, pass_overwrite = false, fill_built = false;
+  int n_fill = 0;
+  void set_grads_fresh(int fresh) override { grads_fresh = fresh != 0; }
+  int begin_gradient_pass(hipStream_t st, bool glyph_only) {
+    pass_overwrite = false;
+    if (!grads_fresh) return RL_OK;
+    grads_fresh = false;
+    const int64_t total = L.arena_elems[AR_TRAIN];
+    if (glyph_only || !g_wgrad_group || !sh) return fill_f32(st, G, 0.0f, total);
+    if (!fill_built) {
+      std::vector<std::pair<int64_t, int64_t>> skip;          // [begin, end) of the tensors the grouped launches overwrite
+      auto add_stack = [&](const StackOff& so) {
+        for (const LayerOff& o : so.layers) {
+          skip.push_back({o.qkv_w, o.qkv_w + 3LL * H * H}); skip.push_back({o.ao_w, o.ao_w + (int64_t)H * H});
+          skip.push_back({o.in_w, o.in_w + (int64_t)I * H}); skip.push_back({o.out_w, o.out_w + (int64_t)H * I});
+        }
+      };
+      add_stack(L.bert);
+      if (cfg.model_type == 1) { add_stack(L.pho); add_stack(L.outb); }
+      std::sort(skip.begin(), skip.end());
+      fill_host.clear();
+      int64_t at = 0;
+      auto emit = [&](int64_t b, int64_t e) {
+        for (int64_t o = b; o < e; o += (1 << 20)) fill_host.push_back(FillChunk{o, (int32_t)std::min<int64_t>(1 << 20, e - o), 0});
+      };
+      for (auto& r : skip) { if (r.first > at) emit(at, r.first); at = std::max(at, r.second); }
+      if (at < total) emit(at, total);
+      if ((int)fill_host.size() > FILL_MAX) return fill_f32(st, G, 0.0f, total);
+      if (hipMemcpyAsync(sh + sh_fill, fill_host.data(), fill_host.size() * sizeof(FillChunk), hipMemcpyHostToDevice, st) != hipSuccess) return RL_ERR_LAUNCH;
+      n_fill = (int)fill_host.size(); fill_built = true;
+    }
+    RL_TRY(zero_chunks(st, G, (const FillChunk*)(sh + sh_fill), n_fill));
+    pass_overwrite = true;
+    return RL_OK;
+  }
+  std::vector<FillChunk> fill_host;
 
   // ---------------------------------------------------------------- backward, in bucket-sized stages
   int n_stages() const { return (int)L.buckets.size(); }
@@ -1063,6 +1109,7 @@ template <typename T> struct Engine : EngineBase {
     const int n = n_stages();
     if (n_events != n || evs == nullptr) return RL_ERR_ARG;
     for (int i = 0; i < n; ++i) if (evs[i] == nullptr) return RL_ERR_ARG;
+    RL_TRY(begin_gradient_pass(st, false));
     cs = 0;
     if (cfg.model_type == 1 && g_branch_overlap && branches_ok()) {
       branch_mode = true;
@@ -1096,6 +1143,7 @@ template <typename T> struct Engine : EngineBase {
     const int n = n_stages();
     if (last_stage < 0) last_stage = n - 1;
     if (first < 0 || last_stage >= n || first > last_stage) return RL_ERR_ARG;
+    if (first == 0) RL_TRY(begin_gradient_pass(st, false));           // (a bucket-by-bucket caller starts its pass with stage 0)
     cs = 0;
     // whole pass in one call (no per-bucket gradient exchange in between): the three branches behind the gate run concurrently
     if (cfg.model_type == 1 && first == 0 && last_stage == n - 1 && g_branch_overlap && branches_ok()) {

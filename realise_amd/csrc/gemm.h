@@ -266,6 +266,8 @@ struct TnEpi {
   // optional fused column sums of the A operand: colsum[i] += alpha * sum_p A[p,i]  (the bias gradient that goes
   // with a Linear weight gradient), computed by one extra ones-vector MFMA per A fragment in the j-tile-0 workgroups
   float* colsum = nullptr;
+  int overwrite = 0;        // TN_OUT_DIRECT only: out = result instead of out += result (the caller knows `out` holds nothing yet:
+                            // no read of the old value, no zero-fill before the pass)
   int probe = 0;            // diagnostics (tools/nt_probe.cpp): 2 no fetches, 3 no MFMA, 4 no fold pass
 };
 
@@ -281,11 +283,11 @@ template <typename T> struct TnGroupProblem {
 };
 template <typename T> struct TnGroup {
   TnGroupProblem<T> p[TN_GROUP_MAX];
-  int n = 0, total_tiles = 0, probe = 0;
+  int n = 0, total_tiles = 0, probe = 0, overwrite = 0;
   float alpha = 1.0f;
 };
 template <typename T>
-int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha = 1.0f);
+int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha = 1.0f, int overwrite = 0);
 
 // C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)
 template <typename T>

@@ -737,7 +737,7 @@ gemm_tn_group_kernel(TnGroup<T> grp, int P, int pchunk) {
   const TnGroupProblem<T>& pr = grp.p[k];
   DenseLoader<T> lb{pr.B, pr.ldb, P, pr.J};
   TnEpi ep;
-  ep.out = pr.out; ep.ldo = pr.ldo; ep.colsum = pr.colsum; ep.alpha = grp.alpha; ep.probe = grp.probe;
+  ep.out = pr.out; ep.ldo = pr.ldo; ep.colsum = pr.colsum; ep.alpha = grp.alpha; ep.probe = grp.probe; ep.overwrite = grp.overwrite;
   tn_tile_body<T, DenseLoader<T>, TR, 2, 2, NST, BPD>(pr.A, pr.lda, lb, P, pr.I, pr.J, pr.tiles_j, pr.ntiles, 1, pchunk, TN_OUT_DIRECT, ep,
                                                       logical - pr.tile_begin);
 }
@@ -904,11 +904,11 @@ static int g_tn_group_ring = 0;      // measured: 4 x 32-row stages 3.76 ms/step
 void set_tn_group_ring(int on) { g_tn_group_ring = on; }
 
 template <typename T>
-int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha) {
+int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha, int overwrite) {
   typedef TnGeo<T> G;
   if (n < 1 || n > TN_GROUP_MAX || P <= 0) return RL_ERR_ARG;
   TnGroup<T> grp;
-  grp.n = n; grp.alpha = alpha; grp.probe = g_tn_probe;
+  grp.n = n; grp.alpha = alpha; grp.probe = g_tn_probe; grp.overwrite = overwrite;
   int total = 0;
   double flops = 0.0;
   for (int k = 0; k < n; ++k) {
@@ -937,8 +937,8 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
 #undef RL_TN_GROUP
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
-template int gemm_tn_group<bf16_t>(hipStream_t, int, const TnGroupProblem<bf16_t>*, int, float);
-template int gemm_tn_group<float>(hipStream_t, int, const TnGroupProblem<float>*, int, float);
+template int gemm_tn_group<bf16_t>(hipStream_t, int, const TnGroupProblem<bf16_t>*, int, float, int);
+template int gemm_tn_group<float>(hipStream_t, int, const TnGroupProblem<float>*, int, float, int);
 
 template <typename T>
 int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep,

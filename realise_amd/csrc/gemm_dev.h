@@ -165,14 +165,14 @@ __device__ __forceinline__ void tn_epilogue4(const TnEpi& ep, int how, int split
   v *= ep.alpha;
   if (how == TN_OUT_DIRECT && ep.mode == TN_PLAIN && (ep.ldo & 3) == 0) {
     floatx4* o = (floatx4*)(ep.out + (int64_t)i * ep.ldo + j);
-    *o = *o + v;
+    if (ep.overwrite) *o = v; else *o = *o + v;
     return;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t idx = tn_out_index(ep, i, j + r);
     if (idx < 0) continue;
-    if (how == TN_OUT_DIRECT) ep.out[idx] += v[r];
+    if (how == TN_OUT_DIRECT) { if (ep.overwrite) ep.out[idx] = v[r]; else ep.out[idx] += v[r]; }
     else atomicAdd(ep.out + idx, v[r]);
   }
 }

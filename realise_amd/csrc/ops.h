@@ -212,6 +212,8 @@ int adamw_grouped(hipStream_t st, float* p, const float* g, float* m, float* v, 
                   const AdamwGroups& gs, const float* norm_sq, float max_norm);
 int clip_scale(hipStream_t st, float* g, int64_t n, const float* norm_sq, float max_norm);
 int fill_f32(hipStream_t st, float* p, float v, int64_t n);
+struct FillChunk { int64_t off; int32_t len, pad; };     // off: 4-element aligned
+int zero_chunks(hipStream_t st, float* base, const FillChunk* chunks_dev, int n);
 int add_i64(hipStream_t st, int64_t* p, int64_t v, int n);
 
 }  // namespace rl

@@ -605,6 +605,20 @@ int clip_scale(hipStream_t st, float* g, int64_t n, const float* norm_sq, float 
   return RL_LAUNCH_CHECK();
 }
 
+// zero several ranges of one arena in ONE launch: block b clears chunk b = [off[b], off[b] + len[b]) (chunks <= 1 Mi floats)
+__global__ void __launch_bounds__(256) zero_chunks_kernel(float* __restrict__ base, const FillChunk* __restrict__ chunks) {
+  const FillChunk c = chunks[blockIdx.x];
+  float* p = base + c.off;
+  const int n4 = c.len >> 2;
+  for (int i = threadIdx.x; i < n4; i += 256) ((floatx4*)p)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int i = (n4 << 2) + threadIdx.x; i < c.len; i += 256) p[i] = 0.f;
+}
+int zero_chunks(hipStream_t st, float* base, const FillChunk* chunks_dev, int n) {
+  if (n <= 0) return RL_OK;
+  hipLaunchKernelGGL(zero_chunks_kernel, dim3(n), dim3(256), 0, st, base, chunks_dev);
+  return RL_LAUNCH_CHECK();
+}
+
 __global__ void fill_kernel(float* p, float v, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }

@@ -292,14 +292,37 @@ class RealiseModule(nn.Module):
         return batch
 
     def zero_grad(self, set_to_none=False):
+        """run.py:211.  On the GPU nothing is zeroed here: the gradients are detached (``p.grad = None``, torch's own default since
+        2.0) and the engine is told that the arena holds nothing to keep - its next backward zero-fills only what it accumulates
+        into and stores the big Linear weight gradients instead of adding to them (no 680 MB memset, no read-modify-write).
+        ``flat_gradients()`` / ``bucket_views()`` / ``clip_grad_norm_()`` materialise the zeros if someone asks before that."""
+        if self._engine is not None and self._grads.is_cuda and self.lazy_zero_grad:
+            self._zero_pending = True
+            for p in self._grad_params():
+                p.grad = None
+            return
         self._grads.zero_()
+        self._zero_pending = False
         if set_to_none:
             for p in self.parameters():
                 p.grad = None
 
+    lazy_zero_grad = True
+
+    def _grad_params(self):
+        if getattr(self, "_grad_param_list", None) is None:
+            self._grad_param_list = [param for name, (arena, off, shape, param) in self._views.items() if arena == _AR_TRAIN and param is not None]
+        return self._grad_param_list
+
+    def _materialize_zero(self):
+        if getattr(self, "_zero_pending", False):
+            self._grads.zero_()
+            self._zero_pending = False
+
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ over the flat gradient arena (run.py:207): two kernels."""
         lib = _capi.load()
+        self._materialize_zero()
         st = self._stream()
         nsq = torch.zeros(1, dtype=torch.float32, device=self.device)
         _capi.check(lib.realise_sumsq(st, self._grads.data_ptr(), self._grads.numel(), nsq.data_ptr()), "realise_sumsq")
@@ -480,9 +503,7 @@ class RealiseModule(nn.Module):
         if getattr(self, "_glyph_fwd_gen", None) != self._fwd_gen:
             raise RuntimeError("glyph_backward needs the activations of a training glyph_forward; another forward ran since (or none did)")
         d = d_res.to(device=self.device, dtype=_DTYPES[self.compute_dtype][1]).contiguous()
-        sentinel = self._views["classifier.bias"][3]
-        if sentinel.grad is None:
-            self._grads.zero_()
+        self._begin_gradient_pass()
         self._glyph_fwd_gen = None
         _capi.check(_capi.load().realise_engine_glyph_backward(self._engine, self._stream(), d.data_ptr()), "realise_engine_glyph_backward")
         self._attach_grads()
@@ -532,17 +553,30 @@ class RealiseModule(nn.Module):
         return ids
 
     def _attach_grads(self):
-        for name, (arena, off, shape, param) in self._views.items():
-            if arena == _AR_TRAIN and param is not None and param.grad is None:
-                n = int(np.prod(shape))
-                param.grad = self._grads[off:off + n].view(shape)
+        views = getattr(self, "_grad_views", None)
+        if views is None or views[0] is not self._grads:
+            # the gradient views are built once per arena and re-attached by assignment (zero_grad() detaches them every step)
+            vs = []
+            for name, (arena, off, shape, param) in self._views.items():
+                if arena == _AR_TRAIN and param is not None:
+                    vs.append((param, self._grads[off:off + int(np.prod(shape))].view(shape)))
+            views = self._grad_views = (self._grads, vs)
+        for param, g in views[1]:
+            if param.grad is None:
+                param.grad = g
+
+    def _begin_gradient_pass(self):
+        """detached gradients (our zero_grad(), or an optimizer's zero_grad(set_to_none=True)) mean "start from zero": the engine
+        does that itself - a one-launch partial fill + overwriting weight-gradient GEMMs (realise_engine_set_grads_fresh)"""
+        sentinel = self._views["classifier.bias"][3]
+        if sentinel.grad is None or getattr(self, "_zero_pending", False):
+            _capi.load().realise_engine_set_grads_fresh(self._engine, 1)
+            self._zero_pending = False
 
     def _run_backward(self, grad_out):
         lib = _capi.load()
         self._raise_on_bad_ids()
-        sentinel = self._views["classifier.bias"][3]
-        if sentinel.grad is None:          # grads were set to None by an optimizer: start from zero
-            self._grads.zero_()
+        self._begin_gradient_pass()
         if not self.assume_unit_loss_grad:
             d = self.tap_dlogits()
             d.mul_(grad_out.to(d.dtype))
@@ -591,12 +625,14 @@ class RealiseModule(nn.Module):
 
     def bucket_views(self):
         """gradient buckets (flat slices of the gradient arena) in backward completion order"""
+        self._materialize_zero()
         return [self._grads[b0:b1] for b0, b1 in self._buckets]
 
     def flat_parameters(self):
         return self._arenas[0][:self._sizes[0]]
 
     def flat_gradients(self):
+        self._materialize_zero()
         return self._grads[:self._sizes[0]]
 
     def flat_bn_buffers(self):
