@@ -364,7 +364,7 @@ template <typename T> struct Engine : EngineBase {
     p.wC1[1] = b.take(Tw * H * e); p.wC2[1] = b.take(Tw * H * e); p.wD[1] = b.take(Tw * I * e); p.wF[1] = b.take(Tw * 3 * H * e);
     p.tn_slab2 = b.take(TN_SLAB_ELEMS * 4);
     p.tn_slab = b.take(TN_SLAB_ELEMS * 4);
-    p.ln_slots = b.take(LN_SLOT_BYTES);
+    p.ln_slots = b.take((int64_t)(LN_FOLD_MAX + 1) * LN_SLOT_BYTES);     // LN_FOLD_MAX deferred sites + one immediate region
     tap("d_x0", p.gB, Tk * H);
     {
       typename Plan::Scratch& s0 = p.sc[0];
@@ -375,12 +375,12 @@ template <typename T> struct Engine : EngineBase {
         if (!glyph_only) {          // pho branch: a full private set (its layers run next to the bert layers)
           typename Plan::Scratch& s1 = p.sc[1];
           s1.gB = b.take(Tk * H * e); s1.gE = b.take(Tk * H * e); s1.rowdot = b.take((int64_t)B * nh * S * 4);
-          s1.tn_slab = b.take(TN_SLAB_ELEMS * 4); s1.tn_slab2 = s1.tn_slab; s1.ln_slots = b.take(LN_SLOT_BYTES);
+          s1.tn_slab = b.take(TN_SLAB_ELEMS * 4); s1.tn_slab2 = s1.tn_slab; s1.ln_slots = b.take((int64_t)(LN_FOLD_MAX + 1) * LN_SLOT_BYTES);
           s1.wC1[0] = b.take(Tk * H * e); s1.wC2[0] = b.take(Tk * H * e); s1.wD[0] = b.take(Tk * I * e); s1.wF[0] = b.take(Tk * 3 * H * e);
           s1.wC1[1] = s1.wC1[0]; s1.wC2[1] = s1.wC2[0]; s1.wD[1] = s1.wD[0]; s1.wF[1] = s1.wF[0];
         }
         typename Plan::Scratch& s2 = p.sc[2];   // glyph branch: LayerNorm-backward output, slabs of the conv weight gradients
-        s2.gE = b.take(Tk * H * e); s2.tn_slab = b.take(TN_SLAB_ELEMS * 4); s2.ln_slots = b.take(LN_SLOT_BYTES);
+        s2.gE = b.take(Tk * H * e); s2.tn_slab = b.take(TN_SLAB_ELEMS * 4); s2.ln_slots = b.take((int64_t)(LN_FOLD_MAX + 1) * LN_SLOT_BYTES);
       }
     }
     if (cfg.model_type == 1) {
@@ -532,6 +532,32 @@ template <typename T> struct Engine : EngineBase {
     return RL_OK;
   }
 
+  // LayerNorm gamma / beta gradients: every ln_bwd leaves one record per workgroup; the records of up to LN_FOLD_MAX sites (the two
+  // LayerNorms of four transformer layers) are folded by ONE launch at the end of the layer group instead of one fold per site
+  // (38 launches of ~7 us on the critical chain per step).  Per scratch set (= per branch stream).
+  LnFoldSites pend[3];
+  float* ln_region(int k) const { return wp<float>(pl.sc[cs].ln_slots) + (int64_t)k * LN_SLOT_FLOATS; }
+  int flush_ln_folds(hipStream_t st) {
+    LnFoldSites& f = pend[cs];
+    if (f.n == 0) return RL_OK;
+    f.H = H;
+    const int rc = ln_fold_multi(st, f);
+    f.n = 0;
+    return rc;
+  }
+  int ln_bwd_deferred(hipStream_t st, LnBwdArgs<T>& ln) {
+    LnFoldSites& f = pend[cs];
+    int nrec = 0;
+    ln.slots = ln_region(f.n);
+    ln.deferred_records = &nrec;
+    RL_TRY(ln_bwd<T>(st, ln));
+    if (nrec > 0) {
+      f.s[f.n++] = LnFoldSite{ln.slots, nrec, ln.dgamma, ln.dbeta};
+      if (f.n == LN_FOLD_MAX) RL_TRY(flush_ln_folds(st));
+    }
+    return RL_OK;
+  }
+
   // backward of layers [hi .. lo] of a stack; gA holds d(output of layer hi) on entry and d(input of layer lo) on exit
   int layers_backward(hipStream_t st, int sid, const StackOff& so, const std::vector<LayerSh>& shs, StackAct& a, int hi, int lo,
                       T* gA) {
@@ -574,10 +600,10 @@ template <typename T> struct Engine : EngineBase {
       };
       const bool keep_dy = ov || grouped;      // the dense-output gradients must outlive the in-place updates of gA / gB
       {  // output LayerNorm: gA = d y2 -> gB = d s2 (residual part of d y1), gC1 = d(dense out) = d s2 * dropmask
-        LnBwdArgs<T> ln; ln.slots = wp<float>(sc.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
+        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
         ln.gamma = pp(o.out_ln_g); ln.dx = gB; ln.dx_drop = (d3.thresh || keep_dy) ? gC1 : nullptr; ln.out_drop = d3;
         ln.dgamma = gp(o.out_ln_g); ln.dbeta = gp(o.out_ln_b);
-        RL_TRY(ln_bwd<T>(st, ln));
+        RL_TRY(ln_bwd_deferred(st, ln));
       }
       const T* dso = (d3.thresh || keep_dy) ? gC1 : gB;
       RL_TRY(wgrad(0, dso, H, wp<T>(t.post), I, H, I, gp(o.out_b), gp(o.out_w)));
@@ -591,10 +617,10 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(gemm_nt<T>(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
       }
       {  // attention-output LayerNorm: gB = d y1 -> gA = d s1, gC2 = d(dense out)
-        LnBwdArgs<T> ln; ln.slots = wp<float>(sc.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
+        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
         ln.gamma = pp(o.ao_ln_g); ln.dx = gA; ln.dx_drop = (d2.thresh || keep_dy) ? gC2 : nullptr; ln.out_drop = d2;
         ln.dgamma = gp(o.ao_ln_g); ln.dbeta = gp(o.ao_ln_b);
-        RL_TRY(ln_bwd<T>(st, ln));
+        RL_TRY(ln_bwd_deferred(st, ln));
       }
       const T* dsa = (d2.thresh || keep_dy) ? gC2 : gA;
       RL_TRY(wgrad(2, dsa, H, wp<T>(t.ctx), H, H, H, gp(o.ao_b), gp(o.ao_w)));
@@ -625,13 +651,13 @@ template <typename T> struct Engine : EngineBase {
         done_pending[p] = true;
       }
     }
-    return RL_OK;
+    return flush_ln_folds(st);
   }
 
   // embeddings backward: gA = d(embedding output) -> dx (T*, d of the pre-LayerNorm sum) ; scatters table grads
   int emb_backward(hipStream_t st, int sid, const StackOff& so, StackAct& a, const int64_t* ids, int pos_zero, const T* gA, T* dx) {
     const int B = pl.B, S = pl.S, Tk = B * S;
-    LnBwdArgs<T> ln; ln.slots = wp<float>(pl.sc[cs].ln_slots); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.in_drop = site(sid * 1000 + 900, cfg.hidden_dropout);
+    LnBwdArgs<T> ln; ln.slots = ln_region(LN_FOLD_MAX); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.in_drop = site(sid * 1000 + 900, cfg.hidden_dropout);
     ln.xhat = wp<T>(a.emb_xhat); ln.rstd = wp<float>(a.emb_rstd); ln.gamma = pp(so.ln_g); ln.dx = dx;
     ln.dgamma = gp(so.ln_g); ln.dbeta = gp(so.ln_b);
     RL_TRY(ln_bwd<T>(st, ln));
@@ -1063,7 +1089,7 @@ template <typename T> struct Engine : EngineBase {
   int stage_glyph(hipStream_t st) {          // resnet LayerNorm, segment sum over the tokens of a glyph, glyph ResNet
     const int Tk = pl.B * pl.S;
     const typename Plan::Scratch& sc = pl.sc[cs];
-    LnBwdArgs<T> ln; ln.slots = wp<float>(sc.ln_slots); ln.rows = Tk; ln.H = H; ln.dy = wp<T>(pl.X3); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
+    LnBwdArgs<T> ln; ln.slots = ln_region(LN_FOLD_MAX); ln.rows = Tk; ln.H = H; ln.dy = wp<T>(pl.X3); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
     ln.gamma = pp(L.res_ln_g); ln.dx = wp<T>(sc.gE); ln.dgamma = gp(L.res_ln_g); ln.dbeta = gp(L.res_ln_b);
     RL_TRY(ln_bwd<T>(st, ln));
     RL_TRY(segment_sum<T>(st, wp<T>(sc.gE), wp<int>(pl.gu_inv), Tk, H, wp<float>(pl.seg_acc), wp<T>(pl.r_dout), wp<int>(pl.gu_bounds)));

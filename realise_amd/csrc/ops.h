@@ -66,8 +66,15 @@ template <typename T> struct LnBwdArgs {
   float* dgamma = nullptr;         // accumulated
   float* dbeta = nullptr;
   float* slots = nullptr;          // optional scratch of LN_SLOT_BYTES: per-workgroup partial records, folded in a fixed order (no atomics)
+  int* deferred_records = nullptr; // non-null: do NOT launch the fold; *deferred_records = number of records written to `slots` (0: none, the
+                                   // gradients were accumulated directly) - the caller folds several sites in one launch (ln_fold_multi)
 };
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a);
+// dgamma / dbeta += fixed-order sum of the per-workgroup records of up to LN_FOLD_MAX LayerNorm sites, one launch
+constexpr int LN_FOLD_MAX = 8;
+struct LnFoldSite { const float* recs; int nrec; float* dgamma; float* dbeta; };
+struct LnFoldSites { int n = 0; int H = 0; LnFoldSite s[LN_FOLD_MAX]; };
+int ln_fold_multi(hipStream_t st, const LnFoldSites& sites);
 void set_ln_fast(int on);            // 1 (default): bf16 rows of 256 / 512 / 768 / 1024 columns take the half-wave-per-row kernels (16-byte accesses)
 void set_ln_bwd_blocks(int n);       // workgroups of the fast LayerNorm backward (default 512)
 

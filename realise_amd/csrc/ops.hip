@@ -414,6 +414,34 @@ __global__ void __launch_bounds__(256) ln_fold_kernel(const float* __restrict__ 
     *(floatx4*)o += red[q][0];
   }
 }
+__global__ void __launch_bounds__(256) ln_fold_multi_kernel(LnFoldSites f) {
+  __shared__ floatx4 red[4][64];
+  const LnFoldSite site = f.s[blockIdx.y];
+  const int H = f.H;
+  const int q = threadIdx.x >> 6, kl = threadIdx.x & 63;
+  const int i = (blockIdx.x * 4 + q) * 4;                  // column in [0, 2H)
+  floatx4 s = floatx4{0.f, 0.f, 0.f, 0.f};
+  if (i < 2 * H)
+    for (int k = kl; k < site.nrec; k += 64) s += *(const floatx4*)(site.recs + (int64_t)k * 2 * H + i);
+  red[q][kl] = s;
+  __syncthreads();
+#pragma unroll
+  for (int w = 32; w > 0; w >>= 1) {
+    if (kl < w) red[q][kl] += red[q][kl + w];
+    __syncthreads();
+  }
+  if (kl == 0 && i < 2 * H) {
+    float* o = i < H ? site.dgamma + i : site.dbeta + (i - H);
+    *(floatx4*)o += red[q][0];
+  }
+}
+int ln_fold_multi(hipStream_t st, const LnFoldSites& sites) {
+  if (sites.n <= 0) return RL_OK;
+  if (sites.n > LN_FOLD_MAX || (sites.H & 3)) return RL_ERR_ARG;
+  hipLaunchKernelGGL(ln_fold_multi_kernel, dim3((2 * sites.H / 4 + 3) / 4, sites.n), dim3(256), 0, st, sites);
+  return RL_LAUNCH_CHECK();
+}
+
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
   if (a.rows <= 0) return RL_OK;
   if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
@@ -431,7 +459,8 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
       const size_t lds = (size_t)5 * a.H * sizeof(float);
       if (a.out_drop.thresh != 0u) hipLaunchKernelGGL((ln_bwd16_kernel<true>), dim3(blocks), dim3(256), lds, st, b);
       else hipLaunchKernelGGL((ln_bwd16_kernel<false>), dim3(blocks), dim3(256), lds, st, b);
-      if (b.slots != nullptr) hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * a.H / 4 + 3) / 4), dim3(256), 0, st, b.slots, blocks, a.H, a.dgamma, a.dbeta);
+      if (a.deferred_records != nullptr) *a.deferred_records = b.slots != nullptr ? blocks : 0;
+      else if (b.slots != nullptr) hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * a.H / 4 + 3) / 4), dim3(256), 0, st, b.slots, blocks, a.H, a.dgamma, a.dbeta);
       return RL_LAUNCH_CHECK();
     }
   }
@@ -439,7 +468,8 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
   else if (nv == 2) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(blocks), dim3(256), 0, st, b);
   else if (nv == 3) hipLaunchKernelGGL((ln_bwd_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, b);
   else hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, b);
-  if (b.slots != nullptr) hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * a.H / 4 + 3) / 4), dim3(256), 0, st, b.slots, blocks, a.H, a.dgamma, a.dbeta);
+  if (a.deferred_records != nullptr) *a.deferred_records = b.slots != nullptr ? blocks : 0;
+  else if (b.slots != nullptr) hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * a.H / 4 + 3) / 4), dim3(256), 0, st, b.slots, blocks, a.H, a.dgamma, a.dbeta);
   return RL_LAUNCH_CHECK();
 }
 template int ln_bwd<bf16_t>(hipStream_t, const LnBwdArgs<bf16_t>&);
