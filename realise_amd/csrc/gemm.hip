@@ -431,7 +431,7 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
     // Wide outputs (qkv, FFN-up + GELU, FFN-down data gradient + GELU', the classifier: >= 1.5 tiles of 256 x 192 per CU): the persistent
     // kernel, whose register epilogue and next-tile prologue overlap what the one-tile kernels leave exposed (gemm_nt8p.hip).
     // Variant 50 forces it wherever it is supported, variant 51 keeps it off.
-    if (la.rows_dev == nullptr && g_nt_probe == 0 && (g_nt_variant == 50 || (g_nt_variant == 0 && M >= 1024 && (long)((M + 255) / 256) * ((N + 191) / 192) >= 384)) &&
+    if (la.rows_dev == nullptr && g_nt_probe == 0 && (g_nt_variant == 50 || ((g_nt_variant == 0 || (g_nt_variant == 53 && ep.mode != EPI_GELU_BWD)) && M >= 1024 && (long)((M + 255) / 256) * ((N + 191) / 192) >= 384)) &&
         nt8p_supported(M, N, K, ep, la.ld, ldb))
       return gemm_nt8p(st, la.base, la.ld, B, ldb, M, N, K, ep);
     if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 44) || g_nt_variant >= 50)) {

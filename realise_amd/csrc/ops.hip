@@ -827,20 +827,31 @@ template int ce_loss<float>(hipStream_t, const float*, int64_t, const int64_t*, 
 // ---------------------------------------------------------------------------------------------
 // Gate fusion (models.py:840-850).  The [T, 4H] concat is never materialised.
 // ---------------------------------------------------------------------------------------------
+// masked mean of the bert states of a sentence (models.py:842-843).  grid (H / 256, B), 256 threads = 64 column quads x 4 row lanes:
+// a thread walks S / 4 rows, the four lanes meet in LDS (one thread per column quad walking all S rows serially took 53 us for
+// 12.6 MB; this form ~10).  Row lane order and the final 4-way sum are fixed: deterministic.
 template <typename T>
-__global__ void gate_mean_kernel(GateArgs<T> a) {     // grid (H/4/64, B)
-  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+__global__ void __launch_bounds__(256) gate_mean_kernel(GateArgs<T> a) {
+  __shared__ floatx4 part[4][64];
+  __shared__ float mpart[4];
+  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + q) * 4;
   const int b = blockIdx.y;
-  if (c >= a.H) return;
   floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
   float ms = 0.f;
-  for (int s = 0; s < a.S; ++s) {
+  for (int s = rl; s < a.S; s += 4) {
     const float m = (float)a.masks[b * a.S + s];
     ms += m;
-    acc += load4<T>(a.bert + ((int64_t)b * a.S + s) * a.H + c) * m;
+    if (c < a.H) acc += load4<T>(a.bert + ((int64_t)b * a.S + s) * a.H + c) * m;
   }
-  *(floatx4*)(a.mean + (int64_t)b * a.H + c) = acc / ms;
-  if (c == 0) a.msum[b] = ms;
+  part[rl][q] = acc;
+  if (q == 0) mpart[rl] = ms;
+  __syncthreads();
+  if (rl == 0) {
+    const float msum = (mpart[0] + mpart[1]) + (mpart[2] + mpart[3]);
+    if (c < a.H) *(floatx4*)(a.mean + (int64_t)b * a.H + c) = ((part[0][q] + part[1][q]) + (part[2][q] + part[3][q])) / msum;
+    if (c == 0) a.msum[b] = msum;
+  }
 }
 
 template <typename T>
@@ -881,7 +892,7 @@ __global__ void __launch_bounds__(256) gate_fwd_kernel(GateArgs<T> a) {   // one
 }
 template <typename T> int gate_fwd(hipStream_t st, const GateArgs<T>& a) {
   if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
-  hipLaunchKernelGGL((gate_mean_kernel<T>), dim3((a.H / 4 + 63) / 64, a.B), dim3(64), 0, st, a);
+  hipLaunchKernelGGL((gate_mean_kernel<T>), dim3((a.H / 4 + 63) / 64, a.B), dim3(256), 0, st, a);
   hipLaunchKernelGGL((gate_fwd_kernel<T>), dim3((a.B * a.S + 3) / 4), dim3(256), 0, st, a);
   return RL_LAUNCH_CHECK();
 }
@@ -933,56 +944,100 @@ __global__ void __launch_bounds__(256) gate_bwd_token_kernel(GateArgs<T> a) {
     }
   }
 }
-// step 2 (per sentence, 4 columns per thread): d(mean) -> spread over the masked tokens of dbert,
-// and dW[:, 3H:4H] += sum_s dz * mean
+// step 2 (per sentence): d(mean) -> spread over the masked tokens of dbert, and dW[:, 3H:4H] += sum_s dz * mean.
+// grid (H / 256, B), 256 threads = 64 column quads x 4 row lanes (the row walk over S is split four ways).
 template <typename T>
-__global__ void gate_bwd_mean_kernel(GateArgs<T> a) {    // grid (H/4/64, B)
-  const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+__global__ void __launch_bounds__(256) gate_bwd_mean_kernel(GateArgs<T> a) {
+  __shared__ float zpart[4][4];
+  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + q) * 4;
   const int b = blockIdx.y;
-  if (c >= a.H) return;
   const int H = a.H;
-  float zs[3] = {0.f, 0.f, 0.f};
-  for (int s = 0; s < a.S; ++s)
+  if (q < 3) {                                   // lane q of row lane rl: partial sum of dz_q over its rows
+    float z = 0.f;
+    for (int s = rl; s < a.S; s += 4) z += a.dz[((int64_t)b * a.S + s) * 4 + q];
+    zpart[rl][q] = z;
+  }
+  __syncthreads();
+  float zs[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) zs[k] += a.dz[((int64_t)b * a.S + s) * 4 + k];
+  for (int k = 0; k < 3; ++k) zs[k] = (zpart[0][k] + zpart[1][k]) + (zpart[2][k] + zpart[3][k]);
+  if (c >= H) return;
   floatx4 dm = floatx4{0.f, 0.f, 0.f, 0.f};
-  const floatx4 mean = *(const floatx4*)(a.mean + (int64_t)b * H + c);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    dm += *(const floatx4*)(a.W + (int64_t)k * 4 * H + 3 * H + c) * zs[k];
+  for (int k = 0; k < 3; ++k) dm += *(const floatx4*)(a.W + (int64_t)k * 4 * H + 3 * H + c) * zs[k];
+  if (rl == 0) {
+    const floatx4 mean = *(const floatx4*)(a.mean + (int64_t)b * H + c);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(a.dW + (int64_t)k * 4 * H + 3 * H + c + j, zs[k] * mean[j]);
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(a.dW + (int64_t)k * 4 * H + 3 * H + c + j, zs[k] * mean[j]);
+    if (c == 0)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) atomicAdd(a.dbias + k, zs[k]);
   }
   dm = dm / a.msum[b];
-  for (int s = 0; s < a.S; ++s) {
-    if (a.masks[b * a.S + s] != 0) {
+  for (int s = rl; s < a.S; s += 4) {
+    const int64_t m = a.masks[b * a.S + s];
+    if (m != 0) {
       T* p = a.dbert + ((int64_t)b * a.S + s) * H + c;
-      store4<T>(p, load4<T>(p) + dm * (float)a.masks[b * a.S + s]);
+      store4<T>(p, load4<T>(p) + dm * (float)m);
     }
   }
-  if (c == 0 && blockIdx.x == 0)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) atomicAdd(a.dbias + k, zs[k]);
 }
-// step 3: dW[k, 0:3H] += sum_t dz_k[t] * X(t, :)
-template <typename T> struct GateWF {
-  const T* x; const float* dz; int64_t ld; int k;
-  __device__ __forceinline__ void operator()(int r, int c, floatx4& a0, floatx4&) const {
-    a0 += load4<T>(x + (int64_t)r * ld + c) * dz[(int64_t)r * 4 + k];
+// step 3: dW[k, src H + c] += sum_t dz_k[t] * X_src(t, c) for the three sources and the three gates in ONE pass over bert / pho / res
+// (was nine column reductions, each re-reading one source: 190 us of launches at the join of the three branches).
+// grid (H / 128, row chunks), 256 threads = 32 column quads x 8 row lanes; nine float4 accumulators per thread; atomics at the end.
+template <typename T>
+__global__ void __launch_bounds__(256) gate_dw_kernel(GateArgs<T> a, int rows_per_block) {
+  __shared__ floatx4 red[8][32];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = (blockIdx.x * 32 + cx) * 4;
+  const int H = a.H, T_ = a.B * a.S;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(T_, r0 + rows_per_block);
+  floatx4 acc[3][3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[s][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+  if (c < H) {
+    for (int r = r0 + ry; r < r1; r += 8) {
+      const floatx4 dz = *(const floatx4*)(a.dz + (int64_t)r * 4);
+      const floatx4 x[3] = {load4<T>(a.bert + (int64_t)r * H + c), load4<T>(a.pho + (int64_t)r * H + c), load4<T>(a.res + (int64_t)r * H + c)};
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[s][k] += x[s] * dz[k];
+    }
   }
-};
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      __syncthreads();
+      red[ry][cx] = acc[s][k];
+      __syncthreads();
+      if (ry == 0 && c < H) {
+        floatx4 v = red[0][cx];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) v += red[j][cx];
+        float* o = a.dW + (int64_t)k * 4 * H + (int64_t)s * H + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(o + j, v[j]);
+      }
+    }
+}
 template <typename T> int gate_bwd(hipStream_t st, const GateArgs<T>& a) {
   if ((a.H & 3) || a.H > LN_MAXV * 256) return RL_ERR_ARG;
   const int T_ = a.B * a.S;
   hipLaunchKernelGGL((gate_bwd_token_kernel<T>), dim3((T_ + 3) / 4), dim3(256), 0, st, a);
-  hipLaunchKernelGGL((gate_bwd_mean_kernel<T>), dim3((a.H / 4 + 63) / 64, a.B), dim3(64), 0, st, a);
-  const T* xs[3] = {a.bert, a.pho, a.res};
-  for (int src = 0; src < 3; ++src)
-    for (int k = 0; k < 3; ++k) {
-      GateWF<T> f{xs[src], a.dz, (int64_t)a.H, k};
-      const int rc = launch_col_reduce(st, f, T_, a.H, a.dW + (int64_t)k * 4 * a.H + (int64_t)src * a.H, nullptr);
-      if (rc != RL_OK) return rc;
-    }
+  hipLaunchKernelGGL((gate_bwd_mean_kernel<T>), dim3((a.H / 4 + 63) / 64, a.B), dim3(256), 0, st, a);
+  const int gx = (a.H + 127) / 128;
+  int gy = 1024 / gx;
+  if (gy > (T_ + 31) / 32) gy = (T_ + 31) / 32;
+  if (gy < 1) gy = 1;
+  const int rows_per_block = (T_ + gy - 1) / gy;
+  hipLaunchKernelGGL((gate_dw_kernel<T>), dim3(gx, gy), dim3(256), 0, st, a, rows_per_block);
   return RL_LAUNCH_CHECK();
 }
 template int gate_bwd<bf16_t>(hipStream_t, const GateArgs<bf16_t>&);
