@@ -20,16 +20,32 @@ void realise_set_nt_allow_n96(int on);
 void realise_set_nt_probe(int mode);
 /* Diagnostics: force an experimental NT tile shape for dense bf16 GEMMs (0 = production heuristic). */
 void realise_set_nt_variant(int v);
-/* step engine: key 0 = enqueue order of the three forward branches (0: bert stack first, 1: the shorter pinyin / glyph branches first) */
+/* step engine: key 0 = enqueue order of the three forward branches (0: bert stack first, 1: the shorter pinyin / glyph branches first);
+ * keys 1 / 2 / 3 = priority class of the pinyin-branch / glyph-branch / weight-gradient stream (-1 highest, 0 device default, +1 lowest),
+ * read when the engine creates the stream, i.e. to be set before the first forward */
 void realise_set_engine(int key, int value);
 /* LayerNorm backward exactly as the engine calls it (bf16): optional second output dx_drop = dx * dropout mask, per-workgroup
  * [dgamma | dbeta] records in `slots` (8 MiB scratch) folded in a fixed order.  tools/ln_probe.py times it. */
 int realise_layernorm_bwd_ex(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,
                              uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* dgamma, float* dbeta, float* slots, int rows, int H);
-/* LayerNorm kernels: key 0 = bf16 fast path (half a wave per row, 16-byte accesses; default 1), key 1 = workgroups of its backward (default 512) */
+/* LayerNorm kernels: key 0 = bf16 fast path (half a wave per row, 16-byte accesses; default 1), key 1 = workgroups of its backward (default 512);
+ * BatchNorm kernels: key 2 = bf16 fast paths (16-byte accesses, paired bn2 + shortcut backward; default 1), key 3 = row chunks of their
+ * column reductions (default 1024) */
 void realise_set_ln(int key, int value);
+/* BatchNorm statistics and backward exactly as the engine's glyph branch runs them (bf16, NHWC viewed as [P, C]; char_cnn.py:15-32):
+ * per-row-chunk partial records in `slots` (1 MiB scratch) folded in a fixed order; `counts` (nullable) = multiplicity of each image of
+ * `hw` pixels (glyph dedup), n_stat = the true sample count of the statistics (0: P).  stats: mean[C] and sq[C] = sum w (x - mean)^2.
+ * bwd: dx = gamma rstd (g - w sum(g) / n - xhat w sum(g xhat) / n) with g = dy masked by relu_src > 0; dgamma / dbeta are ADDED to;
+ * xb != NULL: a second normalisation sharing dy and the mask (bn2 + shortcut BN of a BasicBlock; one pass reads dy and the mask for
+ * both); sums: 4C floats of scratch.  tools/bn_probe.py times them; tests/test_ops_gpu.py checks fast against generic paths. */
+int realise_batchnorm_stats_ex(void* stream, const void* x, int P, int C, int hw, const float* counts, int n_stat, float* mean, float* sq, float* slots);
+int realise_batchnorm_bwd_ex(void* stream, const void* dy, const void* relu_src, int P, int C, int hw, const float* counts, int n_stat,
+                             const void* xa, const float* mean_a, const float* rstd_a, const float* gamma_a, void* dxa, float* dgamma_a, float* dbeta_a,
+                             const void* xb, const float* mean_b, const float* rstd_b, const float* gamma_b, void* dxb, float* dgamma_b, float* dbeta_b,
+                             float* sums, float* slots);
 /* persistent NT kernel (gemm_nt8p.hip): key 0 = tile walk (1 default: every XCD owns a band of tile rows, 0: chunked tile ids),
- * key 1 = workgroups launched (default 256 = one per CU) */
+ * key 1 = workgroups launched (default 256 = one per CU); key 2 = one-round outputs (at most one 128 x 192 tile per CU) on the
+ * three-stage one-per-CU shape (1) or the two-per-CU shape (0, default: faster inside a step) of gemm_nt8.hip */
 void realise_set_nt8p(int key, int value);
 void realise_set_nt_group_m(int g);        /* tile order of the 8-wave NT GEMM: 0 row-major, g: g tile rows per column step (L2 blocking) */
 /* Diagnostics for the TN kernel: 2 no operand fetches, 3 no MFMA work, 4 skip the slab fold pass. */

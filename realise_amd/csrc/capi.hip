@@ -127,9 +127,11 @@ void realise_set_nt_allow_n96(int on) { set_nt_allow_n96(on); }
 void realise_set_nt_probe(int mode) { set_nt_probe(mode); }
 void realise_set_nt_variant(int v) { set_nt_variant(v); }
 void realise_set_nt_group_m(int g) { set_nt8_group_m(g); }
-void realise_set_ln(int key, int value) { if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); }
-void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); }
-void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); }
+void realise_set_ln(int key, int value) {
+  if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); else if (key == 2) set_bn_fast(value); else if (key == 3) set_bn_chunks(value);
+}
+void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); else if (key >= 1 && key <= 3) set_stream_priority(key - 1, value); }
+void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); else if (key == 2) set_nt8_single_round(value); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }
 void realise_set_tn_split(int n) { set_tn_split(n); }
@@ -305,6 +307,33 @@ int realise_batchnorm_bwd(void* stream, int dtype, const void* dy, const void* r
   hipStream_t st = (hipStream_t)stream;
   RL_BY_DTYPE(bn_bwd_t<bf16_t>(st, (const bf16_t*)dy, (const bf16_t*)relu_src, (const bf16_t*)x, save_mean, save_rstd, gamma, P, C, (bf16_t*)dx, dgamma, dbeta, scratch),
               bn_bwd_t<float>(st, (const float*)dy, (const float*)relu_src, (const float*)x, save_mean, save_rstd, gamma, P, C, (float*)dx, dgamma, dbeta, scratch));
+}
+// The BatchNorm reductions / maps exactly as the engine's glyph branch calls them (bf16; include/realise_hip_debug.h)
+int realise_batchnorm_stats_ex(void* stream, const void* x, int P, int C, int hw, const float* counts, int n_stat, float* mean, float* sq, float* slots) {
+  if (!x || !mean || !sq || !slots || P < 1 || C < 4 || (C & 3) || hw < 1) return RL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RowBound rb; rb.counts = counts; rb.hw = hw; rb.slots = slots;
+  RL_TRY(col_sum<bf16_t>(st, (const bf16_t*)x, P, C, mean, rb, 1.0f / (float)(n_stat > 0 ? n_stat : P)));
+  return col_sumsq_centered<bf16_t>(st, (const bf16_t*)x, P, C, mean, sq, rb);
+}
+int realise_batchnorm_bwd_ex(void* stream, const void* dy, const void* relu_src, int P, int C, int hw, const float* counts, int n_stat,
+                             const void* xa, const float* mean_a, const float* rstd_a, const float* gamma_a, void* dxa, float* dgamma_a, float* dbeta_a,
+                             const void* xb, const float* mean_b, const float* rstd_b, const float* gamma_b, void* dxb, float* dgamma_b, float* dbeta_b,
+                             float* sums, float* slots) {
+  if (!dy || !xa || !dxa || !sums || !slots || P < 1 || C < 4 || (C & 3) || hw < 1) return RL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RowBound rb; rb.counts = counts; rb.hw = hw; rb.slots = slots;
+  const bf16_t* g = (const bf16_t*)dy; const bf16_t* o = (const bf16_t*)relu_src;
+  const int ns = n_stat > 0 ? n_stat : P;
+  if (xb != nullptr) {
+    if (bn_bwd_reduce2(st, g, o, (const bf16_t*)xa, mean_a, rstd_a, (const bf16_t*)xb, mean_b, rstd_b, P, C, sums, rb) == RL_OK)
+      return bn_bwd_apply2(st, g, o, (const bf16_t*)xa, mean_a, rstd_a, gamma_a, (bf16_t*)dxa, dgamma_a, dbeta_a, (const bf16_t*)xb, mean_b, rstd_b, gamma_b,
+                           (bf16_t*)dxb, dgamma_b, dbeta_b, sums, P, C, rb, ns);
+    RL_TRY(bn_bwd_reduce<bf16_t>(st, g, o, (const bf16_t*)xb, mean_b, rstd_b, P, C, sums, rb));
+    RL_TRY(bn_bwd_apply<bf16_t>(st, g, o, (const bf16_t*)xb, mean_b, rstd_b, gamma_b, sums, P, C, (bf16_t*)dxb, dgamma_b, dbeta_b, rb, ns));
+  }
+  RL_TRY(bn_bwd_reduce<bf16_t>(st, g, o, (const bf16_t*)xa, mean_a, rstd_a, P, C, sums, rb));
+  return bn_bwd_apply<bf16_t>(st, g, o, (const bf16_t*)xa, mean_a, rstd_a, gamma_a, sums, P, C, (bf16_t*)dxa, dgamma_a, dbeta_a, rb, ns);
 }
 int realise_embedding_bwd(void* stream, int dtype, const void* de, const int64_t* ids, int B, int S, int H, float* word_grad, float* pos_grad,
                           int pos_zero, float* type_grad) {

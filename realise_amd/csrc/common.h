@@ -63,6 +63,13 @@ template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float
   b[0] = __uint_as_float(u.z << 16); b[1] = __uint_as_float(u.z & 0xffff0000u);
   b[2] = __uint_as_float(u.w << 16); b[3] = __uint_as_float(u.w & 0xffff0000u);
 }
+// eight bf16 already in registers (one dwordx4) -> two floatx4
+__device__ __forceinline__ void unpack8(const uint4 u, floatx4& a, floatx4& b) {
+  a[0] = __uint_as_float(u.x << 16); a[1] = __uint_as_float(u.x & 0xffff0000u);
+  a[2] = __uint_as_float(u.y << 16); a[3] = __uint_as_float(u.y & 0xffff0000u);
+  b[0] = __uint_as_float(u.z << 16); b[1] = __uint_as_float(u.z & 0xffff0000u);
+  b[2] = __uint_as_float(u.w << 16); b[3] = __uint_as_float(u.w & 0xffff0000u);
+}
 template <typename T> __device__ __forceinline__ void store8(T* p, floatx4 a, floatx4 b);
 template <> __device__ __forceinline__ void store8<float>(float* p, floatx4 a, floatx4 b) { *(floatx4*)p = a; *(floatx4*)(p + 4) = b; }
 template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, floatx4 a, floatx4 b) {

@@ -44,6 +44,17 @@ static int g_branch_overlap = 1;
 void set_branch_overlap(int on) { g_branch_overlap = on; }
 static int g_fwd_order = 0;
 void set_fwd_order(int o) { g_fwd_order = o; }
+// Priority classes of the engine-owned streams, applied when a stream is created (realise_set_engine keys 1..3, before the first
+// forward): 0 = the device default, -1 = the highest priority the device offers, +1 = the lowest.  [0] pinyin branch, [1] glyph
+// branch, [2] weight-gradient side stream.
+static int g_stream_pri[3] = {0, 0, 0};
+void set_stream_priority(int which, int pri) { if (which >= 0 && which < 3) g_stream_pri[which] = pri < 0 ? -1 : (pri > 0 ? 1 : 0); }
+static hipError_t create_stream(hipStream_t* s, int which) {
+  if (g_stream_pri[which] == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, g_stream_pri[which] < 0 ? greatest : least);
+}
 
 #define RL_TRY(expr) do { const int _rc = (expr); if (_rc != RL_OK) { fprintf(stderr, "[realise_hip] %s failed (%d) at %s:%d\n", #expr, _rc, __FILE__, __LINE__); return _rc; } } while (0)
 
@@ -124,7 +135,7 @@ template <typename T> struct Engine : EngineBase {
   int bw_layers = 0;
   bool side_ok() {
     if (side != nullptr) return true;
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+    if (create_stream(&side, 2) != hipSuccess) { side = nullptr; return false; }
     for (int p = 0; p < 2; ++p) {
       for (int k = 0; k < 4; ++k) (void)hipEventCreateWithFlags(&ev_ready[p][k], hipEventDisableTiming);
       (void)hipEventCreateWithFlags(&ev_done[p], hipEventDisableTiming);
@@ -156,7 +167,7 @@ template <typename T> struct Engine : EngineBase {
   bool branches_ok() {
     if (bst[0] != nullptr) return true;
     for (int k = 0; k < 2; ++k)
-      if (hipStreamCreateWithFlags(&bst[k], hipStreamNonBlocking) != hipSuccess) { bst[0] = bst[1] = nullptr; return false; }
+      if (create_stream(&bst[k], k) != hipSuccess) { bst[0] = bst[1] = nullptr; return false; }
     (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
     for (int k = 0; k < 2; ++k) (void)hipEventCreateWithFlags(&ev_join[k], hipEventDisableTiming);
     return true;
@@ -759,12 +770,27 @@ template <typename T> struct Engine : EngineBase {
       const int64_t* index = nullptr;
       T* dc2 = wp<T>(pl.r_dc2); T* dcs = wp<T>(pl.r_dcs); T* dh1 = wp<T>(pl.r_dh1); T* dc1 = wp<T>(pl.r_dc1);
       // out = relu(bn2(c2) + bns(cs))
-      RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), Pn, Co, sums, rb));
-      RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), pp(o.bn2.g), sums,
-                             Pn, Co, dc2, gp(o.bn2.g), gp(o.bn2.b), rb, Pn));
-      RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), Pn, Co, sums, rb));
-      RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), pp(o.bns.g), sums,
-                             Pn, Co, dcs, gp(o.bns.g), gp(o.bns.b), rb, Pn));
+      // bn2 and the shortcut's BN see the same incoming gradient and ReLU mask: bf16 reads them once for both (two passes over four
+      // tensors instead of four passes over three)
+      bool paired = false;
+      if constexpr (sizeof(T) == 2) {
+        if (4 * Co <= 2048 &&
+            bn_bwd_reduce2(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), wp<T>(a.cs), wp<float>(a.bns.mean),
+                           wp<float>(a.bns.rstd), Pn, Co, sums, rb) == RL_OK) {
+          RL_TRY(bn_bwd_apply2(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), pp(o.bn2.g), dc2, gp(o.bn2.g),
+                               gp(o.bn2.b), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), pp(o.bns.g), dcs, gp(o.bns.g), gp(o.bns.b),
+                               sums, Pn, Co, rb, Pn));
+          paired = true;
+        }
+      }
+      if (!paired) {
+        RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), Pn, Co, sums, rb));
+        RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.c2), wp<float>(a.bn2.mean), wp<float>(a.bn2.rstd), pp(o.bn2.g), sums,
+                               Pn, Co, dc2, gp(o.bn2.g), gp(o.bn2.b), rb, Pn));
+        RL_TRY(bn_bwd_reduce<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), Pn, Co, sums, rb));
+        RL_TRY(bn_bwd_apply<T>(st, d_out, wp<T>(a.out), wp<T>(a.cs), wp<float>(a.bns.mean), wp<float>(a.bns.rstd), pp(o.bns.g), sums,
+                               Pn, Co, dcs, gp(o.bns.g), gp(o.bns.b), rb, Pn));
+      }
       // conv2 (3x3 s1): weight grad and data grad
       { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.mode = TN_CONVW; te.out = gp(o.w2); te.Cin = Co; te.Cpad = Co; te.KHW = 9;
         if (a.Hout == 1) { te.tap0 = 4; RL_TRY(gemm_tn<T>(st, dc2, Co, wp<T>(a.h1), Co, Pn, Co, Co, te, rb.rows_dev)); }       // centre tap only

@@ -311,6 +311,7 @@ bool nt8p_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t ld
 int gemm_nt8p(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
 void set_nt8p_wgs(int n);
 void set_nt8p_order(int o);
+void set_nt8_single_round(int on);   // outputs of at most one 128 x 192 tile per CU: 1 the three-stage one-per-CU shape, 0 (default) the two-per-CU shape
 int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
              const EpiParams<bf16_t>& ep, int tile);
 void set_nt8_probe(int mode);

@@ -238,7 +238,7 @@ void set_nt_allow_n96(int on) { g_nt_n96 = on; }
 static int g_nt_probe = 0, g_nt_wide = 1, g_nt_variant = 0;
 static int g_conv_c64 = 1;          // block-1 conv2 (64 channels, 16x16 maps) through the LDS-resident kernels conv_c64_nt.hip / conv_wgrad_c64.hip
 void set_conv_c64(int on) { g_conv_c64 = on; }
-void set_nt_variant(int v) { g_nt_variant = (RL_PROBES || v == 0 || v == 9 || v == 12 || v == 16 || v >= 50) ? v : 0; }     // production: 0, 9 (4-wave), 12 / 16 (the two shipped 8-wave tiles), 50 / 51 (persistent on / off)
+void set_nt_variant(int v) { g_nt_variant = (RL_PROBES || v == 0 || v == 9 || v == 12 || v == 14 || v == 16 || v >= 50) ? v : 0; }     // production: 0, 9 (4-wave), 12 / 14 / 16 (the three shipped 8-wave tiles), 50 / 51 (persistent on / off)
 static int g_tn_probe = 0, g_tn_split = 0;
 void set_tn_split(int n) { g_tn_split = n; }
 void set_tn_probe(int mode) { g_tn_probe = RL_PROBES ? mode : 0; }

@@ -30,6 +30,8 @@
 namespace rl {
 
 static int g_nt8_group_m = 0;
+static int g_nt8_single_round = 0;        // 1: one-round outputs on the three-stage one-per-CU 128 x 192 shape (realise_set_nt8p key 2)
+void set_nt8_single_round(int on) { g_nt8_single_round = on; }
 void set_nt8_group_m(int g) { g_nt8_group_m = g; }
 
 // Logical tile id -> (tile row, tile column).  group_m <= 1: row-major (a run of consecutive ids walks along N: its tiles share
@@ -513,6 +515,12 @@ int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int6
     // one workgroup per CU) and under its fetch waits: qkv 39.6 -> 35.0 us, ffn1+GELU 56.1 -> 51.3, attn-out 14.6 -> 14.3, the
     // K = 2304 / 3072 shapes equal (tools/nt8_probe.cpp ws, profiles/round2_nt8_probe.log)
     tile = 6;
+    // Knob (off): outputs of at most one 128 x 192 tile per CU (N = 768: attention-output, FFN-down, the data gradients of qkv / FFN-up)
+    // on the three-stage one-per-CU shape.  Alone, with operands coming from HBM, that shape is 4-8 % faster (23.1 vs 24.0 us at
+    // K = 768 with dropout + residual, 48.5 vs 51.8 at K = 3072, 33.3 vs 36.3 at K = 2304: tools/nt8_probe.cpp cold); inside a step
+    // it is 0.3-0.4 ms SLOWER (18.8 vs 18.45 ms, two A/B pairs on one box): its 120 KB of LDS keep the weight-gradient and branch
+    // kernels of the other streams off the CU, which the 80 KB two-per-CU shape lets in.
+    if (g_nt8_single_round && (long)((M + 127) / 128) * ((N + 191) / 192) <= 256) tile = 4;
   }
 #if !RL_PROBES
   if (tile == 0) tile = 2;               // wide outputs the persistent kernel does not take: 256 x 192, one workgroup per CU
@@ -534,10 +542,10 @@ int gemm_nt8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int6
   switch (tile + flavour) {
     case 2: return launch_nt8_cfg<Cfg256x192>(st, A, lda, B, ldb, M, N, K, ep);
     case 6: return launch_nt8_cfg<Cfg128x192q>(st, A, lda, B, ldb, M, N, K, ep);
+    case 4: return launch_nt8_cfg<Cfg128x192>(st, A, lda, B, ldb, M, N, K, ep);
 #if RL_PROBES
     case 1: return launch_nt8_cfg<Cfg256x256>(st, A, lda, B, ldb, M, N, K, ep);
     case 3: return launch_nt8_cfg<Cfg256x128>(st, A, lda, B, ldb, M, N, K, ep);
-    case 4: return launch_nt8_cfg<Cfg128x192>(st, A, lda, B, ldb, M, N, K, ep);
     case 11: return launch_nt8_cfg<Cfg256x256c>(st, A, lda, B, ldb, M, N, K, ep);
     case 12: return launch_nt8_cfg<Cfg256x192c>(st, A, lda, B, ldb, M, N, K, ep);
     case 13: return launch_nt8_cfg<Cfg256x128c>(st, A, lda, B, ldb, M, N, K, ep);

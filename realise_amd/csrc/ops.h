@@ -150,6 +150,16 @@ int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const floa
                   float* d_emb, float* d_w_ih, float* d_b_ih);
 
 // ---- BatchNorm over NHWC activations [P][C] (K9) -------------------------------------------------
+// bf16 fast paths of the BatchNorm kernels (16-byte accesses; C, hw powers of two): knobs for A/B runs, and the two-branch backward of
+// a BasicBlock's bn2 + shortcut BN (shared dy and ReLU mask read once).  *2 functions return RL_ERR_ARG when the fast path does not apply.
+void set_bn_fast(int on);
+void set_bn_chunks(int n);
+int bn_fast();
+int bn_bwd_reduce2(hipStream_t st, const bf16_t* dy, const bf16_t* relu_src, const bf16_t* xa, const float* mean_a, const float* rstd_a,
+                   const bf16_t* xb, const float* mean_b, const float* rstd_b, int P, int C, float* sums4, RowBound rb);
+int bn_bwd_apply2(hipStream_t st, const bf16_t* dy, const bf16_t* relu_src, const bf16_t* xa, const float* mean_a, const float* rstd_a,
+                  const float* gamma_a, bf16_t* dxa, float* dgamma_a, float* dbeta_a, const bf16_t* xb, const float* mean_b, const float* rstd_b,
+                  const float* gamma_b, bf16_t* dxb, float* dgamma_b, float* dbeta_b, const float* sums4, int P, int C, RowBound rb, int n_stat);
 template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out, RowBound rb = RowBound(), float scale = 1.0f);   // scale != 1 needs rb.slots
 template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out, RowBound rb = RowBound());
 // train-mode finalize: stats -> (mean, rstd, scale, shift), running-stat update (unbiased var, momentum)

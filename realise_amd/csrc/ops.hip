@@ -157,6 +157,10 @@ __global__ void __launch_bounds__(256) ln_fwd16_kernel(LnFwdArgs<bf16_t> a) {
 }
 
 static int g_ln_fast = 1, g_ln_bwd_blocks = 512;
+static int g_bn_fast = 1, g_bn_chunks = 1024;       // bf16 16-byte BatchNorm / column-reduction kernels; row chunks (= workgroups) of the reductions
+void set_bn_fast(int on) { g_bn_fast = on; }
+void set_bn_chunks(int n) { if (n >= 1 && n <= 4096) g_bn_chunks = n; }
+int bn_fast() { return g_bn_fast; }
 void set_ln_fast(int on) { g_ln_fast = on; }
 void set_ln_bwd_blocks(int n) { g_ln_bwd_blocks = n > 0 ? n : 512; }
 
@@ -635,6 +639,147 @@ static int launch_col_reduce(hipStream_t st, const F& f, int rows, int C, float*
   return RL_LAUNCH_CHECK();
 }
 
+// ---- bf16 fast path of the column reductions: 16-byte loads, C a power of two in [8, 2048] ----------------------------------
+// One workgroup spans all C columns (C / 8 threads per row, 2048 / C rows per pass) over a contiguous chunk of rows.  The four row
+// passes of an iteration are LOADED before the first is added (4 x 16 B per input tensor in flight per thread, against 4 x 8 B and
+// a 64-bit row * ld multiply per load in the generic kernel), row weights come from a shift, and the per-column constants (mean,
+// rstd) sit in registers for the whole loop.  Partial sums go to the chunk's record and the same ordered fold as above: bitwise
+// reproducible.  The 64-channel reductions over the 957k rows of block 1 went from 1.1-1.6 TB/s to the figures in
+// profiles/round3_bn_probe.log.
+struct RowW16 {                       // multiplicity of a row's glyph (dedup), hw a power of two
+  const float* counts; int hw_shift;
+  __device__ __forceinline__ float operator()(int r) const { return counts ? counts[r >> hw_shift] : 1.0f; }
+};
+template <int N> struct Acc16 { floatx4 lo[N], hi[N]; };
+
+struct WSum16F {                      // sum_r w_r x[r][c]
+  static constexpr int NACC = 1;
+  const bf16_t* x; RowW16 w;
+  struct Item { uint4 x; };
+  struct Ctx {};
+  __device__ __forceinline__ Ctx prep(int) const { return Ctx{}; }
+  __device__ __forceinline__ Item load(int64_t e) const { return Item{*(const uint4*)(x + e)}; }
+  __device__ __forceinline__ void add(Acc16<1>& a, const Item& it, const Ctx&, int r) const {
+    floatx4 lo, hi; unpack8(it.x, lo, hi);
+    const float ww = w(r);
+    a.lo[0] += lo * ww; a.hi[0] += hi * ww;
+  }
+};
+struct SumSqC16F {                    // sum_r w_r (x[r][c] - mean[c])^2
+  static constexpr int NACC = 1;
+  const bf16_t* x; const float* mean; RowW16 w;
+  struct Item { uint4 x; };
+  struct Ctx { floatx4 mlo, mhi; };
+  __device__ __forceinline__ Ctx prep(int col) const { return Ctx{*(const floatx4*)(mean + col), *(const floatx4*)(mean + col + 4)}; }
+  __device__ __forceinline__ Item load(int64_t e) const { return Item{*(const uint4*)(x + e)}; }
+  __device__ __forceinline__ void add(Acc16<1>& a, const Item& it, const Ctx& c, int r) const {
+    floatx4 lo, hi; unpack8(it.x, lo, hi);
+    lo -= c.mlo; hi -= c.mhi;
+    const float ww = w(r);
+    a.lo[0] += lo * lo * ww; a.hi[0] += hi * hi * ww;
+  }
+};
+// BatchNorm backward sums of NB normalisations that share the incoming gradient and ReLU mask (bn2 and the shortcut's BN both feed
+// out = relu(bn2(c2) + bns(cs)), char_cnn.py:30-32): acc 0 = sum g, acc 1 + b = sum g * xhat_b, with dy and the mask read ONCE.
+template <int NB> struct BnBwd16F {
+  static constexpr int NACC = 1 + NB;
+  const bf16_t* dy; const bf16_t* relu_src; const bf16_t* x[NB]; const float* mean[NB]; const float* rstd[NB];
+  struct Item { uint4 g, o, x[NB]; };
+  struct Ctx { floatx4 mlo[NB], mhi[NB], rlo[NB], rhi[NB]; };
+  __device__ __forceinline__ Ctx prep(int col) const {
+    Ctx c;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      c.mlo[b] = *(const floatx4*)(mean[b] + col); c.mhi[b] = *(const floatx4*)(mean[b] + col + 4);
+      c.rlo[b] = *(const floatx4*)(rstd[b] + col); c.rhi[b] = *(const floatx4*)(rstd[b] + col + 4);
+    }
+    return c;
+  }
+  __device__ __forceinline__ Item load(int64_t e) const {
+    Item it;
+    it.g = *(const uint4*)(dy + e);
+    it.o = relu_src ? *(const uint4*)(relu_src + e) : uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) it.x[b] = *(const uint4*)(x[b] + e);
+    return it;
+  }
+  __device__ __forceinline__ void add(Acc16<NACC>& a, const Item& it, const Ctx& c, int) const {
+    floatx4 glo, ghi, olo, ohi;
+    unpack8(it.g, glo, ghi); unpack8(it.o, olo, ohi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { glo[j] = olo[j] > 0.f ? glo[j] : 0.f; ghi[j] = ohi[j] > 0.f ? ghi[j] : 0.f; }
+    a.lo[0] += glo; a.hi[0] += ghi;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      floatx4 xlo, xhi; unpack8(it.x[b], xlo, xhi);
+      a.lo[1 + b] += glo * ((xlo - c.mlo[b]) * c.rlo[b]);
+      a.hi[1 + b] += ghi * ((xhi - c.mhi[b]) * c.rhi[b]);
+    }
+  }
+};
+
+template <typename F>
+__global__ void __launch_bounds__(256) col_reduce16_kernel(F f, int rows_max, int c_shift, RowBound rb, float* __restrict__ slots, int slot_stride,
+                                                            int dup0_at) {
+  __shared__ floatx4 red[2][256];
+  const int tshift = c_shift - 3, tpr = 1 << tshift, rpp = 256 >> tshift;
+  const int cx = threadIdx.x & (tpr - 1), ry = threadIdx.x >> tshift, col = cx * 8;
+  const int rows = rb_rows(rb, rows_max);
+  const int chunk = (rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
+  Acc16<F::NACC> acc;
+#pragma unroll
+  for (int k = 0; k < F::NACC; ++k) acc.lo[k] = acc.hi[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const typename F::Ctx ctx = f.prep(col);
+  int r = r0 + ry;
+  const int64_t step = (int64_t)rpp << c_shift;
+  int64_t e = ((int64_t)r << c_shift) + col;
+  for (; r + 3 * rpp < r1; r += 4 * rpp, e += 4 * step) {
+    const typename F::Item i0 = f.load(e), i1 = f.load(e + step), i2 = f.load(e + 2 * step), i3 = f.load(e + 3 * step);
+    f.add(acc, i0, ctx, r); f.add(acc, i1, ctx, r + rpp); f.add(acc, i2, ctx, r + 2 * rpp); f.add(acc, i3, ctx, r + 3 * rpp);
+  }
+  for (; r < r1; r += rpp, e += step) { const typename F::Item i0 = f.load(e); f.add(acc, i0, ctx, r); }
+  float* rec = slots + (int64_t)blockIdx.x * slot_stride;
+  const int C = 1 << c_shift;
+#pragma unroll
+  for (int k = 0; k < F::NACC; ++k) {
+    red[0][threadIdx.x] = acc.lo[k];
+    red[1][threadIdx.x] = acc.hi[k];
+    __syncthreads();
+    if (ry == 0) {
+      floatx4 lo = acc.lo[k], hi = acc.hi[k];
+      for (int j = 1; j < rpp; ++j) { lo += red[0][j * tpr + cx]; hi += red[1][j * tpr + cx]; }
+      // record layout: accumulator k at [k * C, (k + 1) * C); with dup0_at > 0 (two normalisations) accumulator 0 is stored again at
+      // dup0_at * C and accumulators >= dup0_at move up one slot, so that the folded output reads [sum g | sum g xhat_0 | sum g | sum g xhat_1]
+      const int slot = (dup0_at > 0 && k >= dup0_at) ? k + 1 : k;
+      *(floatx4*)(rec + slot * C + col) = lo; *(floatx4*)(rec + slot * C + col + 4) = hi;
+      if (k == 0 && dup0_at > 0) { *(floatx4*)(rec + dup0_at * C + col) = lo; *(floatx4*)(rec + dup0_at * C + col + 4) = hi; }
+    }
+    __syncthreads();
+  }
+}
+static inline int pow2_shift(int C) { int s = 0; while ((1 << s) < C) ++s; return (1 << s) == C ? s : -1; }
+// fast path applies: bf16, C a power of two in [8, 2048], hw a power of two, ordered-fold scratch present
+static inline bool col16_ok(int C, const RowBound& rb) {
+  const int cs = pow2_shift(C);
+  return g_bn_fast && cs >= 3 && cs <= 11 && pow2_shift(rb.hw) >= 0 && rb.slots != nullptr;
+}
+// nout = folded outputs of C floats each, written contiguously to `out` (overwritten); alpha scales them
+template <typename F>
+static int launch_col_reduce16(hipStream_t st, const F& f, int rows, int C, float* out, int nout, int dup0_at, const RowBound& rb, float alpha) {
+  if (rows <= 0) return RL_OK;
+  const int cs = pow2_shift(C), rpp = 2048 >> cs;
+  const int stride = nout * C;
+  int g = g_bn_chunks;
+  const int max_g = (rows + 4 * rpp - 1) / (4 * rpp);
+  if (g > max_g) g = max_g;
+  if ((int64_t)g * stride > COL_SLOT_FLOATS) g = COL_SLOT_FLOATS / stride;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL((col_reduce16_kernel<F>), dim3(g), dim3(256), 0, st, f, rows, cs, rb, rb.slots, stride, dup0_at);
+  hipLaunchKernelGGL(col_fold_kernel, dim3((stride + 31) / 32), dim3(256), 0, st, rb.slots, stride, g, stride, out, out + C, C, 1, 0, alpha);
+  return RL_LAUNCH_CHECK();
+}
+
 template <typename T> struct SumF {
   const T* x; int64_t ld;
   __device__ __forceinline__ void operator()(int r, int c, floatx4& a0, floatx4&) const { a0 += load4<T>(x + (int64_t)r * ld + c); }
@@ -656,6 +801,9 @@ template <typename T> struct WSumF {
   }
 };
 template <typename T> int col_sum(hipStream_t st, const T* x, int P, int C, float* out, RowBound rb, float scale) {
+  if constexpr (sizeof(T) == 2) {
+    if (col16_ok(C, rb)) { WSum16F f{x, RowW16{rb.counts, pow2_shift(rb.hw)}}; return launch_col_reduce16(st, f, P, C, out, 1, 0, rb, scale); }
+  }
   WSumF<T> f{x, (int64_t)C, rb};
   return launch_col_reduce(st, f, P, C, out, nullptr, rb, rb.slots, scale);
 }
@@ -670,6 +818,9 @@ template <typename T> struct SumSqCF {
   }
 };
 template <typename T> int col_sumsq_centered(hipStream_t st, const T* x, int P, int C, const float* mean, float* out, RowBound rb) {
+  if constexpr (sizeof(T) == 2) {
+    if (col16_ok(C, rb)) { SumSqC16F f{x, mean, RowW16{rb.counts, pow2_shift(rb.hw)}}; return launch_col_reduce16(st, f, P, C, out, 1, 0, rb, 1.0f); }
+  }
   SumSqCF<T> f{x, (int64_t)C, mean, rb};
   return launch_col_reduce(st, f, P, C, out, nullptr, rb, rb.slots);
 }
@@ -693,8 +844,19 @@ template <typename T> struct BnBwdF {
 template <typename T>
 int bn_bwd_reduce(hipStream_t st, const T* dy, const T* relu_src, const T* x, const float* mean, const float* rstd, int P, int C,
                   float* sums, RowBound rb) {
+  if constexpr (sizeof(T) == 2) {
+    if (col16_ok(C, rb)) { BnBwd16F<1> f{dy, relu_src, {x}, {mean}, {rstd}}; return launch_col_reduce16(st, f, P, C, sums, 2, 0, rb, 1.0f); }
+  }
   BnBwdF<T> f{dy, relu_src, x, mean, rstd, (int64_t)C};
   return launch_col_reduce(st, f, P, C, sums, sums + C, rb, rb.slots);
+}
+// Two normalisations sharing dy and the ReLU mask: sums = [sum g | sum g xhat_a | sum g | sum g xhat_b] (4C floats).  Returns
+// RL_ERR_ARG when the fast path does not apply (the caller then runs the two single reductions).
+int bn_bwd_reduce2(hipStream_t st, const bf16_t* dy, const bf16_t* relu_src, const bf16_t* xa, const float* mean_a, const float* rstd_a,
+                   const bf16_t* xb, const float* mean_b, const float* rstd_b, int P, int C, float* sums, RowBound rb) {
+  if (!col16_ok(C, rb)) return RL_ERR_ARG;
+  BnBwd16F<2> f{dy, relu_src, {xa, xb}, {mean_a, mean_b}, {rstd_a, rstd_b}};
+  return launch_col_reduce16(st, f, P, C, sums, 4, 2, rb, 1.0f);
 }
 template int bn_bwd_reduce<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, const float*, const float*, int, int, float*, RowBound);
 template int bn_bwd_reduce<float>(hipStream_t, const float*, const float*, const float*, const float*, const float*, int, int, float*, RowBound);

@@ -272,12 +272,141 @@ __global__ void bn_apply_kernel(const T* __restrict__ x1, const float* __restric
     store4<T>(y + i, v);
   }
 }
+// ---- bf16 fast paths of the BatchNorm maps: 16-byte accesses, C and hw powers of two ------------------------------------------
+// A thread owns 8 consecutive channels; the grid stride (workgroups x 2048 elements) is a multiple of C, so its channels never
+// change and scale / shift / mean / rstd / gamma live in registers for the whole loop; rows and glyph multiplicities come from
+// shifts (the generic kernels pay a 64-bit i % C and i / C per 4 elements); four items are loaded before the first is used.
+static inline int pow2_shift2(int C) { int s = 0; while ((1 << s) < C) ++s; return (1 << s) == C ? s : -1; }
+struct F8 { floatx4 lo, hi; };
+__device__ __forceinline__ F8 ld8f(const float* p) { return F8{*(const floatx4*)p, *(const floatx4*)(p + 4)}; }
+
+template <int NX>
+__global__ void __launch_bounds__(256) bn_apply16_kernel(const bf16_t* __restrict__ x1, const float* __restrict__ sc1, const float* __restrict__ sh1,
+                                                          const bf16_t* __restrict__ x2, const float* __restrict__ sc2, const float* __restrict__ sh2,
+                                                          bf16_t* __restrict__ y, int P, int c_shift, int relu, RowBound rb) {
+  const int64_t n8 = ((int64_t)rb_rows(rb, P) << c_shift) >> 3;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)((i << 3) & ((1 << c_shift) - 1));
+  const F8 s1 = ld8f(sc1 + c), h1 = ld8f(sh1 + c);
+  F8 s2 = s1, h2 = h1;
+  if constexpr (NX == 2) { s2 = ld8f(sc2 + c); h2 = ld8f(sh2 + c); }
+  auto one = [&](int64_t k, uint4 u1, uint4 u2) {
+    floatx4 lo, hi; unpack8(u1, lo, hi);
+    lo = lo * s1.lo + h1.lo; hi = hi * s1.hi + h1.hi;
+    if constexpr (NX == 2) {
+      floatx4 lo2, hi2; unpack8(u2, lo2, hi2);
+      lo += lo2 * s2.lo + h2.lo; hi += hi2 * s2.hi + h2.hi;
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lo[j] = fmaxf(lo[j], 0.f); hi[j] = fmaxf(hi[j], 0.f); }
+    }
+    store8<bf16_t>(y + (k << 3), lo, hi);
+  };
+  const uint4* p1 = (const uint4*)x1; const uint4* p2 = (const uint4*)x2;
+  for (; i + 3 * stride < n8; i += 4 * stride) {
+    const uint4 a0 = p1[i], a1 = p1[i + stride], a2 = p1[i + 2 * stride], a3 = p1[i + 3 * stride];
+    uint4 b0 = a0, b1 = a1, b2 = a2, b3 = a3;
+    if constexpr (NX == 2) { b0 = p2[i]; b1 = p2[i + stride]; b2 = p2[i + 2 * stride]; b3 = p2[i + 3 * stride]; }
+    one(i, a0, b0); one(i + stride, a1, b1); one(i + 2 * stride, a2, b2); one(i + 3 * stride, a3, b3);
+  }
+  for (; i < n8; i += stride) { const uint4 a0 = p1[i]; uint4 b0 = a0; if constexpr (NX == 2) b0 = p2[i]; one(i, a0, b0); }
+}
+
+// dx_b = gamma_b rstd_b (g - w m1 - xhat_b w m2_b) for NB normalisations that share dy and the ReLU mask (bn2 + shortcut BN)
+struct BnBwdBranch { const bf16_t* x; const float* mean; const float* rstd; const float* gamma; const float* sums; bf16_t* dx; float* dgamma; float* dbeta; };
+template <int NB>
+__global__ void __launch_bounds__(256) bn_bwd_apply16_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ relu_src, BnBwdBranch b0,
+                                                              BnBwdBranch b1, int P, int c_shift, int hw_shift, float inv_p, RowBound rb) {
+  const int C = 1 << c_shift;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      if (b0.dgamma != nullptr) { b0.dbeta[c] += b0.sums[c]; b0.dgamma[c] += b0.sums[C + c]; }
+      if (NB == 2 && b1.dgamma != nullptr) { b1.dbeta[c] += b1.sums[c]; b1.dgamma[c] += b1.sums[C + c]; }
+    }
+  }
+  const int64_t n8 = ((int64_t)rb_rows(rb, P) << c_shift) >> 3;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)((i << 3) & (C - 1));
+  const BnBwdBranch br[2] = {b0, b1};
+  F8 mean[NB], k0[NB], rs[NB], m2[NB];
+  const F8 m1 = ld8f(b0.sums + c);                      // sum g is the same for both branches
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    mean[b] = ld8f(br[b].mean + c); rs[b] = ld8f(br[b].rstd + c); m2[b] = ld8f(br[b].sums + C + c);
+    const F8 g = ld8f(br[b].gamma + c);
+    k0[b].lo = g.lo * rs[b].lo; k0[b].hi = g.hi * rs[b].hi;
+  }
+  const int row_shift = c_shift - 3 + hw_shift;         // item index -> glyph index
+  const uint4* pg = (const uint4*)dy; const uint4* po = (const uint4*)relu_src;
+  auto one = [&](int64_t k, uint4 ug, uint4 uo, const uint4* ux) {
+    floatx4 glo, ghi, olo, ohi;
+    unpack8(ug, glo, ghi);
+    if (relu_src != nullptr) {
+      unpack8(uo, olo, ohi);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { glo[j] = olo[j] > 0.f ? glo[j] : 0.f; ghi[j] = ohi[j] > 0.f ? ghi[j] : 0.f; }
+    }
+    const float w = (rb.counts ? rb.counts[k >> row_shift] : 1.0f) * inv_p;
+    const floatx4 a_lo = glo - m1.lo * w, a_hi = ghi - m1.hi * w;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      floatx4 xlo, xhi; unpack8(ux[b], xlo, xhi);
+      xlo = (xlo - mean[b].lo) * rs[b].lo; xhi = (xhi - mean[b].hi) * rs[b].hi;
+      store8<bf16_t>(br[b].dx + (k << 3), k0[b].lo * (a_lo - xlo * (m2[b].lo * w)), k0[b].hi * (a_hi - xhi * (m2[b].hi * w)));
+    }
+  };
+  for (; i + stride < n8; i += 2 * stride) {
+    const uint4 g0 = pg[i], g1 = pg[i + stride];
+    uint4 o0 = g0, o1 = g1;
+    if (relu_src != nullptr) { o0 = po[i]; o1 = po[i + stride]; }
+    uint4 x0[NB], x1[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { x0[b] = ((const uint4*)br[b].x)[i]; x1[b] = ((const uint4*)br[b].x)[i + stride]; }
+    one(i, g0, o0, x0); one(i + stride, g1, o1, x1);
+  }
+  for (; i < n8; i += stride) {
+    const uint4 g0 = pg[i];
+    uint4 o0 = g0;
+    if (relu_src != nullptr) o0 = po[i];
+    uint4 x0[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) x0[b] = ((const uint4*)br[b].x)[i];
+    one(i, g0, o0, x0);
+  }
+}
+static inline int ew16_blocks(int64_t n8) { int64_t b = (n8 + 255) / 256; b = (b + 3) / 4; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+static inline bool bn16_ok(int P, int C, const RowBound& rb) {
+  const int cs = pow2_shift2(C);
+  return bn_fast() && cs >= 3 && cs <= 11 && pow2_shift2(rb.hw) >= 0 && (((int64_t)P * C) & 7) == 0;
+}
+// the two-branch backward map (bn2 + shortcut BN of a BasicBlock): RL_ERR_ARG when the fast path does not apply
+int bn_bwd_apply2(hipStream_t st, const bf16_t* dy, const bf16_t* relu_src, const bf16_t* xa, const float* mean_a, const float* rstd_a,
+                  const float* gamma_a, bf16_t* dxa, float* dgamma_a, float* dbeta_a, const bf16_t* xb, const float* mean_b, const float* rstd_b,
+                  const float* gamma_b, bf16_t* dxb, float* dgamma_b, float* dbeta_b, const float* sums4, int P, int C, RowBound rb, int n_stat) {
+  if (!bn16_ok(P, C, rb)) return RL_ERR_ARG;
+  const BnBwdBranch b0{xa, mean_a, rstd_a, gamma_a, sums4, dxa, dgamma_a, dbeta_a}, b1{xb, mean_b, rstd_b, gamma_b, sums4 + 2 * C, dxb, dgamma_b, dbeta_b};
+  const int64_t n8 = (int64_t)P * C / 8;
+  hipLaunchKernelGGL((bn_bwd_apply16_kernel<2>), dim3(ew16_blocks(n8)), dim3(256), 0, st, dy, relu_src, b0, b1, P, pow2_shift2(C), pow2_shift2(rb.hw),
+                     1.0f / (float)(n_stat > 0 ? n_stat : P), rb);
+  return RL_LAUNCH_CHECK();
+}
+
 static inline int ew_blocks(int64_t n4) { int64_t b = (n4 + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 template <typename T>
 int bn_apply(hipStream_t st, const T* x1, const float* sc1, const float* sh1, const T* x2, const float* sc2, const float* sh2,
              T* y, int P, int C, int relu, RowBound rb) {
   if (C & 3) return RL_ERR_ARG;
   const int64_t n = (int64_t)P * C;
+  if constexpr (sizeof(T) == 2) {
+    if (bn16_ok(P, C, rb)) {
+      if (x2 != nullptr) hipLaunchKernelGGL((bn_apply16_kernel<2>), dim3(ew16_blocks(n / 8)), dim3(256), 0, st, x1, sc1, sh1, x2, sc2, sh2, y, P, pow2_shift2(C), relu, rb);
+      else hipLaunchKernelGGL((bn_apply16_kernel<1>), dim3(ew16_blocks(n / 8)), dim3(256), 0, st, x1, sc1, sh1, x2, sc2, sh2, y, P, pow2_shift2(C), relu, rb);
+      return RL_LAUNCH_CHECK();
+    }
+  }
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, x1, sc1, sh1, x2, sc2, sh2, y, P, C, relu, rb);
   return RL_LAUNCH_CHECK();
 }
@@ -316,6 +445,14 @@ int bn_bwd_apply(hipStream_t st, const T* dy, const T* relu_src, const T* x, con
                  const float* gamma, const float* sums, int P, int C, T* dx, float* dgamma, float* dbeta, RowBound rb, int n_stat) {
   if (C & 3) return RL_ERR_ARG;
   const int64_t n = (int64_t)P * C;
+  if constexpr (sizeof(T) == 2) {
+    if (bn16_ok(P, C, rb)) {
+      const BnBwdBranch b0{x, mean, rstd, gamma, sums, dx, dgamma, dbeta};
+      hipLaunchKernelGGL((bn_bwd_apply16_kernel<1>), dim3(ew16_blocks(n / 8)), dim3(256), 0, st, dy, relu_src, b0, b0, P, pow2_shift2(C), pow2_shift2(rb.hw),
+                         1.0f / (float)(n_stat > 0 ? n_stat : P), rb);
+      return RL_LAUNCH_CHECK();
+    }
+  }
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, dy, relu_src, x, mean, rstd, gamma,
                      sums, P, C, 1.0f / (float)(n_stat > 0 ? n_stat : P), dx, rb, dgamma, dbeta);
   return RL_LAUNCH_CHECK();

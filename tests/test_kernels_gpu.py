@@ -487,10 +487,11 @@ def test_build_pho_matches_host_bookkeeping(T_):
     assert alive.cpu().tolist() == [int((lens > t).sum()) for t in range(Tw)]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 50])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 14, 16, 50])
 def test_gemm_nt_tile_variants(variant):
     """realise_set_nt_variant: every NT kernel the library holds must give the default choice's results.  The production library
-    ships 9 (4-wave), 12 (8-wave 256x192), 16 (8-wave 128x192, two workgroups per CU) and 50 (persistent 256x192); the measured-and-
+    ships 9 (4-wave), 12 (8-wave 256x192), 14 (8-wave 128x192, three stages), 16 (8-wave 128x192, two workgroups per CU) and 50
+    (persistent 256x192); the measured-and-
     rejected shapes 1..8 (8-wave 128x192 / 256x128 tiles of the 4-wave family, 3-stage rings, spread fetch issue, the phase-shifted
     two-group kernel) exist in the probe build only (REALISE_HIP_PROBES=1)."""
     lib = _capi.load()
