@@ -29,16 +29,20 @@ void realise_set_engine(int key, int value);
 int realise_layernorm_bwd_ex(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,
                              uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* dgamma, float* dbeta, float* slots, int rows, int H);
 /* LayerNorm kernels: key 0 = bf16 fast path (half a wave per row, 16-byte accesses; default 1), key 1 = workgroups of its backward (default 512);
- * BatchNorm kernels: key 2 = bf16 fast paths (16-byte accesses, paired bn2 + shortcut backward; default 1), key 3 = row chunks of their
+ * BatchNorm kernels: key 2 = bf16 fast paths (1, default: 16-byte accesses, paired bn2 + shortcut backward, one-pass training
+ * statistics; 3: the same with two-pass statistics; 0: generic kernels), key 3 = row chunks of their
  * column reductions (default 1024) */
 void realise_set_ln(int key, int value);
-/* BatchNorm statistics and backward exactly as the engine's glyph branch runs them (bf16, NHWC viewed as [P, C]; char_cnn.py:15-32):
- * per-row-chunk partial records in `slots` (1 MiB scratch) folded in a fixed order; `counts` (nullable) = multiplicity of each image of
- * `hw` pixels (glyph dedup), n_stat = the true sample count of the statistics (0: P).  stats: mean[C] and sq[C] = sum w (x - mean)^2.
+/* BatchNorm training statistics and backward exactly as the engine's glyph branch runs them (bf16, NHWC viewed as [P, C];
+ * char_cnn.py:15-32): per-row-chunk partial records in `slots` (1 MiB scratch) folded in a fixed order; `counts` (nullable) =
+ * multiplicity of each image of `hw` pixels (glyph dedup), n_stat = the true sample count of the statistics (0: P).
+ * stats: mean / rstd / scale / shift [C], running buffers updated (unbiased variance), num_batches_tracked += 1; sq_scratch: C floats.
  * bwd: dx = gamma rstd (g - w sum(g) / n - xhat w sum(g xhat) / n) with g = dy masked by relu_src > 0; dgamma / dbeta are ADDED to;
  * xb != NULL: a second normalisation sharing dy and the mask (bn2 + shortcut BN of a BasicBlock; one pass reads dy and the mask for
  * both); sums: 4C floats of scratch.  tools/bn_probe.py times them; tests/test_ops_gpu.py checks fast against generic paths. */
-int realise_batchnorm_stats_ex(void* stream, const void* x, int P, int C, int hw, const float* counts, int n_stat, float* mean, float* sq, float* slots);
+int realise_batchnorm_stats_ex(void* stream, const void* x, int P, int C, int hw, const float* counts, int n_stat, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
+                               float* scale, float* shift, float* sq_scratch, float* slots);
 int realise_batchnorm_bwd_ex(void* stream, const void* dy, const void* relu_src, int P, int C, int hw, const float* counts, int n_stat,
                              const void* xa, const float* mean_a, const float* rstd_a, const float* gamma_a, void* dxa, float* dgamma_a, float* dbeta_a,
                              const void* xb, const float* mean_b, const float* rstd_b, const float* gamma_b, void* dxb, float* dgamma_b, float* dbeta_b,

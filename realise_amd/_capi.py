@@ -86,7 +86,7 @@ SYMBOLS = {
     "realise_set_ln": (None, [_I, _I]),
     "realise_set_engine": (None, [_I, _I]),
     "realise_layernorm_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_float, _P, _P, _P, _I, _I]),
-    "realise_batchnorm_stats_ex": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "realise_batchnorm_stats_ex": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, C.c_float, C.c_float] + [_P] * 9),
     "realise_batchnorm_bwd_ex": (_I, [_P, _P, _P, _I, _I, _I, _P, _I] + [_P] * 7 + [_P] * 7 + [_P, _P]),
     "realise_set_tn_probe": (None, [_I]),
     "realise_set_tn_split": (None, [_I]),

@@ -309,12 +309,18 @@ int realise_batchnorm_bwd(void* stream, int dtype, const void* dy, const void* r
               bn_bwd_t<float>(st, (const float*)dy, (const float*)relu_src, (const float*)x, save_mean, save_rstd, gamma, P, C, (float*)dx, dgamma, dbeta, scratch));
 }
 // The BatchNorm reductions / maps exactly as the engine's glyph branch calls them (bf16; include/realise_hip_debug.h)
-int realise_batchnorm_stats_ex(void* stream, const void* x, int P, int C, int hw, const float* counts, int n_stat, float* mean, float* sq, float* slots) {
-  if (!x || !mean || !sq || !slots || P < 1 || C < 4 || (C & 3) || hw < 1) return RL_ERR_ARG;
+int realise_batchnorm_stats_ex(void* stream, const void* x, int P, int C, int hw, const float* counts, int n_stat, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd,
+                               float* scale, float* shift, float* sq_scratch, float* slots) {
+  if (!x || !mean || !rstd || !scale || !shift || !sq_scratch || !slots || !running_mean || !running_var || P < 1 || C < 4 || (C & 3) || hw < 1) return RL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   RowBound rb; rb.counts = counts; rb.hw = hw; rb.slots = slots;
-  RL_TRY(col_sum<bf16_t>(st, (const bf16_t*)x, P, C, mean, rb, 1.0f / (float)(n_stat > 0 ? n_stat : P)));
-  return col_sumsq_centered<bf16_t>(st, (const bf16_t*)x, P, C, mean, sq, rb);
+  const int n = n_stat > 0 ? n_stat : P;
+  if (bn_stats_train16(st, (const bf16_t*)x, P, C, n, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, num_batches_tracked, rb) == RL_OK)
+    return RL_OK;
+  RL_TRY(col_sum<bf16_t>(st, (const bf16_t*)x, P, C, mean, rb, 1.0f / (float)n));
+  RL_TRY(col_sumsq_centered<bf16_t>(st, (const bf16_t*)x, P, C, mean, sq_scratch, rb));
+  return bn_finalize_train(st, mean, sq_scratch, C, n, gamma, beta, eps, momentum, running_mean, running_var, rstd, scale, shift, num_batches_tracked);
 }
 int realise_batchnorm_bwd_ex(void* stream, const void* dy, const void* relu_src, int P, int C, int hw, const float* counts, int n_stat,
                              const void* xa, const float* mean_a, const float* rstd_a, const float* gamma_a, void* dxa, float* dgamma_a, float* dbeta_a,

@@ -699,6 +699,11 @@ template <typename T> struct Engine : EngineBase {
   int bn_forward(hipStream_t st, const T* x, int Pn, int C, const BnOff& o, const BnAct& a, const RowBound& rb) {
     if (last.training) {
       float* sums = wp<float>(pl.bn_sums);
+      if constexpr (sizeof(T) == 2) {
+        if (bn_stats_train16(st, x, Pn, C, Pn, pp(o.g), pp(o.b), 1e-5f, 0.1f, BF + o.rmean, BF + o.rvar, wp<float>(a.mean), wp<float>(a.rstd),
+                             wp<float>(a.scale), wp<float>(a.shift), BI + o.nbt, rb) == RL_OK)
+          return RL_OK;
+      }
       RL_TRY(col_sum<T>(st, x, Pn, C, wp<float>(a.mean), rb, 1.0f / (float)Pn));          // the fold writes the mean directly
       RL_TRY(col_sumsq_centered<T>(st, x, Pn, C, wp<float>(a.mean), sums + C, rb));
       RL_TRY(bn_finalize_train(st, wp<float>(a.mean), sums + C, C, Pn, pp(o.g), pp(o.b), 1e-5f, 0.1f, BF + o.rmean, BF + o.rvar,

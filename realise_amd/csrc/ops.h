@@ -155,6 +155,10 @@ int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const floa
 void set_bn_fast(int on);
 void set_bn_chunks(int n);
 int bn_fast();
+// one-pass training statistics of a bf16 [P, C] map + everything bn_finalize_train does (2 launches instead of 5, x read once);
+// RL_ERR_ARG when the fast path does not apply
+int bn_stats_train16(hipStream_t st, const bf16_t* x, int P, int C, int n_stat, const float* gamma, const float* beta, float eps, float momentum,
+                     float* rmean, float* rvar, float* mean, float* rstd, float* scale, float* shift, int64_t* nbt, RowBound rb);
 int bn_bwd_reduce2(hipStream_t st, const bf16_t* dy, const bf16_t* relu_src, const bf16_t* xa, const float* mean_a, const float* rstd_a,
                    const bf16_t* xb, const float* mean_b, const float* rstd_b, int P, int C, float* sums4, RowBound rb);
 int bn_bwd_apply2(hipStream_t st, const bf16_t* dy, const bf16_t* relu_src, const bf16_t* xa, const float* mean_a, const float* rstd_a,

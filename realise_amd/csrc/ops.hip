@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(256) ln_fwd16_kernel(LnFwdArgs<bf16_t> a) {
 
 static int g_ln_fast = 1, g_ln_bwd_blocks = 512;
 static int g_bn_fast = 1, g_bn_chunks = 1024;       // bf16 16-byte BatchNorm / column-reduction kernels; row chunks (= workgroups) of the reductions
-void set_bn_fast(int on) { g_bn_fast = on; }
+static int g_bn_onepass = 1;                        // bf16 training statistics in one pass about the running mean (bn_stats_train16)
+void set_bn_fast(int on) { g_bn_fast = on & 1; g_bn_onepass = (on & 1) && !(on & 2); }
 void set_bn_chunks(int n) { if (n >= 1 && n <= 4096) g_bn_chunks = n; }
 int bn_fast() { return g_bn_fast; }
 void set_ln_fast(int on) { g_ln_fast = on; }
@@ -718,6 +719,61 @@ template <int NB> struct BnBwd16F {
   }
 };
 
+// One-pass BatchNorm training statistics: S1 = sum w (x - K), S2 = sum w (x - K)^2 about the per-channel pivot K = the running mean
+// (what the mean has been; 0 at initialisation).  mean = K + S1 / n, var = S2 / n - (S1 / n)^2: with fp32 sums the cancellation error
+// is ~1e-7 (1 + (mean - K)^2 / var) relative, far inside bf16 activations' own rounding; the fp32 parity mode keeps the two-pass form.
+struct Moments16F {
+  static constexpr int NACC = 2;
+  const bf16_t* x; const float* pivot; RowW16 w;
+  struct Item { uint4 x; };
+  struct Ctx { floatx4 klo, khi; };
+  __device__ __forceinline__ Ctx prep(int col) const { return Ctx{*(const floatx4*)(pivot + col), *(const floatx4*)(pivot + col + 4)}; }
+  __device__ __forceinline__ Item load(int64_t e) const { return Item{*(const uint4*)(x + e)}; }
+  __device__ __forceinline__ void add(Acc16<2>& a, const Item& it, const Ctx& c, int r) const {
+    floatx4 lo, hi; unpack8(it.x, lo, hi);
+    lo -= c.klo; hi -= c.khi;
+    const float ww = w(r);
+    const floatx4 wlo = lo * ww, whi = hi * ww;
+    a.lo[0] += wlo; a.hi[0] += whi;
+    a.lo[1] += wlo * lo; a.hi[1] += whi * hi;
+  }
+};
+// Ordered fold of the [S1 | S2] records (same lane / tree order as col_fold_kernel) + everything bn_train_kernel does, one workgroup
+// per 32 channels: mean, rstd, scale, shift, running statistics (unbiased variance, momentum), num_batches_tracked.
+__global__ void __launch_bounds__(256) bn_fold_train_kernel(const float* __restrict__ slots, int slot_stride, int nrec, int C, float inv_n, float unbias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                                             float* rmean, float* rvar, float* mean, float* rstd, float* scale, float* shift, int64_t* nbt) {
+  __shared__ floatx4 red[2][32][8];
+  const int cq = threadIdx.x & 7, kl = threadIdx.x >> 3;
+  const int c = (blockIdx.x * 8 + cq) * 4;
+  floatx4 s1 = floatx4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  if (c < C)
+    for (int k = kl; k < nrec; k += 32) {
+      const float* rec = slots + (int64_t)k * slot_stride;
+      s1 += *(const floatx4*)(rec + c);
+      s2 += *(const floatx4*)(rec + C + c);
+    }
+  red[0][kl][cq] = s1; red[1][kl][cq] = s2;
+  __syncthreads();
+#pragma unroll
+  for (int w = 16; w > 0; w >>= 1) {
+    if (kl < w) { red[0][kl][cq] += red[0][kl + w][cq]; red[1][kl][cq] += red[1][kl + w][cq]; }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt != nullptr) *nbt += 1;
+  if (kl == 0 && c < C) {
+    s1 = red[0][0][cq]; s2 = red[1][0][cq];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = s1[j] * inv_n, m = rmean[c + j] + d;               // the pivot was the running mean
+      const float var = fmaxf(s2[j] * inv_n - d * d, 0.f);
+      const float rs = 1.0f / sqrtf(var + eps), g = gamma[c + j];
+      mean[c + j] = m; rstd[c + j] = rs; scale[c + j] = g * rs; shift[c + j] = beta[c + j] - m * g * rs;
+      rmean[c + j] = (1.0f - momentum) * rmean[c + j] + momentum * m;
+      rvar[c + j] = (1.0f - momentum) * rvar[c + j] + momentum * (var * unbias);
+    }
+  }
+}
 template <typename F>
 __global__ void __launch_bounds__(256) col_reduce16_kernel(F f, int rows_max, int c_shift, RowBound rb, float* __restrict__ slots, int slot_stride,
                                                             int dup0_at) {
@@ -849,6 +905,22 @@ int bn_bwd_reduce(hipStream_t st, const T* dy, const T* relu_src, const T* x, co
   }
   BnBwdF<T> f{dy, relu_src, x, mean, rstd, (int64_t)C};
   return launch_col_reduce(st, f, P, C, sums, sums + C, rb, rb.slots);
+}
+int bn_stats_train16(hipStream_t st, const bf16_t* x, int P, int C, int n_stat, const float* gamma, const float* beta, float eps, float momentum,
+                     float* rmean, float* rvar, float* mean, float* rstd, float* scale, float* shift, int64_t* nbt, RowBound rb) {
+  if (!col16_ok(C, rb) || !g_bn_onepass || P <= 0) return RL_ERR_ARG;
+  const int cs = pow2_shift(C), rpp = 2048 >> cs, stride = 2 * C;
+  int g = g_bn_chunks;
+  const int max_g = (P + 4 * rpp - 1) / (4 * rpp);
+  if (g > max_g) g = max_g;
+  if ((int64_t)g * stride > COL_SLOT_FLOATS) g = COL_SLOT_FLOATS / stride;
+  if (g < 1) g = 1;
+  Moments16F f{x, rmean, RowW16{rb.counts, pow2_shift(rb.hw)}};
+  hipLaunchKernelGGL((col_reduce16_kernel<Moments16F>), dim3(g), dim3(256), 0, st, f, P, cs, rb, rb.slots, stride, 0);
+  const int n = n_stat > 0 ? n_stat : P;
+  hipLaunchKernelGGL(bn_fold_train_kernel, dim3((C + 31) / 32), dim3(256), 0, st, rb.slots, stride, g, C, 1.0f / (float)n,
+                     (float)n / (float)(n > 1 ? n - 1 : 1), gamma, beta, eps, momentum, rmean, rvar, mean, rstd, scale, shift, nbt);
+  return RL_LAUNCH_CHECK();
 }
 // Two normalisations sharing dy and the ReLU mask: sums = [sum g | sum g xhat_a | sum g | sum g xhat_b] (4C floats).  Returns
 // RL_ERR_ARG when the fast path does not apply (the caller then runs the two single reductions).

@@ -100,6 +100,74 @@ def test_batchnorm_forward_backward_match_torch(dtype, relu):
         assert F.cosine_similarity(dg.cpu(), gr.grad, dim=0).item() > 0.999 and F.cosine_similarity(db.cpu(), br.grad, dim=0).item() > 0.999
 
 
+@pytest.mark.parametrize("mode", [0, 3, 1])
+def test_batchnorm_engine_form_with_glyph_multiplicities(mode):
+    """The BatchNorm passes as the glyph branch runs them (bf16, ordered-fold records, every distinct glyph weighted by its multiplicity,
+    bn2 + shortcut BN sharing the incoming gradient and ReLU mask): generic kernels (0), the 16-byte kernels with two-pass statistics (3)
+    and with one-pass statistics about the running mean (1) against the dense fp32 formulas on the expanded batch (char_cnn.py:15-32)."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(11)
+    images, hw, Cc = 300, 64, 128
+    P = images * hw
+    counts = torch.randint(1, 5, (images,), generator=g).float()
+    w = counts.repeat_interleave(hw)[:, None]                               # weight of every row
+    n = int(w.sum().item())
+    bf = torch.bfloat16
+    xa = (torch.randn(P, Cc, generator=g) * 1.5 + torch.linspace(-3, 3, Cc)).to(bf)
+    xb = (torch.randn(P, Cc, generator=g) * 0.7 + 0.5).to(bf)
+    dy = torch.randn(P, Cc, generator=g).to(bf)
+    o = torch.randn(P, Cc, generator=g).to(bf)                              # the block output: the ReLU mask is o > 0
+    gamma_a, gamma_b = torch.rand(Cc, generator=g) + 0.5, torch.rand(Cc, generator=g) + 0.5
+    beta = torch.randn(Cc, generator=g) * 0.2
+    rm0, rv0 = torch.randn(Cc, generator=g) * 0.3, torch.rand(Cc, generator=g) + 0.5
+
+    def ref_stats(x):
+        xf = x.float()
+        m = (xf * w).sum(0) / n
+        var = ((xf - m) ** 2 * w).sum(0) / n
+        return m, var
+
+    try:
+        lib.realise_set_ln(2, mode)
+        slots, sums = torch.empty(262144, device="cuda"), torch.empty(4 * Cc, device="cuda")
+        xad, xbd, dyd, od = dev(xa, bf), dev(xb, bf), dev(dy, bf), dev(o, bf)
+        cd = dev(counts)
+        stats = {}
+        for name, xd, x in (("a", xad, xa), ("b", xbd, xb)):
+            rm, rv = dev(rm0), dev(rv0)
+            mean, rstd, sc, sh, sq = (torch.empty(Cc, device="cuda") for _ in range(5))
+            nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+            ga = gamma_a if name == "a" else gamma_b
+            _capi.check(lib.realise_batchnorm_stats_ex(st(), p(xd), P, Cc, hw, p(cd), n, p(dev(ga)), p(dev(beta)), 1e-5, 0.1, p(rm), p(rv), p(nbt), p(mean),
+                                                       p(rstd), p(sc), p(sh), p(sq), p(slots)), "bn stats")
+            m_ref, var_ref = ref_stats(x)
+            rs_ref = 1.0 / torch.sqrt(var_ref + 1e-5)
+            assert (mean.cpu() - m_ref).abs().max().item() < 2e-5 * (1 + m_ref.abs().max().item())
+            assert ((rstd.cpu() - rs_ref) / rs_ref).abs().max().item() < 2e-5
+            assert (sc.cpu() - ga * rs_ref).abs().max().item() < 1e-4 and (sh.cpu() - (beta - m_ref * ga * rs_ref)).abs().max().item() < 1e-4
+            assert (rm.cpu() - (0.9 * rm0 + 0.1 * m_ref)).abs().max().item() < 1e-5
+            assert (rv.cpu() - (0.9 * rv0 + 0.1 * var_ref * n / (n - 1))).abs().max().item() < 1e-4
+            assert int(nbt.item()) == 1
+            stats[name] = (mean, rstd, m_ref, rs_ref)
+        dxa, dxb = torch.empty(P, Cc, device="cuda", dtype=bf), torch.empty(P, Cc, device="cuda", dtype=bf)
+        dga, dba, dgb, dbb = (torch.zeros(Cc, device="cuda") for _ in range(4))
+        _capi.check(lib.realise_batchnorm_bwd_ex(st(), p(dyd), p(od), P, Cc, hw, p(cd), n, p(xad), p(stats["a"][0]), p(stats["a"][1]), p(dev(gamma_a)), p(dxa),
+                                                 p(dga), p(dba), p(xbd), p(stats["b"][0]), p(stats["b"][1]), p(dev(gamma_b)), p(dxb), p(dgb), p(dbb), p(sums),
+                                                 p(slots)), "bn bwd")
+        torch.cuda.synchronize()
+    finally:
+        lib.realise_set_ln(2, 1)
+    gm = torch.where(o.float() > 0, dy.float(), torch.zeros(()))          # gradient per DISTINCT row (already summed over its tokens)
+    for x, ga, (_, _, m_ref, rs_ref), dx, dgam, dbet in ((xa, gamma_a, stats["a"], dxa, dga, dba), (xb, gamma_b, stats["b"], dxb, dgb, dbb)):
+        xh = (x.float() - m_ref) * rs_ref
+        s1, s2 = gm.sum(0), (gm * xh).sum(0)
+        dx_ref = ga * rs_ref * (gm - w * s1 / n - xh * w * s2 / n)
+        assert (dx.float().cpu() - dx_ref).abs().max().item() < 2e-2 * dx_ref.abs().max().item()
+        assert F.cosine_similarity(dx.float().cpu().reshape(-1), dx_ref.reshape(-1), dim=0).item() > 0.9999
+        assert (dbet.cpu() - s1).abs().max().item() < 1e-3 * s1.abs().max().item() + 1e-2
+        assert (dgam.cpu() - s2).abs().max().item() < 1e-3 * s2.abs().max().item() + 1e-2
+
+
 def test_batchnorm_eval_uses_running_statistics():
     lib = _capi.load()
     P, Cc = 4096, 128

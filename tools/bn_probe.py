@@ -46,6 +46,7 @@ def run(images, hw, Cc, dedup=True):
     dg2, db2 = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
     rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
     scratch = torch.empty(4 * Cc, device="cuda")
+    sc_, sh_ = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
     it = [0]
 
     def nxt():
@@ -54,7 +55,8 @@ def run(images, hw, Cc, dedup=True):
 
     def stats():
         s = nxt()
-        _capi.check(lib.realise_batchnorm_stats_ex(st(), p(s["x"]), P, Cc, hw, p(counts), n_stat, p(mean), p(sq), p(slots)), "stats")
+        _capi.check(lib.realise_batchnorm_stats_ex(st(), p(s["x"]), P, Cc, hw, p(counts), n_stat, p(gamma), p(beta), 1e-5, 0.1, p(rm), p(rv), None, p(mean),
+                                                   p(sq), p(sc_), p(sh_), p(scratch), p(slots)), "stats")
 
     def apply1():
         s = nxt()
@@ -69,24 +71,26 @@ def run(images, hw, Cc, dedup=True):
 
     mb = P * Cc * 2 / 1e6
     res = {}
-    for fast in (0, 1):
+    for fast in (0, 3, 1):          # generic kernels; 16-byte kernels with two-pass statistics; the same with one-pass statistics
         lib.realise_set_ln(2, fast)
+        rm.zero_(); rv.fill_(1.0)
         t_stats, t_apply, t_b1, t_b2 = timed(stats), timed(apply1), timed(lambda: bwd(False)), timed(lambda: bwd(True))
         # results on set 0 for the comparison
         it[0] = -1
+        rm.zero_(); rv.fill_(1.0)
         stats(); m0, q0 = mean.clone(), sq.clone()
         it[0] = -1
         dg.zero_(); db.zero_(); dg2.zero_(); db2.zero_()
         bwd(True)
         torch.cuda.synchronize()
         res[fast] = (m0, q0, sets[0]["dxa"].float().clone(), sets[0]["dxb"].float().clone(), dg.clone(), dg2.clone(), db.clone())
-        print("P %8d C %3d hw %3d %s | fast %d | stats (2 reads) %7.1f us %5.2f TB/s | apply (1r 1w) %7.1f us %5.2f TB/s | bwd single (6r 1w) %7.1f us %5.2f TB/s |"
+        print("P %8d C %3d hw %3d %s | fast %d | stats + finalize %7.1f us | apply (1r 1w) %7.1f us %5.2f TB/s | bwd single (6r 1w) %7.1f us %5.2f TB/s |"
               " bwd bn2+shortcut %7.1f us (generic: 12r 2w, fast: 8r 2w) %5.2f TB/s" %
-              (P, Cc, hw, "dedup" if dedup else "dense", fast, t_stats, 2 * mb / t_stats, t_apply, 2 * mb / t_apply, t_b1, 7 * mb / t_b1, t_b2,
+              (P, Cc, hw, "dedup" if dedup else "dense", fast, t_stats, t_apply, 2 * mb / t_apply, t_b1, 7 * mb / t_b1, t_b2,
                (10 if fast else 14) * mb / t_b2), flush=True)
     lib.realise_set_ln(2, 1)
     a, b = res[0], res[1]
-    names = ("mean", "sq", "dx_a", "dx_b", "dgamma_a", "dgamma_b", "dbeta")
+    names = ("mean", "rstd", "dx_a", "dx_b", "dgamma_a", "dgamma_b", "dbeta")
     for n, u, v in zip(names, a, b):
         d = (u - v).abs().max().item()
         ref = u.abs().max().item()
