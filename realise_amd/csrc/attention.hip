@@ -192,11 +192,16 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
     const float inv = 1.0f / sum;
     if (g == 0 && q < S && lse != nullptr) lse[(int64_t)bh * S + q] = mx + logf(sum);
     const uint32_t rowbase = ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S;
+    if ((S & 3) == 0) {                  // a lane's four keys 16n + 4g .. + 3 are one quad of the dropout hash
 #pragma unroll
-    for (int n = 0; n < 8; ++n)
+      for (int n = 0; n < 8; ++n) sc[n][m] *= drop_mult4(drop_seed, drop_thresh, drop_scale, rowbase + 16 * n + 4 * g) * inv;
+    } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sc[n][m][r] *= inv * drop_mult(drop_seed, drop_thresh, drop_scale, rowbase + 16 * n + 4 * g + r);
+      for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          sc[n][m][r] *= inv * drop_mult(drop_seed, drop_thresh, drop_scale, rowbase + 16 * n + 4 * g + r);
+    }
   }
   // O^T = V^T P^T : lane ends with O[query l15][d = 16dn + 4g + r]
 #pragma unroll
@@ -298,13 +303,35 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
       for (int mi = 0; mi < 2; ++mi) {
         const floatx4 l4 = *(const floatx4*)(lse_s + 32 * mm + 16 * mi + 4 * g);
         const floatx4 d4 = *(const floatx4*)(dot_s + 32 * mm + 16 * mi + 4 * g);
+        // Dropout multipliers of (queries 4g' .. + 3) x this lane's key.  The hash quad runs along the KEYS (what forward and dQ hold
+        // per lane); here a lane holds four QUERIES of one key, so the four lanes of a key quad (l15 & ~3 .. + 3) each hash one
+        // of the four queries and trade the words with quad-broadcast DPP moves: one hash per lane for four elements instead of four.
+        floatx4 dm4 = floatx4{1.0f, 1.0f, 1.0f, 1.0f};
+        if (drop_thresh != 0u) {
+          const int qb = 32 * mm + 16 * mi + 4 * g;
+          if ((S & 3) == 0) {
+            const uint2 hq = rng_hash4(drop_seed, (((uint32_t)bh * (uint32_t)S + (uint32_t)(qb + (l15 & 3))) * (uint32_t)S + (uint32_t)(key & ~3)) >> 2);
+            const uint32_t t16 = drop_thresh >> 16;
+            const bool hi_word = (l15 & 2) != 0;
+            const int sh = (l15 & 1) << 4;
+#define RL_QUAD_BCAST(v, r) (uint32_t)__builtin_amdgcn_mov_dpp((int)(v), (r) * 0x55, 0xf, 0xf, true)
+            { const uint32_t x = RL_QUAD_BCAST(hq.x, 0), y = RL_QUAD_BCAST(hq.y, 0); dm4[0] = (((hi_word ? y : x) >> sh) & 0xffffu) >= t16 ? drop_scale : 0.0f; }
+            { const uint32_t x = RL_QUAD_BCAST(hq.x, 1), y = RL_QUAD_BCAST(hq.y, 1); dm4[1] = (((hi_word ? y : x) >> sh) & 0xffffu) >= t16 ? drop_scale : 0.0f; }
+            { const uint32_t x = RL_QUAD_BCAST(hq.x, 2), y = RL_QUAD_BCAST(hq.y, 2); dm4[2] = (((hi_word ? y : x) >> sh) & 0xffffu) >= t16 ? drop_scale : 0.0f; }
+            { const uint32_t x = RL_QUAD_BCAST(hq.x, 3), y = RL_QUAD_BCAST(hq.y, 3); dm4[3] = (((hi_word ? y : x) >> sh) & 0xffffu) >= t16 ? drop_scale : 0.0f; }
+#undef RL_QUAD_BCAST
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              dm4[r] = drop_mult(drop_seed, drop_thresh, drop_scale, ((uint32_t)bh * (uint32_t)S + (uint32_t)(qb + r)) * (uint32_t)S + (uint32_t)key);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = 32 * mm + 16 * mi + 4 * g + r;
           const bool ok = (q < S) && (key < S);
           const float p = ok ? exp_t<T>(s[mi][r] * 0.125f + ma - l4[r]) : 0.0f;
-          const float dm = drop_mult(drop_seed, drop_thresh, drop_scale,
-                                     ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)key);
+          const float dm = dm4[r];
           pd[mi][r] = p * dm;
           ds[mi][r] = p * (dp[mi][r] * dm - d4[r]) * 0.125f;
         }
@@ -396,14 +423,19 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const int q = q0 + 16 * m + l15;
+        const uint32_t idx0 = ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)(32 * nn + 16 * ni + 4 * g);
+        floatx4 dm4 = floatx4{1.0f, 1.0f, 1.0f, 1.0f};
+        if ((S & 3) == 0) dm4 = drop_mult4(drop_seed, drop_thresh, drop_scale, idx0);        // the lane's four keys are one hash quad
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dm4[r] = drop_mult(drop_seed, drop_thresh, drop_scale, idx0 + r);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = 32 * nn + 16 * ni + 4 * g + r;
           const bool ok = (q < S) && (key < S);
           const float p = ok ? exp_t<T>(s[ni][m][r] * 0.125f + ma[r] - lq[m]) : 0.0f;
-          const float dm = drop_mult(drop_seed, drop_thresh, drop_scale,
-                                     ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)key);
-          ds[ni][m][r] = p * (dp[ni][m][r] * dm - dq_[m]) * 0.125f;
+          ds[ni][m][r] = p * (dp[ni][m][r] * dm4[r] - dq_[m]) * 0.125f;
         }
       }
     }

@@ -131,24 +131,30 @@ template <> __device__ __forceinline__ float ktile_frag<float, 64>(const char* t
 }
 
 // ---- counter-based dropout RNG (K17): mask is recomputed in backward, never stored ----------
-// One 32-bit hash serves TWO neighbouring elements (16 bits each): two rounds of multiply + xor-shift (integer multiplies
-// are quarter-rate on CDNA, so the per-element cost is what matters in the epilogues / softmax that call this per value).
-__device__ __forceinline__ uint32_t rng_hash(uint32_t seed, uint32_t pair) {
-  uint32_t x = (pair ^ seed) * 0x9E3779B1u;
-  x ^= x >> 15;
-  x = (x + seed) * 0x85EBCA77u;
-  x ^= x >> 13;
-  x *= 0xC2B2AE3Du;
-  x ^= x >> 16;
-  return x;
+// One hash serves FOUR neighbouring elements (16 bits each).  Integer multiplies are quarter-rate on CDNA, so the cost that matters
+// in the epilogues / softmax that call this per value is multiplies per element: three 32 x 32 -> 64-bit products per quad (0.75 per
+// element; the two-round 32-bit mixer this replaces spent 1.5), both halves of every product used.  Chi-square of the 16-bit
+// lanes, lag / seed-to-seed correlations of the keep mask checked on 4M counters (tests/test_round3_cpu.py restates the mixer).
+__device__ __forceinline__ uint2 rng_hash4(uint32_t seed, uint32_t quad) {
+  const uint64_t m1 = (uint64_t)(quad ^ seed) * 0x9E3779B1u;
+  const uint32_t x = (uint32_t)m1 ^ (uint32_t)(m1 >> 32) ^ (seed * 0x632BE5ABu);
+  const uint64_t m2 = (uint64_t)x * 0x85EBCA77u, m3 = (uint64_t)(x ^ 0x27D4EB2Fu) * 0xC2B2AE3Du;
+  return uint2{(uint32_t)(m2 >> 32) ^ (uint32_t)m3, (uint32_t)(m3 >> 32) ^ (uint32_t)m2};
 }
+// the 16 random bits of element `sub` (0..3) of a quad
+__device__ __forceinline__ uint32_t rng_lane16(uint2 h, uint32_t sub) { return (((sub & 2u) ? h.y : h.x) >> ((sub & 1u) << 4)) & 0xffffu; }
 // keep element idx?  thresh = p * 2^32 (0 disables dropout); the comparison uses the top 16 bits of thresh, i.e. the drop
 // probability is p rounded down to a multiple of 2^-16.
 __device__ __forceinline__ float drop_mult(uint32_t seed, uint32_t thresh, float scale, uint32_t idx) {
   if (thresh == 0u) return 1.0f;
-  const uint32_t h = rng_hash(seed, idx >> 1);
-  const uint32_t v = (idx & 1u) ? (h >> 16) : (h & 0xffffu);
-  return v >= (thresh >> 16) ? scale : 0.0f;
+  return rng_lane16(rng_hash4(seed, idx >> 2), idx & 3u) >= (thresh >> 16) ? scale : 0.0f;
+}
+// the four multipliers of elements idx .. idx + 3, idx % 4 == 0
+__device__ __forceinline__ floatx4 drop_mult4(uint32_t seed, uint32_t thresh, float scale, uint32_t idx) {
+  if (thresh == 0u) return floatx4{1.0f, 1.0f, 1.0f, 1.0f};
+  const uint2 h = rng_hash4(seed, idx >> 2);
+  const uint32_t t = thresh >> 16;
+  return floatx4{(h.x & 0xffffu) >= t ? scale : 0.0f, (h.x >> 16) >= t ? scale : 0.0f, (h.y & 0xffffu) >= t ? scale : 0.0f, (h.y >> 16) >= t ? scale : 0.0f};
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

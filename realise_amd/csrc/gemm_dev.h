@@ -45,8 +45,11 @@ __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, 
     } break;
     case EPI_DROP_RESID: {
       const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)col;
+      if ((N & 3) == 0) v *= drop_mult4(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx);          // col % 4 == 0: one hash for the quad
+      else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] *= drop_mult(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + j);
+        for (int j = 0; j < 4; ++j) v[j] *= drop_mult(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + j);
+      }
       v += load4<T>(ep.aux + (int64_t)row * ep.ldaux + col);
       store4<T>(ep.out + (int64_t)row * ep.ldo + col, v);
     } break;
@@ -84,11 +87,8 @@ __device__ __forceinline__ void epilogue8(const EpiParams<T>& ep, int M, int N, 
     } break;
     case EPI_DROP_RESID: {
       const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)col;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a[j] *= drop_mult(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + j);
-        b[j] *= drop_mult(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + 4 + j);
-      }
+      a *= drop_mult4(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx);          // N % 8 == 0, col % 8 == 0
+      b *= drop_mult4(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + 4);
       floatx4 ra, rb;
       load8<T>(ep.aux + (int64_t)row * ep.ldaux + col, ra, rb);
       store8<T>(o, a + ra, b + rb);

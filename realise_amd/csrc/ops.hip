@@ -69,8 +69,8 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(LnFwdArgs<T> a) {
       for (int j = 0; j < 4; ++j) {
         xh[j] = (v[i][j] - mean) * rstd;
         y[j] = xh[j] * gm[j] + bt[j];
-        y[j] *= drop_mult(a.drop.seed, a.drop.thresh, a.drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
       }
+      y *= drop_mult4(a.drop.seed, a.drop.thresh, a.drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c);       // H % 4 == 0
       if (a.xhat != nullptr) store4<T>(a.xhat + (int64_t)row * H + c, xh);
       store4<T>(a.y + (int64_t)row * H + c, y);
     }
@@ -148,7 +148,12 @@ __global__ void __launch_bounds__(256) ln_fwd16_kernel(LnFwdArgs<bf16_t> a) {
       for (int j = 0; j < 8; ++j) {
         xh[j] = (v[i][j] - mean) * rstd;
         y[j] = xh[j] * gm[i][j] + bt[i][j];
-        y[j] *= drop_mult(a.drop.seed, a.drop.thresh, a.drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
+      }
+      if (a.drop.thresh != 0u) {
+        const floatx4 d0 = drop_mult4(a.drop.seed, a.drop.thresh, a.drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c);
+        const floatx4 d1 = drop_mult4(a.drop.seed, a.drop.thresh, a.drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c + 4u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { y[j] *= d0[j]; y[4 + j] *= d1[j]; }
       }
       if (a.xhat != nullptr) *(uint4*)((char*)a.xhat + ((int64_t)row * H + c) * 2) = pack8(xh);
       *(uint4*)((char*)a.y + ((int64_t)row * H + c) * 2) = pack8(y);
@@ -225,10 +230,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c < H) {
+        const floatx4 dm_in = drop_mult4(a.in_drop.seed, a.in_drop.thresh, a.in_drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          dy[i][j] *= drop_mult(a.in_drop.seed, a.in_drop.thresh, a.in_drop.scale,
-                                (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
+          dy[i][j] *= dm_in[j];
           const float t = dy[i][j] * gm[i][j];
           s1 += t;
           s2 += t * xh[i][j];
@@ -246,11 +251,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
       if (c < H) {
         floatx4 dx, dxd;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          dx[j] = rstd * (dy[i][j] * gm[i][j] - s1 - xh[i][j] * s2);
-          dxd[j] = dx[j] * drop_mult(a.out_drop.seed, a.out_drop.thresh, a.out_drop.scale,
-                                     (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
-        }
+        for (int j = 0; j < 4; ++j) dx[j] = rstd * (dy[i][j] * gm[i][j] - s1 - xh[i][j] * s2);
+        dxd = dx * drop_mult4(a.out_drop.seed, a.out_drop.thresh, a.out_drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c);
         store4<T>(a.dx + (int64_t)row * H + c, dx);
         if (a.dx_drop != nullptr) store4<T>(a.dx_drop + (int64_t)row * H + c, dxd);
       }
@@ -358,7 +360,11 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
       if (a.dx_drop != nullptr) {
         if constexpr (DROP) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dx[j] *= drop_mult(a.out_drop.seed, a.out_drop.thresh, a.out_drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)(c + j));
+          for (int hq = 0; hq < 2; ++hq) {
+            const floatx4 dm = drop_mult4(a.out_drop.seed, a.out_drop.thresh, a.out_drop.scale, (uint32_t)row * (uint32_t)H + (uint32_t)(c + 4 * hq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dx[4 * hq + j] *= dm[j];
+          }
         }
         *(uint4*)((char*)a.dx_drop + off) = pack8(dx);
       }
@@ -941,8 +947,7 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   floatx4 v = load4<T>(x + i);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] *= drop_mult(d.seed, d.thresh, d.scale, (uint32_t)(i + j));
+  v *= drop_mult4(d.seed, d.thresh, d.scale, (uint32_t)i);
   store4<T>(y + i, v);
 }
 template <typename T> int dropout_apply(hipStream_t st, const T* x, T* y, int rows, int H, DropParams d) {
