@@ -45,7 +45,7 @@ RESNET_FLOPS_PER_STACK = 126418944      # CharResNet forward on one 3 x 32 x 32 
 # HIP-event pairs around every launch of the MFMA kernel families cost ~4 us of stream time each (~8 % of a step when every
 # step is bracketed): the timed region brackets every 10th step, which leaves the averages intact and the cost below 1 %.
 PROFILE_EVERY = 10
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "round2_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "round3_pmc_traffic.json")
 
 
 def fwd_flops_per_sentence(S, mean_len, resnet_frac=1.0):
@@ -420,9 +420,10 @@ def main():
                 fams[name]["rows_live_frac"] = live
         if "gemm_nt" in fams:
             f = fams["gemm_nt"]
-            traffic, tnote = pmc_traffic_per_launch(["gemm_nt8_kernel", "gemm_nt_kernel<bf16_t, DenseLoader<bf16_t>", "gemm_nt_pp_kernel"])
+            traffic, tnote = pmc_traffic_per_launch(["gemm_nt8_kernel", "gemm_nt8p_kernel", "gemm_nt_kernel<bf16_t, DenseLoader<bf16_t>"])
             out["roofline"] = {"bound": "mfma",
-                               "kernel": "dense NT GEMM family: gemm_nt8_kernel<256x192 | 128x192 | 256x256> (ping-pong 8-wave) + "
+                               "kernel": "dense NT GEMM family: gemm_nt8p_kernel<256x192> (persistent 8-wave ping-pong: qkv, FFN-up, FFN-down "
+                                         "dgrad, classifier) + gemm_nt8_kernel<128x192, two per CU> (N = 768 outputs) + "
                                          "gemm_nt_kernel<bf16, DenseLoader> (GRU steps), v_mfma_f32_16x16x32_bf16",
                                "achieved": round(f["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(f["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tnote,

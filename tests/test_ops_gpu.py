@@ -115,7 +115,11 @@ def test_batchnorm_engine_form_with_glyph_multiplicities(mode):
     bf = torch.bfloat16
     xa = (torch.randn(P, Cc, generator=g) * 1.5 + torch.linspace(-3, 3, Cc)).to(bf)
     xb = (torch.randn(P, Cc, generator=g) * 0.7 + 0.5).to(bf)
-    dy = torch.randn(P, Cc, generator=g).to(bf)
+    # the incoming gradient has a per-channel mean and a component along each normalised input, so that both subtracted terms of
+    # the backward (w sum(g) / n and xhat w sum(g xhat) / n) are as large as g itself
+    xha = (xa.float() - xa.float().mean(0)) / xa.float().std(0)
+    xhb = (xb.float() - xb.float().mean(0)) / xb.float().std(0)
+    dy = (torch.randn(P, Cc, generator=g) * 0.5 + torch.linspace(-1, 1, Cc) + 0.6 * xha - 0.4 * xhb).to(bf)
     o = torch.randn(P, Cc, generator=g).to(bf)                              # the block output: the ReLU mask is o > 0
     gamma_a, gamma_b = torch.rand(Cc, generator=g) + 0.5, torch.rand(Cc, generator=g) + 0.5
     beta = torch.randn(Cc, generator=g) * 0.2

@@ -27,5 +27,5 @@ for k, n, rd, wr, m in rows[:40]:
     f = lambda c: (100.0 * m.get(c, 0.0) / m['SQ_WAVE_CYCLES']) if m.get('SQ_WAVE_CYCLES') else 0.0
     print("| `%s` | %d | %.2f | %.2f | %.1f | %.1f | %.1f | %.1f | %.0f |" % (k[:90], n, rd / 1e6, wr / 1e6, mf, f('SQ_WAIT_ANY'), f('SQ_WAIT_INST_ANY'), f('SQ_ACTIVE_INST_ANY'), m.get('SQ_LDS_BANK_CONFLICT', 0.0)))
     out[k] = {"launches": n, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr}
-json.dump({"kernels_sha": kernels_sha(), "command": "rocprofv3 --pmc <set> --kernel-trace -- python bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-profile (one pass per counter set)",
+json.dump({"kernels_sha": kernels_sha(), "command": "rocprofv3 --pmc <set> --kernel-trace -- python bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-forward --no-glyph256 (one pass per counter set)",
            "units": "bytes per launch; FETCH_SIZE KiB x 2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE KiB", "kernels": out}, open(root + '/traffic.json', 'w'), indent=1)
