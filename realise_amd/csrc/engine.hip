@@ -47,6 +47,8 @@ void set_fwd_order(int o) { g_fwd_order = o; }
 // Priority classes of the engine-owned streams, applied when a stream is created (realise_set_engine keys 1..3, before the first
 // forward): 0 = the device default, -1 = the highest priority the device offers, +1 = the lowest.  [0] pinyin branch, [1] glyph
 // branch, [2] weight-gradient side stream.
+static int g_cls_compact = 1;     // classifier backward over the rows that enter the loss only (realise_set_engine key 4)
+void set_cls_compact(int on) { g_cls_compact = on; }
 static int g_stream_pri[3] = {0, 0, 0};
 void set_stream_priority(int which, int pri) { if (which >= 0 && which < 3) g_stream_pri[which] = pri < 0 ? -1 : (pri > 0 ? 1 : 0); }
 static hipError_t create_stream(hipStream_t* s, int which) {
@@ -107,6 +109,7 @@ template <typename T> struct Engine : EngineBase {
     StackAct bert, pho, outb;
     BlockAct blk[5];
     int64_t mask_add, out_d, dlogits, count, loss_internal;
+    int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc;     // classifier backward over the rows that enter the loss only (stage_head)
     int64_t ids_clean = 0, pho_clean = 0;                 // range-checked copies of src_idx / pho_idx (sanitize_ids)
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
     int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
@@ -184,6 +187,7 @@ template <typename T> struct Engine : EngineBase {
   }
   const int32_t* alive_dev = nullptr;      // device-side n_alive[Tp] of the last batch (nullptr: host counts)
   bool have_fwd = false;
+  bool cls_compact = false;                // the last forward wrote compacted classifier-gradient rows (stage_head must match)
 
   template <typename U> U* wp(int64_t off) const { return (U*)(ws + off); }
   template <typename U> U* sp(int64_t off) const { return (U*)(sh + off); }
@@ -362,9 +366,13 @@ template <typename T> struct Engine : EngineBase {
       p.out_d = b.take(Tk * H * e);
       p.dlogits = b.take(Tk * Vp * e);
       tap("dlogits", p.dlogits, Tk * Vp);
+      p.zero_once.push_back({p.dlogits, Tk * Vp * e});      // compacted gradient rows: the rows beyond the live count hold old (finite) values
     }
     p.count = b.take(256);
     p.loss_internal = b.take(Tk * 4 + 256);       // per-row loss terms (ordered fold: reproducible loss)
+    p.cls_act = b.take(Tk * 4); p.cls_inv = b.take(Tk * 4); p.cls_nact = b.take(256);
+    p.cls_xc = b.take(Tk * H * e); p.cls_gc = b.take(Tk * H * e);
+    p.zero_once.push_back({p.cls_xc, Tk * H * e}); p.zero_once.push_back({p.cls_gc, Tk * H * e});
     // shared backward scratch
     p.gA = b.take(Tk * H * e); p.gB = b.take(Tk * H * e); p.gC = b.take(Tk * H * e); p.gE = b.take(Tk * H * e);
     const int64_t Tw = glyph_only ? 1 : Tk;               // the wide BERT scratch is not needed by the glyph-only plan
@@ -983,8 +991,15 @@ template <typename T> struct Engine : EngineBase {
     }
     if (b.tgt_idx != nullptr) {
       if (!b.loss_masks || !b.loss_out) return RL_ERR_ARG;
+      // Backward of the classifier over the rows that enter the loss only (loss_masks: no [CLS] / [SEP] / padding - 60 % of the
+      // rows of a SIGHAN-shaped batch): the gradient rows are written compacted, the classifier input is gathered to match; the
+      // other rows' gradients are exact zeros in the dense form, so the weight / bias / data gradients are the same sums.
+      cls_compact = g_cls_compact && b.want_dlogits && Tk <= 65536;
+      CeCompact cc;
+      if (cls_compact) { cc.act_idx = wp<int>(pl.cls_act); cc.inv = wp<int>(pl.cls_inv); cc.n_act = wp<int>(pl.cls_nact); }
       RL_TRY(ce_loss<T>(st, (const T*)b.logits_out, V, b.tgt_idx, b.loss_masks, Tk, V, b.loss_out, wp<float>(pl.count),
-                        b.want_dlogits ? wp<T>(pl.dlogits) : nullptr, wp<float>(pl.loss_internal), Vp));
+                        b.want_dlogits ? wp<T>(pl.dlogits) : nullptr, wp<float>(pl.loss_internal), Vp, cc));
+      if (cls_compact) RL_TRY(gather_rows<T>(st, cls_in, wp<int>(pl.cls_act), wp<int>(pl.cls_nact), Tk, H, wp<T>(pl.cls_xc)));
     }
     have_fwd = b.training && b.tgt_idx != nullptr && b.want_dlogits;
     return RL_OK;
@@ -1073,6 +1088,14 @@ template <typename T> struct Engine : EngineBase {
     const DropParams dfin = site(5000, cfg.hidden_dropout);
     const T* top = cfg.model_type == 1 ? wp<T>(pl.outb.layers.back().y2) : wp<T>(pl.bert.layers.back().y2);
     const T* cls_in = dfin.thresh ? wp<T>(pl.out_d) : top;
+    if (cls_compact) {
+      const int* n_act = wp<int>(pl.cls_nact);
+      { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(L.cls_b); te.out = gp(L.cls_w); te.ldo = H;
+        RL_TRY(gemm_tn<T>(st, dl, Vp, wp<T>(pl.cls_xc), H, Tk, V, H, te, n_act)); }
+      { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = wp<T>(pl.cls_gc); ep.ldo = H; ep.m_dev = n_act;
+        RL_TRY(gemm_nt<T>(st, dl, Vp, sp<T>(sh_cls_wT), Vp, Tk, H, Vp, ep)); }
+      return scatter_rows_drop<T>(st, wp<T>(pl.cls_gc), wp<int>(pl.cls_inv), Tk, H, gA, dfin);      // rows outside the loss: zero; + the final dropout's map
+    }
     { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(L.cls_b); te.out = gp(L.cls_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dl, Vp, cls_in, H, Tk, V, H, te)); }
     { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H;
       RL_TRY(gemm_nt<T>(st, dl, Vp, sp<T>(sh_cls_wT), Vp, Tk, H, Vp, ep)); }      // K = Vp: the padding columns are exact zeros on both sides

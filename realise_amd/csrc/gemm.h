@@ -29,6 +29,10 @@ template <typename T> struct EpiParams {
   int rm_hw_shift = -1, rm_w_shift = 0, rm_par = 0;
   int wide = 0;                 // set by the launcher: rows are 8-element aligned -> LDS-staged epilogue, 16 B per lane
   int probe = 0;                // diagnostics (tools/nt_probe.cpp): 1 all tiles fetch tile 0, 2 no fetches, 3 no MFMA
+  // optional device-side count of the rows that matter (the 8-wave kernel skips tiles that start at or beyond it; rows of a partly
+  // live tile beyond the count are still computed and stored: for outputs whose dead rows nobody reads - the compacted classifier
+  // data gradient, engine.hip stage_head)
+  const int* m_dev = nullptr;
 };
 
 // ---- operand loaders ---------------------------------------------------------------------------

@@ -66,6 +66,7 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
   int tm, tn;
   tile_coords(tile, tiles_n, ntiles, group_m, tm, tn);
   const int m0 = tm * C::BM, n0 = tn * C::BN;
+  if (ep.m_dev != nullptr && m0 >= *ep.m_dev) return;      // device-side live-row count: the whole workgroup leaves before any barrier
   const int nk = (K + 63) >> 6;
   const int ktail = KTAIL ? (K & 63) : 0;   // elements of a ragged last K-tile (multiple of 8); KTAIL = false: K % 64 == 0
 

@@ -91,9 +91,16 @@ template <typename T> int dropout_apply(hipStream_t st, const T* x, T* y, int ro
 // = d loss / d logits.  count_buf: 1 float scratch.  Rows whose label is -100 (CrossEntropyLoss's ignore_index) are skipped in
 // the mean; any other label outside [0, V) turns the loss into NaN.  row_loss (optional, `rows` floats): per-row terms folded in
 // a fixed order - the loss is then bitwise reproducible; nullptr: one float atomicAdd per row.
+// cc.act_idx != nullptr (needs row_loss): COMPACTED gradient rows - dlogits row j belongs to the j-th row that enters the loss
+// (cc.act_idx[j] = its token row, cc.inv[row] = j or -1, *cc.n_act = how many; all written here); rows outside the loss are neither
+// visited nor written.  The classifier's data / weight gradients then run over *n_act rows instead of all of them.
+struct CeCompact { int* act_idx = nullptr; int* inv = nullptr; int* n_act = nullptr; };
 template <typename T>
 int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask, int rows, int V,
-            float* loss_out, float* count_buf, T* dlogits, float* row_loss = nullptr, int64_t ld_dl = 0);   // ld_dl: row pitch of dlogits (0: ld)
+            float* loss_out, float* count_buf, T* dlogits, float* row_loss = nullptr, int64_t ld_dl = 0, const CeCompact& cc = CeCompact());
+// out[j] = in[idx[j]], j < *n_dev (rows of H elements); out[row] = inv[row] >= 0 ? in[inv[row]] * dropout mask : 0
+template <typename T> int gather_rows(hipStream_t st, const T* in, const int* idx, const int* n_dev, int max_rows, int H, T* out);
+template <typename T> int scatter_rows_drop(hipStream_t st, const T* in, const int* inv, int rows, int H, T* out, DropParams d);   // ld_dl: row pitch of dlogits (0: ld)
 
 // ---- eval decode (run.py:262-263): ids[row] = argmax_v logits[row][v], first maximum wins (numpy / torch semantics), a NaN
 // counts as the maximum.  Only the ids leave the device (32 KB instead of the 692 MB fp32 logits of run.py:262).

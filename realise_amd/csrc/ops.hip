@@ -983,14 +983,48 @@ __device__ __forceinline__ float block_reduce(float v, float* sm, bool is_max) {
   return r;
 }
 
+// Rows that enter the loss, in order: act_idx[j] = token row of the j-th active row, inv[row] = j (or -1), *n_act and *count = how
+// many, row_loss[row] = 0 for the others.  One workgroup of 1024 threads (rows <= 65536), ballot + wave-prefix scan: deterministic.
+__global__ void __launch_bounds__(1024) active_rows_kernel(const int64_t* __restrict__ m, const int64_t* __restrict__ labels, int n,
+                                                            int* __restrict__ act_idx, int* __restrict__ inv, int* __restrict__ n_act,
+                                                            float* __restrict__ count, float* __restrict__ row_loss) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base_s = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < n; r0 += 1024) {
+    const int r = r0 + threadIdx.x;
+    const bool a = r < n && m[r] == 1 && labels[r] != RL_CE_IGNORE_INDEX;
+    const unsigned long long b = __ballot(a);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wave] = __popcll(b);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (r < n) {
+      if (a) { act_idx[off + before] = r; inv[r] = off + before; }
+      else { inv[r] = -1; if (row_loss != nullptr) row_loss[r] = 0.f; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = base_s; for (int w = 0; w < 16; ++w) t += wsum[w]; base_s = t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *n_act = base_s; *count = (float)base_s; }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels, const int64_t* __restrict__ loss_mask,
-          int V, float* loss_out, const float* __restrict__ count, T* __restrict__ dlogits, float* __restrict__ row_loss, int64_t ld_dl) {
+          int V, float* loss_out, const float* __restrict__ count, T* __restrict__ dlogits, float* __restrict__ row_loss, int64_t ld_dl,
+          const int* __restrict__ act_idx, const int* __restrict__ n_act) {
   __shared__ float sm[4];
-  const int row = blockIdx.x;
+  // compacted form (act_idx != nullptr): workgroup j works on the j-th ACTIVE row and writes gradient row j; the rows outside the loss
+  // are not visited at all (their loss terms were zeroed by active_rows_kernel, their gradient rows do not exist)
+  if (act_idx != nullptr && (int)blockIdx.x >= *n_act) return;
+  const int row = act_idx != nullptr ? act_idx[blockIdx.x] : (int)blockIdx.x;
   const T* x = logits + (int64_t)row * ld;
-  T* dx = dlogits ? dlogits + (int64_t)row * ld_dl : nullptr;
+  T* dx = dlogits ? dlogits + (int64_t)(act_idx != nullptr ? (int)blockIdx.x : row) * ld_dl : nullptr;
   // a padded gradient row (ld_dl > V: 128-byte aligned rows for the GEMMs that consume it) keeps exact zeros in its tail
   if (dx != nullptr)
     for (int c = V + threadIdx.x * 4; c < ld_dl; c += 1024) store4<T>(dx + c, floatx4{0.f, 0.f, 0.f, 0.f});
@@ -1050,18 +1084,61 @@ __global__ void __launch_bounds__(256) ce_fold_kernel(const float* __restrict__ 
 }
 template <typename T>
 int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask, int rows, int V,
-            float* loss_out, float* count_buf, T* dlogits, float* row_loss, int64_t ld_dl) {
+            float* loss_out, float* count_buf, T* dlogits, float* row_loss, int64_t ld_dl, const CeCompact& cc) {
   if (ld_dl <= 0) ld_dl = ld;
   if ((V & 3) || (ld & 3) || (ld_dl & 3) || ld_dl < V) return RL_ERR_ARG;
+  if (cc.act_idx != nullptr) {       // compacted gradient rows (needs the per-row loss terms: the ordered fold is the only sum)
+    if (row_loss == nullptr || cc.inv == nullptr || cc.n_act == nullptr || rows > 65536) return RL_ERR_ARG;
+    hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(1024), 0, st, loss_mask, labels, rows, cc.act_idx, cc.inv, cc.n_act, count_buf, row_loss);
+    hipLaunchKernelGGL((ce_kernel<T>), dim3(rows), dim3(256), 0, st, logits, ld, labels, loss_mask, V, loss_out, count_buf, dlogits, row_loss, ld_dl,
+                       (const int*)cc.act_idx, (const int*)cc.n_act);
+    hipLaunchKernelGGL(ce_fold_kernel, dim3(1), dim3(256), 0, st, row_loss, rows, loss_out);
+    return RL_LAUNCH_CHECK();
+  }
   (void)hipMemsetAsync(loss_out, 0, sizeof(float), st);
   (void)hipMemsetAsync(count_buf, 0, sizeof(float), st);
   hipLaunchKernelGGL(count_active_kernel, dim3(64), dim3(256), 0, st, loss_mask, labels, rows, count_buf);
-  hipLaunchKernelGGL((ce_kernel<T>), dim3(rows), dim3(256), 0, st, logits, ld, labels, loss_mask, V, loss_out, count_buf, dlogits, row_loss, ld_dl);
+  hipLaunchKernelGGL((ce_kernel<T>), dim3(rows), dim3(256), 0, st, logits, ld, labels, loss_mask, V, loss_out, count_buf, dlogits, row_loss, ld_dl,
+                     (const int*)nullptr, (const int*)nullptr);
   if (row_loss != nullptr) hipLaunchKernelGGL(ce_fold_kernel, dim3(1), dim3(256), 0, st, row_loss, rows, loss_out);
   return RL_LAUNCH_CHECK();
 }
-template int ce_loss<bf16_t>(hipStream_t, const bf16_t*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, bf16_t*, float*, int64_t);
-template int ce_loss<float>(hipStream_t, const float*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, float*, float*, int64_t);
+template int ce_loss<bf16_t>(hipStream_t, const bf16_t*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, bf16_t*, float*, int64_t, const CeCompact&);
+template int ce_loss<float>(hipStream_t, const float*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, float*, float*, int64_t, const CeCompact&);
+
+// out[j] = in[idx[j]] for j < *n (rows of H elements, 16 bytes per lane)
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ in, const int* __restrict__ idx, const int* __restrict__ n, int H, T* __restrict__ out) {
+  const int j = blockIdx.x;
+  if (j >= *n) return;
+  const uint4* src = (const uint4*)(in + (int64_t)idx[j] * H);
+  uint4* dst = (uint4*)(out + (int64_t)j * H);
+  for (int c = threadIdx.x; c < H * (int)sizeof(T) / 16; c += blockDim.x) dst[c] = src[c];
+}
+template <typename T> int gather_rows(hipStream_t st, const T* in, const int* idx, const int* n_dev, int max_rows, int H, T* out) {
+  if ((H * (int)sizeof(T)) & 15) return RL_ERR_ARG;
+  hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(max_rows), dim3(96), 0, st, in, idx, n_dev, H, out);
+  return RL_LAUNCH_CHECK();
+}
+template int gather_rows<bf16_t>(hipStream_t, const bf16_t*, const int*, const int*, int, int, bf16_t*);
+template int gather_rows<float>(hipStream_t, const float*, const int*, const int*, int, int, float*);
+// out[row] = inv[row] >= 0 ? in[inv[row]] * dropout(row, c) : 0   (the inverse of the gather, fused with the dropout map of the site)
+template <typename T>
+__global__ void scatter_rows_drop_kernel(const T* __restrict__ in, const int* __restrict__ inv, int H, T* __restrict__ out, DropParams d) {
+  const int row = blockIdx.x, j = inv[row];
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+    floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (j >= 0) v = load4<T>(in + (int64_t)j * H + c) * drop_mult4(d.seed, d.thresh, d.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c);
+    store4<T>(out + (int64_t)row * H + c, v);
+  }
+}
+template <typename T> int scatter_rows_drop(hipStream_t st, const T* in, const int* inv, int rows, int H, T* out, DropParams d) {
+  if (H & 3) return RL_ERR_ARG;
+  hipLaunchKernelGGL((scatter_rows_drop_kernel<T>), dim3(rows), dim3(192), 0, st, in, inv, H, out, d);
+  return RL_LAUNCH_CHECK();
+}
+template int scatter_rows_drop<bf16_t>(hipStream_t, const bf16_t*, const int*, int, int, bf16_t*, DropParams);
+template int scatter_rows_drop<float>(hipStream_t, const float*, const int*, int, int, float*, DropParams);
 
 // ---------------------------------------------------------------------------------------------
 // Gate fusion (models.py:840-850).  The [T, 4H] concat is never materialised.
