@@ -23,7 +23,8 @@ void realise_set_nt_variant(int v);
 /* step engine: key 0 = enqueue order of the three forward branches (0: bert stack first, 1: the shorter pinyin / glyph branches first);
  * keys 1 / 2 / 3 = priority class of the pinyin-branch / glyph-branch / weight-gradient stream (-1 highest, 0 device default, +1 lowest),
  * read when the engine creates the stream, i.e. to be set before the first forward; key 4 = classifier backward over the rows that
- * enter the loss only (1, default) or over all rows (0) */
+ * enter the loss only (1, default) or over all rows (0); key 5 = the backward skips the rows of padding tokens, whose gradient rows are
+ * exact zeros (LayerNorm backward rows, 64-row tiles of the weight-gradient reductions; 1 default, 0 off) */
 void realise_set_engine(int key, int value);
 /* LayerNorm backward exactly as the engine calls it (bf16): optional second output dx_drop = dx * dropout mask, per-workgroup
  * [dgamma | dbeta] records in `slots` (8 MiB scratch) folded in a fixed order.  tools/ln_probe.py times it. */

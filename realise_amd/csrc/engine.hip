@@ -47,6 +47,8 @@ void set_fwd_order(int o) { g_fwd_order = o; }
 // Priority classes of the engine-owned streams, applied when a stream is created (realise_set_engine keys 1..3, before the first
 // forward): 0 = the device default, -1 = the highest priority the device offers, +1 = the lowest.  [0] pinyin branch, [1] glyph
 // branch, [2] weight-gradient side stream.
+static int g_skip_dead = 1;       // backward skips the rows of padding tokens: LayerNorm backward rows, 64-row tiles of the weight-gradient reductions (key 5)
+void set_skip_dead(int on) { g_skip_dead = on; }
 static int g_cls_compact = 1;     // classifier backward over the rows that enter the loss only (realise_set_engine key 4)
 void set_cls_compact(int on) { g_cls_compact = on; }
 static int g_stream_pri[3] = {0, 0, 0};
@@ -109,7 +111,8 @@ template <typename T> struct Engine : EngineBase {
     StackAct bert, pho, outb;
     BlockAct blk[5];
     int64_t mask_add, out_d, dlogits, count, loss_internal;
-    int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc;     // classifier backward over the rows that enter the loss only (stage_head)
+    int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc;
+    int64_t row_live, live_t64, live_t32, live_n;          // padding rows: exact-zero gradient rows the backward skips (row_liveness)     // classifier backward over the rows that enter the loss only (stage_head)
     int64_t ids_clean = 0, pho_clean = 0;                 // range-checked copies of src_idx / pho_idx (sanitize_ids)
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
     int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
@@ -187,6 +190,10 @@ template <typename T> struct Engine : EngineBase {
   }
   const int32_t* alive_dev = nullptr;      // device-side n_alive[Tp] of the last batch (nullptr: host counts)
   bool have_fwd = false;
+  bool dead_ok = false;                    // the last forward produced the row-liveness tables (training batch, B * S % 64 == 0)
+  const uint8_t* live_rows() const { return dead_ok ? wp<uint8_t>(pl.row_live) : nullptr; }
+  const int* live_tiles() const { return dead_ok ? wp<int>(sizeof(T) == 2 ? pl.live_t64 : pl.live_t32) : nullptr; }
+  const int* live_tile_count() const { return dead_ok ? wp<int>(pl.live_n) + (sizeof(T) == 2 ? 0 : 1) : nullptr; }
   bool cls_compact = false;                // the last forward wrote compacted classifier-gradient rows (stage_head must match)
 
   template <typename U> U* wp(int64_t off) const { return (U*)(ws + off); }
@@ -371,6 +378,7 @@ template <typename T> struct Engine : EngineBase {
     p.count = b.take(256);
     p.loss_internal = b.take(Tk * 4 + 256);       // per-row loss terms (ordered fold: reproducible loss)
     p.cls_act = b.take(Tk * 4); p.cls_inv = b.take(Tk * 4); p.cls_nact = b.take(256);
+    p.row_live = b.take(Tk + 64); p.live_t64 = b.take((Tk / 32 + 2) * 4); p.live_t32 = b.take((Tk / 32 + 2) * 4); p.live_n = b.take(256);
     p.cls_xc = b.take(Tk * H * e); p.cls_gc = b.take(Tk * H * e);
     p.zero_once.push_back({p.cls_xc, Tk * H * e}); p.zero_once.push_back({p.cls_gc, Tk * H * e});
     // shared backward scratch
@@ -619,7 +627,7 @@ template <typename T> struct Engine : EngineBase {
       };
       const bool keep_dy = ov || grouped;      // the dense-output gradients must outlive the in-place updates of gA / gB
       {  // output LayerNorm: gA = d y2 -> gB = d s2 (residual part of d y1), gC1 = d(dense out) = d s2 * dropmask
-        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
+        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gA; ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2); ln.row_live = live_rows();
         ln.gamma = pp(o.out_ln_g); ln.dx = gB; ln.dx_drop = (d3.thresh || keep_dy) ? gC1 : nullptr; ln.out_drop = d3;
         ln.dgamma = gp(o.out_ln_g); ln.dbeta = gp(o.out_ln_b);
         RL_TRY(ln_bwd_deferred(st, ln));
@@ -636,7 +644,7 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(gemm_nt<T>(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
       }
       {  // attention-output LayerNorm: gB = d y1 -> gA = d s1, gC2 = d(dense out)
-        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
+        LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1); ln.row_live = live_rows();
         ln.gamma = pp(o.ao_ln_g); ln.dx = gA; ln.dx_drop = (d2.thresh || keep_dy) ? gC2 : nullptr; ln.out_drop = d2;
         ln.dgamma = gp(o.ao_ln_g); ln.dbeta = gp(o.ao_ln_b);
         RL_TRY(ln_bwd_deferred(st, ln));
@@ -659,7 +667,7 @@ template <typename T> struct Engine : EngineBase {
           if (hipEventRecord(ev_ready[p][3], st) != hipSuccess || hipStreamWaitEvent(side, ev_ready[p][3], 0) != hipSuccess) return RL_ERR_LAUNCH;
           ws_ = side;
         }
-        RL_TRY(gemm_tn_group<T>(ws_, 4, gp4, Tk, 1.0f, pass_overwrite ? 1 : 0));
+        RL_TRY(gemm_tn_group<T>(ws_, 4, gp4, Tk, 1.0f, pass_overwrite ? 1 : 0, live_tiles(), live_tile_count()));
       }
       {  // d x_in = d s1 + d qkv . W_qkv
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H; ep.accumulate = 1;
@@ -938,6 +946,7 @@ template <typename T> struct Engine : EngineBase {
     last = b;
     last.Tp = Tp;
     have_glyph_fwd = false;            // the activations a glyph_backward would read are about to be overwritten
+    dead_ok = false; cls_compact = false;
     last_alive.assign(Tp, 0);
     // host counts (the reference's contract: pho_lens is a host list) or, after realise_build_pho, device counts: every
     // step is then launched over all B*S rows and bounded on the device
@@ -994,6 +1003,11 @@ template <typename T> struct Engine : EngineBase {
       // Backward of the classifier over the rows that enter the loss only (loss_masks: no [CLS] / [SEP] / padding - 60 % of the
       // rows of a SIGHAN-shaped batch): the gradient rows are written compacted, the classifier input is gathered to match; the
       // other rows' gradients are exact zeros in the dense form, so the weight / bias / data gradients are the same sums.
+      // Rows after a sentence's last real / loss position are padding no query attends to and no loss term reads: every backward
+      // activation row there is an exact zero (the embedding scatter has relied on it since round 1).  The backward skips them:
+      // LayerNorm backward rows, whole 64-row tiles of the weight-gradient reductions.
+      dead_ok = g_skip_dead && b.want_dlogits && b.masks != nullptr && (Tk % 64) == 0;
+      if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_n)));
       cls_compact = g_cls_compact && b.want_dlogits && Tk <= 65536;
       CeCompact cc;
       if (cls_compact) { cc.act_idx = wp<int>(pl.cls_act); cc.inv = wp<int>(pl.cls_inv); cc.n_act = wp<int>(pl.cls_nact); }
@@ -1144,6 +1158,7 @@ template <typename T> struct Engine : EngineBase {
     const int Tk = pl.B * pl.S;
     const typename Plan::Scratch& sc = pl.sc[cs];
     LnBwdArgs<T> ln; ln.slots = ln_region(LN_FOLD_MAX); ln.rows = Tk; ln.H = H; ln.dy = wp<T>(pl.X3); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
+    ln.row_live = live_rows();
     ln.gamma = pp(L.res_ln_g); ln.dx = wp<T>(sc.gE); ln.dgamma = gp(L.res_ln_g); ln.dbeta = gp(L.res_ln_b);
     RL_TRY(ln_bwd<T>(st, ln));
     RL_TRY(segment_sum<T>(st, wp<T>(sc.gE), wp<int>(pl.gu_inv), Tk, H, wp<float>(pl.seg_acc), wp<T>(pl.r_dout), wp<int>(pl.gu_bounds)));

@@ -273,6 +273,11 @@ struct TnEpi {
   int overwrite = 0;        // TN_OUT_DIRECT only: out = result instead of out += result (the caller knows `out` holds nothing yet:
                             // no read of the old value, no zero-fill before the pass)
   int probe = 0;            // diagnostics (tools/nt_probe.cpp): 2 no fetches, 3 no MFMA, 4 no fold pass
+  // Optional list of the LIVE reduction tiles (unsplit dense reductions only): tile_list[t] = index of the t-th BP-row block of the
+  // reduction rows that holds anything but exact zeros in A (BP = 64 bf16 / 32 fp32 rows, P % BP == 0), *n_tiles = how many.  The
+  // rows of the other blocks are skipped - the gradient rows of padding tokens are exact zeros (engine.hip row_liveness).
+  const int* tile_list = nullptr;
+  const int* n_tiles = nullptr;
 };
 
 // Grouped TN (weight-gradient) launch: problems sharing the reduction length P, one 128x128 tile per workgroup, no reduction split.
@@ -289,9 +294,12 @@ template <typename T> struct TnGroup {
   TnGroupProblem<T> p[TN_GROUP_MAX];
   int n = 0, total_tiles = 0, probe = 0, overwrite = 0;
   float alpha = 1.0f;
+  const int* tile_list = nullptr;      // live reduction tiles (see TnEpi)
+  const int* n_tiles = nullptr;
 };
 template <typename T>
-int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha = 1.0f, int overwrite = 0);
+int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha = 1.0f, int overwrite = 0,
+                  const int* tile_list = nullptr, const int* n_tiles = nullptr);
 
 // C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)
 template <typename T>

@@ -559,6 +559,9 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
   const int p_begin = split * pchunk;
   const int p_end = max(p_begin, min(Pe, p_begin + pchunk));
   const void* zero = (const void*)g_zero16;
+  // live-tile list (unsplit dense reductions): the t-th tile of the loop is block tile_list[t] of the rows
+  constexpr bool kDenseB0 = sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
+  const bool listed = kDenseB0 && ep.tile_list != nullptr && nsplit == 1;
 
   // per-lane chunk coordinates are the same for every reduction tile: only the row base moves
   constexpr bool kDenseB = sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
@@ -626,10 +629,25 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
       incb[q] = bok[q] ? (int64_t)BP * ldb_bytes : 0;
     }
   }
+  int ptr_tile = p_begin / BP;           // the reduction tile pa / pb point at (live-tile list mode)
   auto issue = [&](int pt, int stage) {
     if (RL_PROBES && ep.probe == 2) return;
     char* base = smem + stage * STAGE;
     const bool full = pt + BP <= p_end;
+    // listed tiles are not consecutive: the pointers are rebuilt from the tile's first row (pa / pb hold the addresses of row 0 then)
+    if (listed) {
+      // listed tiles are mostly consecutive: the running pointers only jump (a wave-uniform number of tiles) over a run of dead blocks
+      const int d = pt / BP - ptr_tile;
+      if (d != 0) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) pa[q] += inca[q] * (int64_t)d;
+        if constexpr (kDenseB) {
+#pragma unroll
+          for (int q = 0; q < NB; ++q) pb[q] += incb[q] * (int64_t)d;
+        }
+      }
+      ptr_tile = pt / BP + 1;
+    }
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
       const void* src = pa[q];
@@ -654,10 +672,20 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
   };
 
   constexpr int NL = NA + NB;                          // fetch instructions per wave per tile
-  const int nt = (p_end - p_begin + BP - 1) / BP;
+  const int nt = listed ? min(*ep.n_tiles, (p_end - p_begin) / BP) : (p_end - p_begin + BP - 1) / BP;
   int issued = 0;
+  // the live-tile list is read 64 entries at a time into one register per lane (a load per tile would sit in front of every issue)
+  int list_reg = (listed && lane < nt) ? ep.tile_list[lane] : 0;
   auto issue_next = [&]() {
-    if (issued < nt) { issue(p_begin + issued * BP, issued % NST); ++issued; }
+    if (issued < nt) {
+      int pt = p_begin + issued * BP;
+      if (listed) {
+        if (issued != 0 && (issued & 63) == 0) list_reg = (issued + lane < nt) ? ep.tile_list[issued + lane] : 0;
+        pt = __builtin_amdgcn_readlane(list_reg, issued & 63) * BP;
+      }
+      issue(pt, issued % NST);
+      ++issued;
+    }
   };
 #pragma unroll
   for (int q = 0; q < NST - 1; ++q) issue_next();
@@ -738,6 +766,7 @@ gemm_tn_group_kernel(TnGroup<T> grp, int P, int pchunk) {
   DenseLoader<T> lb{pr.B, pr.ldb, P, pr.J};
   TnEpi ep;
   ep.out = pr.out; ep.ldo = pr.ldo; ep.colsum = pr.colsum; ep.alpha = grp.alpha; ep.probe = grp.probe; ep.overwrite = grp.overwrite;
+  ep.tile_list = grp.tile_list; ep.n_tiles = grp.n_tiles;
   tn_tile_body<T, DenseLoader<T>, TR, 2, 2, NST, BPD>(pr.A, pr.lda, lb, P, pr.I, pr.J, pr.tiles_j, pr.ntiles, 1, pchunk, TN_OUT_DIRECT, ep,
                                                       logical - pr.tile_begin);
 }
@@ -904,11 +933,13 @@ static int g_tn_group_ring = 0;      // measured: 4 x 32-row stages 3.76 ms/step
 void set_tn_group_ring(int on) { g_tn_group_ring = on; }
 
 template <typename T>
-int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha, int overwrite) {
+int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha, int overwrite, const int* tile_list,
+                  const int* n_tiles) {
   typedef TnGeo<T> G;
   if (n < 1 || n > TN_GROUP_MAX || P <= 0) return RL_ERR_ARG;
   TnGroup<T> grp;
   grp.n = n; grp.alpha = alpha; grp.probe = g_tn_probe; grp.overwrite = overwrite;
+  if (tile_list != nullptr && n_tiles != nullptr && (P % G::BP) == 0 && !g_tn_group_ring) { grp.tile_list = tile_list; grp.n_tiles = n_tiles; }
   int total = 0;
   double flops = 0.0;
   for (int k = 0; k < n; ++k) {
@@ -937,8 +968,8 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
 #undef RL_TN_GROUP
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
-template int gemm_tn_group<bf16_t>(hipStream_t, int, const TnGroupProblem<bf16_t>*, int, float, int);
-template int gemm_tn_group<float>(hipStream_t, int, const TnGroupProblem<float>*, int, float, int);
+template int gemm_tn_group<bf16_t>(hipStream_t, int, const TnGroupProblem<bf16_t>*, int, float, int, const int*, const int*);
+template int gemm_tn_group<float>(hipStream_t, int, const TnGroupProblem<float>*, int, float, int, const int*, const int*);
 
 template <typename T>
 int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep,

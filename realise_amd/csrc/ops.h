@@ -66,9 +66,17 @@ template <typename T> struct LnBwdArgs {
   float* dgamma = nullptr;         // accumulated
   float* dbeta = nullptr;
   float* slots = nullptr;          // optional scratch of LN_SLOT_BYTES: per-workgroup partial records, folded in a fixed order (no atomics)
+  const uint8_t* row_live = nullptr; // optional: row_live[r] == 0 -> dy[r] is known to be exact zeros (a padding token): the row is not read,
+                                   // its outputs are written as zeros (bf16 fast path; the generic kernel reads the zeros)
   int* deferred_records = nullptr; // non-null: do NOT launch the fold; *deferred_records = number of records written to `slots` (0: none, the
                                    // gradients were accumulated directly) - the caller folds several sites in one launch (ln_fold_multi)
 };
+// Rows of a [B, S] token batch whose gradients can be non-zero: row (b, s) is live iff s < 1 + the last position of sentence b with
+// masks == 1 or loss_masks == 1 (everything after it is padding that no query attends to and no loss term reads: every backward
+// activation row there is an exact zero).  row_live[B * S] bytes; tiles64 / tiles32: ascending indices of the 64- / 32-row blocks of
+// the token rows that hold a live row, n_tiles[0] / n_tiles[1] their counts (the live-tile lists of the weight-gradient reductions).
+int row_liveness(hipStream_t st, const int64_t* masks, const int64_t* loss_masks, int B, int S, uint8_t* row_live, int* tiles64, int* tiles32,
+                 int* n_tiles);
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a);
 // dgamma / dbeta += fixed-order sum of the per-workgroup records of up to LN_FOLD_MAX LayerNorm sites, one launch
 constexpr int LN_FOLD_MAX = 8;

@@ -318,13 +318,25 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
   auto load = [&](int row, LnRow16& r) {
-    const bool ok = active && row < a.rows;
+    const bool ok = active && row < a.rows && (a.row_live == nullptr || a.row_live[row] != 0);
     const uint32_t o0 = ((uint32_t)row * (uint32_t)H + (uint32_t)c0) * 2u, o1 = o0 + (uint32_t)H;      // rows * H * 2 < 4 GiB (launcher)
     const uint4 z = uint4{0u, 0u, 0u, 0u};
     r.dy[0] = ok ? *(const uint4*)((const char*)a.dy + o0) : z; r.dy[1] = ok ? *(const uint4*)((const char*)a.dy + o1) : z;
     r.xh[0] = ok ? *(const uint4*)((const char*)a.xhat + o0) : z; r.xh[1] = ok ? *(const uint4*)((const char*)a.xhat + o1) : z;
   };
   auto process = [&](int row, LnRow16& r) {
+    if (a.row_live != nullptr && a.row_live[row] == 0) {      // a padding row (wave-uniform): dy = 0 -> dx = 0, no dgamma / dbeta term
+      if (active) {
+        const uint4 z = uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint32_t off = ((uint32_t)row * (uint32_t)H + (uint32_t)(i ? c1 : c0)) * 2u;
+          *(uint4*)((char*)a.dx + off) = z;
+          if (a.dx_drop != nullptr) *(uint4*)((char*)a.dx_drop + off) = z;
+        }
+      }
+      return;
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -981,6 +993,63 @@ __device__ __forceinline__ float block_reduce(float v, float* sm, bool is_max) {
   float r = sm[0];
   for (int w = 1; w < 4; ++w) r = is_max ? fmaxf(r, sm[w]) : r + sm[w];
   return r;
+}
+
+// row_liveness (ops.h): one workgroup.  Phase 1: last flagged position of every sentence; phase 2: row bytes; phase 3: the 64- and
+// 32-row block lists by ballot + prefix scan (ascending, deterministic).
+__global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __restrict__ masks, const int64_t* __restrict__ loss_masks, int B, int S,
+                                                             uint8_t* __restrict__ row_live, int* __restrict__ tiles64, int* __restrict__ tiles32,
+                                                             int* __restrict__ n_tiles) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int T = B * S, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // phases 1 + 2: a wave per sentence finds 1 + the last flagged position, then writes the sentence's row bytes
+  for (int b = wave; b < B; b += 16) {
+    int last = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      const bool f = s < S && (masks[(int64_t)b * S + s] == 1 || (loss_masks != nullptr && loss_masks[(int64_t)b * S + s] == 1));
+      const unsigned long long bal = __ballot(f);
+      if (bal != 0ull) last = s0 + 64 - __clzll(bal);
+    }
+    for (int s = lane; s < S; s += 64) row_live[(int64_t)b * S + s] = s < last ? 1 : 0;
+  }
+  __syncthreads();
+  // phase 3: block lists
+  for (int pass = 0; pass < 2; ++pass) {
+    const int bp = pass ? 32 : 64;
+    int* out = pass ? tiles32 : tiles64;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    const int nblk = T / bp;
+    for (int k0 = 0; k0 < nblk; k0 += 1024) {
+      const int k = k0 + threadIdx.x;
+      bool live = false;
+      if (k < nblk)
+        for (int r = 0; r < bp; r += 16) {                       // 16 row bytes at a time
+          const uint4 v = *(const uint4*)(row_live + (int64_t)k * bp + r);
+          live = live || (v.x | v.y | v.z | v.w) != 0u;
+        }
+      const unsigned long long bal = __ballot(live);
+      const int before = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wsum[wave] = __popcll(bal);
+      __syncthreads();
+      int off = base_s;
+      for (int w = 0; w < wave; ++w) off += wsum[w];
+      if (live) out[off + before] = k;
+      __syncthreads();
+      if (threadIdx.x == 0) { int t = base_s; for (int w = 0; w < 16; ++w) t += wsum[w]; base_s = t; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) n_tiles[pass] = base_s;
+    __syncthreads();
+  }
+}
+int row_liveness(hipStream_t st, const int64_t* masks, const int64_t* loss_masks, int B, int S, uint8_t* row_live, int* tiles64, int* tiles32,
+                 int* n_tiles) {
+  if (B < 1 || S < 1 || ((int64_t)B * S) % 64 != 0 || masks == nullptr) return RL_ERR_ARG;
+  hipLaunchKernelGGL(row_liveness_kernel, dim3(1), dim3(1024), 0, st, masks, loss_masks, B, S, row_live, tiles64, tiles32, n_tiles);
+  return RL_LAUNCH_CHECK();
 }
 
 // Rows that enter the loss, in order: act_idx[j] = token row of the j-th active row, inv[row] = j (or -1), *n_act and *count = how
