@@ -13,5 +13,7 @@ int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
 template <typename T>
 int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, const float* mask_add, const T* ctx,
              const T* dctx, int64_t ldc, const float* lse, float* rowdot, T* dq, T* dk, T* dv, int64_t ldd,
-             int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale);
+             int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* rlen = nullptr);
+// rlen (optional, B ints): rows >= rlen[b] of sentence b are padding whose dctx rows are exact zeros and whose keys are masked - the
+// kernels do not visit them (their dq / dk / dv rows are stored as zeros)
 }  // namespace rl

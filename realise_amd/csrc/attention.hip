@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(256, 3)
 attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
                     const float* __restrict__ mask_add, const T* __restrict__ ctx, const T* __restrict__ dctx, int64_t ldc,
                     const float* __restrict__ lse, float* __restrict__ rowdot, T* __restrict__ dk_, T* __restrict__ dv_,
-                    int64_t ldd, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+                    int64_t ldd, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* __restrict__ rlen) {
   typedef typename MmaOf<T>::type Mma;
   typedef AttnGeo<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -243,9 +243,13 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
   const T* V = v_ + (int64_t)b * S * ldq + h * HD;
   const T* O = ctx + (int64_t)b * S * H + h * HD;
   const T* dO = dctx + (int64_t)b * S * H + h * HD;
+  // Sl: rows of this sentence that can carry a gradient (rlen[b]; S without the table).  Rows >= Sl are padding: their dO is an exact
+  // zero (no loss term, nothing attends to them), so they add nothing as queries, and as keys their probabilities are exact zeros:
+  // query blocks beyond Sl are not visited, key tiles beyond Sl store zeros without being computed.
+  const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;
 
-  stage_rows<T>(Q, ldq, S, Qs, tid);
-  stage_rows<T>(dO, H, S, dOs, tid);
+  stage_rows<T>(Q, ldq, Sl, Qs, tid);
+  stage_rows<T>(dO, H, Sl, dOs, tid);
   {  // rowdot[q] = sum_d dO[q,d] * O[q,d]  (two threads per row)
     const int row = tid >> 1, half = tid & 1;
     float acc = 0.f;
@@ -285,8 +289,9 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
     floatx4 dv[4], dk[4];
 #pragma unroll
     for (int dn = 0; dn < 4; ++dn) { dv[dn] = floatx4{0.f, 0.f, 0.f, 0.f}; dk[dn] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+    const int q_end = (k0 + 16 * n >= Sl) ? 0 : Sl;        // a tile of padding keys: dK = dV = 0
     for (int mm = 0; mm < 4; ++mm) {
-      if (32 * mm >= S) break;
+      if (32 * mm >= q_end) break;
       floatx4 s[2], dp[2];   // [mi] : queries 32mm + 16mi + 4g + r, key k0 + 16n + l15
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -354,7 +359,7 @@ __global__ void __launch_bounds__(256, 3)
 attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
                    const float* __restrict__ mask_add, const T* __restrict__ dctx, int64_t ldc,
                    const float* __restrict__ lse, const float* __restrict__ rowdot, T* __restrict__ dq_out, int64_t ldd,
-                   int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+                   int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* __restrict__ rlen) {
   typedef typename MmaOf<T>::type Mma;
   typedef AttnGeo<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -369,12 +374,25 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
   const T* V = v_ + (int64_t)b * S * ldq + h * HD;
   const T* dO = dctx + (int64_t)b * S * H + h * HD;
 
-  stage_rows<T>(K, ldq, S, Ks, tid);
-  stage_rows<T>(V, ldq, S, Vs, tid);
+  const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;       // see attn_bwd_dkv_kernel: padding keys are not visited, padding queries get dQ = 0
+  stage_rows<T>(K, ldq, Sl, Ks, tid);
+  stage_rows<T>(V, ldq, Sl, Vs, tid);
   if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
   __syncthreads();
   const int q0 = wave * 32;
   if (q0 >= S) return;
+  if (q0 >= Sl) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int q = q0 + 16 * m + l15;
+      if (q < S) {
+        T* dst = dq_out + ((int64_t)b * S + q) * ldd + h * HD + 4 * g;
+#pragma unroll
+        for (int dn = 0; dn < 4; ++dn) store4<T>(dst + 16 * dn, floatx4{0.f, 0.f, 0.f, 0.f});
+      }
+    }
+    return;
+  }
 
   typename Mma::Frag qf[2][G::KSTEPS], dof[2][G::KSTEPS];
   float lq[2], dq_[2];
@@ -396,7 +414,7 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
     for (int dn = 0; dn < 4; ++dn) dq[m][dn] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   for (int nn = 0; nn < 4; ++nn) {
-    if (32 * nn >= S) break;
+    if (32 * nn >= Sl) break;
     floatx4 s[2][2], dp[2][2];   // [ni][m] : keys 32nn + 16ni + 4g + r, query q0 + 16m + l15
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
@@ -475,7 +493,7 @@ int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
 template <typename T>
 int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, const float* mask_add, const T* ctx,
              const T* dctx, int64_t ldc, const float* lse, float* rowdot, T* dq, T* dk, T* dv, int64_t ldd,
-             int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+             int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* rlen) {
   if (S < 1 || S > SMAX || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC) || (ldd & 3)) return RL_ERR_ARG;
   typedef AttnGeo<T> G;
   const size_t lds1 = 2 * G::KT_BYTES + 2 * SMAX * sizeof(float);
@@ -487,19 +505,19 @@ int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
   {
     ProfScope ps(st, PK_ATTN_BWD, 6.0 * B * nh * (double)S * S * 64);
     RL_LAUNCH((attn_bwd_dkv_kernel<T>), dim3(B * nh), dim3(256), lds1, st, q, k, v, ldq, mask_add, ctx, dctx, ldc,
-              lse, rowdot, dk, dv, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale);
+              lse, rowdot, dk, dv, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale, rlen);
   }
   {
     ProfScope ps(st, PK_ATTN_BWD, 4.0 * B * nh * (double)S * S * 64);
     RL_LAUNCH((attn_bwd_dq_kernel<T>), dim3(B * nh), dim3(256), lds2, st, q, k, v, ldq, mask_add, dctx, ldc, lse,
-              rowdot, dq, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale);
+              rowdot, dq, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale, rlen);
   }
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
 template int attn_fwd<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, int64_t, const float*, bf16_t*, int64_t, float*, int, int, int, uint32_t, uint32_t, float);
 template int attn_fwd<float>(hipStream_t, const float*, const float*, const float*, int64_t, const float*, float*, int64_t, float*, int, int, int, uint32_t, uint32_t, float);
-template int attn_bwd<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, int64_t, const float*, const bf16_t*, const bf16_t*, int64_t, const float*, float*, bf16_t*, bf16_t*, bf16_t*, int64_t, int, int, int, uint32_t, uint32_t, float);
-template int attn_bwd<float>(hipStream_t, const float*, const float*, const float*, int64_t, const float*, const float*, const float*, int64_t, const float*, float*, float*, float*, float*, int64_t, int, int, int, uint32_t, uint32_t, float);
+template int attn_bwd<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, int64_t, const float*, const bf16_t*, const bf16_t*, int64_t, const float*, float*, bf16_t*, bf16_t*, bf16_t*, int64_t, int, int, int, uint32_t, uint32_t, float, const int*);
+template int attn_bwd<float>(hipStream_t, const float*, const float*, const float*, int64_t, const float*, const float*, const float*, int64_t, const float*, float*, float*, float*, float*, int64_t, int, int, int, uint32_t, uint32_t, float, const int*);
 
 }  // namespace rl

@@ -112,7 +112,7 @@ template <typename T> struct Engine : EngineBase {
     BlockAct blk[5];
     int64_t mask_add, out_d, dlogits, count, loss_internal;
     int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc;
-    int64_t row_live, live_t64, live_t32, live_n;          // padding rows: exact-zero gradient rows the backward skips (row_liveness)     // classifier backward over the rows that enter the loss only (stage_head)
+    int64_t row_live, live_t64, live_t32, live_n, live_rlen;          // padding rows: exact-zero gradient rows the backward skips (row_liveness)     // classifier backward over the rows that enter the loss only (stage_head)
     int64_t ids_clean = 0, pho_clean = 0;                 // range-checked copies of src_idx / pho_idx (sanitize_ids)
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
     int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
@@ -378,7 +378,7 @@ template <typename T> struct Engine : EngineBase {
     p.count = b.take(256);
     p.loss_internal = b.take(Tk * 4 + 256);       // per-row loss terms (ordered fold: reproducible loss)
     p.cls_act = b.take(Tk * 4); p.cls_inv = b.take(Tk * 4); p.cls_nact = b.take(256);
-    p.row_live = b.take(Tk + 64); p.live_t64 = b.take((Tk / 32 + 2) * 4); p.live_t32 = b.take((Tk / 32 + 2) * 4); p.live_n = b.take(256);
+    p.row_live = b.take(Tk + 64); p.live_t64 = b.take((Tk / 32 + 2) * 4); p.live_t32 = b.take((Tk / 32 + 2) * 4); p.live_n = b.take(256); p.live_rlen = b.take(B * 4 + 64);
     p.cls_xc = b.take(Tk * H * e); p.cls_gc = b.take(Tk * H * e);
     p.zero_once.push_back({p.cls_xc, Tk * H * e}); p.zero_once.push_back({p.cls_gc, Tk * H * e});
     // shared backward scratch
@@ -658,7 +658,7 @@ template <typename T> struct Engine : EngineBase {
       {
         const T* q = wp<T>(t.qkv);
         RL_TRY(attn_bwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), gE, H, wp<float>(t.lse),
-                           wp<float>(sc.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale));
+                           wp<float>(sc.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale, dead_ok ? wp<int>(pl.live_rlen) : nullptr));
       }
       RL_TRY(wgrad(3, gF, 3 * H, x_in, H, 3 * H, H, gp(o.qkv_b), gp(o.qkv_w)));
       if (grouped) {
@@ -1007,7 +1007,7 @@ template <typename T> struct Engine : EngineBase {
       // activation row there is an exact zero (the embedding scatter has relied on it since round 1).  The backward skips them:
       // LayerNorm backward rows, whole 64-row tiles of the weight-gradient reductions.
       dead_ok = g_skip_dead && b.want_dlogits && b.masks != nullptr && (Tk % 64) == 0;
-      if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_n)));
+      if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_n), wp<int>(pl.live_rlen)));
       cls_compact = g_cls_compact && b.want_dlogits && Tk <= 65536;
       CeCompact cc;
       if (cls_compact) { cc.act_idx = wp<int>(pl.cls_act); cc.inv = wp<int>(pl.cls_inv); cc.n_act = wp<int>(pl.cls_nact); }

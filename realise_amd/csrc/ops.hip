@@ -999,7 +999,7 @@ __device__ __forceinline__ float block_reduce(float v, float* sm, bool is_max) {
 // 32-row block lists by ballot + prefix scan (ascending, deterministic).
 __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __restrict__ masks, const int64_t* __restrict__ loss_masks, int B, int S,
                                                              uint8_t* __restrict__ row_live, int* __restrict__ tiles64, int* __restrict__ tiles32,
-                                                             int* __restrict__ n_tiles) {
+                                                             int* __restrict__ n_tiles, int* __restrict__ rlen) {
   __shared__ int wsum[16];
   __shared__ int base_s;
   const int T = B * S, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1013,6 +1013,7 @@ __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __res
       if (bal != 0ull) last = s0 + 64 - __clzll(bal);
     }
     for (int s = lane; s < S; s += 64) row_live[(int64_t)b * S + s] = s < last ? 1 : 0;
+    if (lane == 0 && rlen != nullptr) rlen[b] = last;
   }
   __syncthreads();
   // phase 3: block lists
@@ -1046,9 +1047,9 @@ __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __res
   }
 }
 int row_liveness(hipStream_t st, const int64_t* masks, const int64_t* loss_masks, int B, int S, uint8_t* row_live, int* tiles64, int* tiles32,
-                 int* n_tiles) {
+                 int* n_tiles, int* rlen) {
   if (B < 1 || S < 1 || ((int64_t)B * S) % 64 != 0 || masks == nullptr) return RL_ERR_ARG;
-  hipLaunchKernelGGL(row_liveness_kernel, dim3(1), dim3(1024), 0, st, masks, loss_masks, B, S, row_live, tiles64, tiles32, n_tiles);
+  hipLaunchKernelGGL(row_liveness_kernel, dim3(1), dim3(1024), 0, st, masks, loss_masks, B, S, row_live, tiles64, tiles32, n_tiles, rlen);
   return RL_LAUNCH_CHECK();
 }
 
