@@ -1,0 +1,263 @@
+// Stand-alone probe (NOT part of librealise_hip.so; next round's first experiment):
+// a bf16 NT GEMM  C[M,N] = A[M,K] . B[N,K]^T  with ONE WAVE PER SIMD and a 128 x (BN/2) register tile per wave.
+//
+// Why: the shipped 8-wave kernels read (RM + RN) * 64 * 2 bytes of operand fragments per wave and K-tile - 24 flop per LDS byte at the
+// 32 x 96 wave tile, 38 at 64 x 96 - and the LDS (128 B/clk/CU, shared with the LDS-DMA fill) saturates before the MFMA pipe does
+// (DESIGN.md section 6.2).  A 128 x 128 wave tile does 64 flop per fragment byte: per 32-deep K step a CU reads 64 KB of fragments
+// (512 clk) and takes 32 KB of fill (256 clk) against 1024 clk of MFMA issue.
+//
+// Shape of the kernel: 256 threads = 4 waves as 2 x 2 over a 256 x BN tile (BN = 256: 128 x 128 per wave, 256 accumulator registers;
+// BN = 192: 128 x 96).  K advances in steps of 32 (one v_mfma_f32_16x16x32_bf16 deep): a stage is [256 + BN] rows of 64 bytes, FOUR
+// stages ring (128 KB at BN = 256), LDS-DMA fills issued three steps ahead with a counted s_waitcnt vmcnt, ONE raw s_barrier per
+// step; the fragments of step t+1 are read (16 ds_read_b128) while the 64 MFMAs of step t issue, from a second register set.
+// 64-byte rows: chunk c of row r sits at slot c ^ ((r >> 1) & 3) (rows r, r+1 share a 128-byte bank row: eight rows of a fragment
+// read touch eight distinct 16-byte slots), the swizzle is applied on the SOURCE address of the fill.
+// MFMA operands are swapped (B fragment first), so a lane ends with 4 consecutive columns of one row: 8-byte stores.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/nt1w_probe.hip -o /tmp/nt1w_probe && /tmp/nt1w_probe
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(4))) float floatx4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {           // round to nearest even
+  uint32_t x = __float_as_uint(a), y = __float_as_uint(b);
+  x += 0x7fffu + ((x >> 16) & 1u);
+  y += 0x7fffu + ((y >> 16) & 1u);
+  return (x >> 16) | (y & 0xffff0000u);
+}
+
+// (the body lives in a __device__ function: as in-kernel lambdas around device-only builtins the host pass of hipcc 7.2 silently
+//  fails to emit the kernel stub)
+template <int BN>
+__device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, uint16_t* __restrict__ C, int ldc,
+                                          int M, int N, int K, int tiles_n, int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, RM = 128, RN = BN / 2, MT = RM / 16, NT = RN / 16;
+  constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NS = 4, NPIECE = ROWS / 16, NPW = NPIECE / 4;     // 1-KiB pieces (16 rows) per step, per wave
+  static_assert(NPIECE % 4 == 0, "pieces split evenly over the four waves");
+  static_assert(NS * STAGE <= 160 * 1024, "LDS");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // block b lands on XCD b % 8: give every XCD a contiguous run of tiles (row-major: its tiles share A row panels)
+  const int q8 = ntiles >> 3, r8 = ntiles & 7, x8 = blockIdx.x & 7;
+  const int tile = ((x8 < r8) ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (blockIdx.x >> 3);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = K >> 5;                                                  // K % 32 == 0
+
+  // ---- fill: piece p = s * 4 + wave covers rows [16p, 16p + 16) of the [A rows | B rows] stage image; lane i writes LDS bytes
+  //      [16i, 16i + 16) of the piece = row i >> 2, slot i & 3, which holds logical chunk (i & 3) ^ ((row >> 1) & 3)
+  const int lrow = lane >> 2;
+  const int chunk_b = (((lane & 3) ^ ((lrow >> 1) & 3)) << 4);
+  uint32_t go[NPW];
+  bool isb[NPW];
+#pragma unroll
+  for (int s = 0; s < NPW; ++s) {
+    const int row = (s * 4 + wave) * 16 + lrow;
+    isb[s] = row >= BM;
+    const int grow = isb[s] ? min(n0 + row - BM, N - 1) : min(m0 + row, M - 1);
+    go[s] = (uint32_t)((int64_t)grow * (isb[s] ? ldb : lda) * 2 + chunk_b);
+  }
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((int64_t)(M - 1) * lda + K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(((int64_t)(N - 1) * ldb + K) * 2), 0x00020000);
+  auto fill = [&](int t) {
+    char* base = smem + (t & (NS - 1)) * STAGE;
+#pragma unroll
+    for (int s = 0; s < NPW; ++s)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isb[s] ? rsB : rsA, (__attribute__((address_space(3))) void*)(base + (s * 4 + wave) * 1024), 16, go[s],
+                                               t * 64, 0, 0);
+  };
+
+  // ---- fragments: lane (l15, g) reads row l15 of a 16-row tile, logical chunk g -> slot g ^ ((l15 >> 1) & 3)
+  const int frag_lane = l15 * 64 + ((g ^ ((l15 >> 1) & 3)) << 4);
+  const int fa = wm * RM * 64 + frag_lane, fb = BM * 64 + wn * RN * 64 + frag_lane;
+  bf16x8_t a0[MT], b0[NT], a1[MT], b1[NT];
+  auto read_frags = [&](int t, bf16x8_t* af, bf16x8_t* bfr) {
+    const char* base = smem + (t & (NS - 1)) * STAGE;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8_t*)(base + fa + i * 1024);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8_t*)(base + fb + j * 1024);
+  };
+  floatx4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  auto mma_all = [&](const bf16x8_t* af, const bf16x8_t* bfr) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);      // lane: row l15 of tile i, columns 4g .. 4g + 3 of tile j
+  };
+
+  // ---- prologue: three steps in flight, step 0 landed and read
+  fill(0);
+  if (nk > 1) fill(1);
+  if (nk > 2) fill(2);
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  read_frags(0, a0, b0);
+
+  // ---- steady state, two steps per trip (two statically named fragment sets)
+  auto step = [&](int t, const bf16x8_t* af, const bf16x8_t* bfr, bf16x8_t* an, bf16x8_t* bn) {
+    // stage (t + 3) & 3 held step t - 1, whose fragments every wave finished reading before the barrier of step t - 1
+    if (t + 3 < nk) fill(t + 3);
+    if (t + 1 < nk) {
+      // step t + 1 has landed once at most the two younger steps' pieces are outstanding
+      // (lgkmcnt(0): this wave's fragment reads of step t, issued a step ago and about to be used, have left the stage the next
+      //  fill overwrites)
+      if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NPW) : "memory");
+      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      read_frags(t + 1, an, bn);
+    }
+    __builtin_amdgcn_s_setprio(1);
+    mma_all(af, bfr);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  for (int t = 0; t < nk; t += 2) {
+    step(t, a0, b0, a1, b1);
+    if (t + 1 < nk) step(t + 1, a1, b1, a0, b0);
+  }
+
+  // ---- epilogue: 4 consecutive columns per lane
+  const int row_w = m0 + wm * RM, col_w = n0 + wn * RN;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = row_w + 16 * i + l15;
+    if (row >= M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = col_w + 16 * j + 4 * g;
+      if (col + 3 < N) {
+        uint2 u;
+        u.x = pack2bf(acc[i][j][0], acc[i][j][1]);
+        u.y = pack2bf(acc[i][j][2], acc[i][j][3]);
+        *(uint2*)(C + (int64_t)row * ldc + col) = u;
+      }
+    }
+  }
+#endif
+}
+template <int BN>
+__global__ void __launch_bounds__(256, 1)
+nt1w_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, uint16_t* __restrict__ C, int ldc, int M, int N, int K,
+            int tiles_n, int ntiles) {
+  nt1w_body<BN>(A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles);
+}
+
+// plain reference: one thread per output, fp32 accumulation in k order
+__global__ void ref_kernel(const uint16_t* A, int lda, const uint16_t* B, int ldb, float* C, int M, int N, int K, const int* rows, int nrows) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, ri = blockIdx.y;
+  if (n >= N || ri >= nrows) return;
+  const int m = rows[ri];
+  float s = 0.f;
+  for (int k = 0; k < K; ++k) s += __uint_as_float((uint32_t)A[(int64_t)m * lda + k] << 16) * __uint_as_float((uint32_t)B[(int64_t)n * ldb + k] << 16);
+  C[(int64_t)ri * N + n] = s;
+}
+
+static uint16_t f2bf(float f) { uint32_t x; memcpy(&x, &f, 4); x += 0x7fffu + ((x >> 16) & 1u); return (uint16_t)(x >> 16); }
+static float bf2f(uint16_t h) { uint32_t x = (uint32_t)h << 16; float f; memcpy(&f, &x, 4); return f; }
+
+template <int BN>
+static void launch(hipStream_t st, const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K) {
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+  const size_t lds = (size_t)4 * (256 + BN) * 64;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)nt1w_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((nt1w_kernel<BN>), dim3(ntiles), dim3(256), lds, st, A, K, B, K, C, N, M, N, K, tiles_n, ntiles);
+}
+
+int main() {
+  struct Shape { int M, N, K; const char* what; };
+  const Shape shapes[] = {{8192, 21128, 768, "classifier"}, {8192, 3072, 768, "ffn-up"}, {8192, 2304, 768, "qkv"}, {8192, 768, 3072, "ffn-down"},
+                          {1000, 776, 128, "ragged M, N"}, {8192, 768, 21184, "classifier dgrad"}};
+  hipStream_t st; (void)hipStreamCreate(&st);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  size_t total_bad = 0;
+  for (const Shape& sh : shapes) {
+    const size_t na = (size_t)sh.M * sh.K, nb = (size_t)sh.N * sh.K, nc = (size_t)sh.M * sh.N;
+    // several operand sets: the cold timing cycles through them so that nothing is found in the Infinity Cache
+    const size_t set = na + nb + nc;
+    int nsets = (int)(((size_t)500 << 20) / set) + 2;
+    if (nsets > 24) nsets = 24;
+    std::vector<uint16_t> ha(na), hb(nb);
+    uint32_t rng = 12345u;
+    auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return ((rng >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& v : ha) v = f2bf(rnd());
+    for (auto& v : hb) v = f2bf(rnd() * 0.25f);
+    uint16_t* pool; (void)hipMalloc(&pool, (size_t)nsets * set * 2);
+    for (int s = 0; s < nsets; ++s) {
+      (void)hipMemcpy(pool + (size_t)s * set, ha.data(), na * 2, hipMemcpyHostToDevice);
+      (void)hipMemcpy(pool + (size_t)s * set + na, hb.data(), nb * 2, hipMemcpyHostToDevice);
+    }
+    const int nrows = 24;
+    std::vector<int> hrows(nrows);
+    for (int i = 0; i < nrows; ++i) hrows[i] = (int)(((int64_t)i * 349 + 7) % sh.M);
+    hrows[0] = 0; hrows[1] = sh.M - 1;
+    int* drows; float* dref;
+    (void)hipMalloc(&drows, nrows * 4); (void)hipMalloc(&dref, (size_t)nrows * sh.N * 4);
+    (void)hipMemcpy(drows, hrows.data(), nrows * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(ref_kernel, dim3((sh.N + 255) / 256, nrows), dim3(256), 0, st, pool, sh.K, pool + na, sh.K, dref, sh.M, sh.N, sh.K, drows, nrows);
+    std::vector<float> href((size_t)nrows * sh.N);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost);
+    for (int bn : {256, 192}) {
+      auto run = [&](int s) {
+        uint16_t* base = pool + (size_t)(s % nsets) * set;
+        if (bn == 256) launch<256>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K);
+        else launch<192>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K);
+      };
+      (void)hipMemsetAsync(pool + na + nb, 0xff, nc * 2, st);
+      run(0);
+      (void)hipStreamSynchronize(st);
+      if (hipGetLastError() != hipSuccess) { printf("launch failed\n"); return 1; }
+      std::vector<uint16_t> hc(nc);
+      (void)hipMemcpy(hc.data(), pool + na + nb, nc * 2, hipMemcpyDeviceToHost);
+      size_t bad = 0; double worst = 0.0;
+      for (int i = 0; i < nrows; ++i)
+        for (int n = 0; n < (sh.N & ~3); ++n) {
+          const float want = href[(size_t)i * sh.N + n], got = bf2f(hc[(size_t)hrows[i] * sh.N + n]);
+          const double err = std::fabs((double)got - want), tol = 1e-2 * std::fabs(want) + 2e-2;       // bf16 output + accumulation order
+          if (!(err <= tol)) { if (bad < 5) printf("   mismatch row %d col %d: got %g want %g\n", hrows[i], n, got, want); ++bad; }
+          if (err > worst) worst = err;
+        }
+      total_bad += bad;
+      const int reps = sh.N > 4096 || sh.K > 4096 ? 8 : 24;
+      for (int s = 0; s < 2; ++s) run(0);
+      (void)hipEventRecord(e0, st);
+      for (int s = 0; s < reps; ++s) run(0);
+      (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
+      float warm = 0.f; (void)hipEventElapsedTime(&warm, e0, e1);
+      for (int s = 0; s < nsets; ++s) run(s);
+      (void)hipEventRecord(e0, st);
+      for (int s = 0; s < reps; ++s) run(s);
+      (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
+      float cold = 0.f; (void)hipEventElapsedTime(&cold, e0, e1);
+      const double fl = 2.0 * sh.M * sh.N * sh.K;
+      printf("nt1w 256x%d  %5d x %5d x %5d %-18s | warm %7.1f us %5.0f TF | cold %7.1f us %5.0f TF | checked %d rows: %zu mismatches, worst |err| %.3g\n", bn,
+             sh.M, sh.N, sh.K, sh.what, warm * 1000.0 / reps, fl / (warm * 1e-3 / reps) * 1e-12, cold * 1000.0 / reps, fl / (cold * 1e-3 / reps) * 1e-12,
+             nrows, bad, worst);
+      fflush(stdout);
+    }
+    (void)hipFree(pool); (void)hipFree(drows); (void)hipFree(dref);
+  }
+  printf("TOTAL mismatches: %zu\n", total_bad);
+  return total_bad ? 2 : 0;
+}
