@@ -1,4 +1,5 @@
-// Stand-alone probe (NOT part of librealise_hip.so; next round's first experiment):
+// Stand-alone probe (NOT part of librealise_hip.so; next round's first experiment; first run:
+// profiles/round3_nt1w_probe.log - correct, v0 issue schedule 679 TF on the classifier against 958-1097 for the shipped kernel):
 // a bf16 NT GEMM  C[M,N] = A[M,K] . B[N,K]^T  with ONE WAVE PER SIMD and a 128 x (BN/2) register tile per wave.
 //
 // Why: the shipped 8-wave kernels read (RM + RN) * 64 * 2 bytes of operand fragments per wave and K-tile - 24 flop per LDS byte at the
