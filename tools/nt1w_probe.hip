@@ -1,5 +1,6 @@
-// Stand-alone probe (NOT part of librealise_hip.so; next round's first experiment; first run:
-// profiles/round3_nt1w_probe.log - correct, v0 issue schedule 679 TF on the classifier against 958-1097 for the shipped kernel):
+// Stand-alone probe (NOT part of librealise_hip.so; next round's first experiment; three runs on
+// record in profiles/round3_nt1w_probe.log - correct in every variant; SCHED 0 front-loaded issue 679 TF on the classifier, SCHED 1
+// interleaved issue 771, SCHED 2 persistent walk 745, SCHED 3 the same without stores 1040; shipped kernel 958-1097 with stores):
 // a bf16 NT GEMM  C[M,N] = A[M,K] . B[N,K]^T  with ONE WAVE PER SIMD and a 128 x (BN/2) register tile per wave.
 //
 // Why: the shipped 8-wave kernels read (RM + RN) * 64 * 2 bytes of operand fragments per wave and K-tile - 24 flop per LDS byte at the
@@ -37,7 +38,15 @@ __device__ __forceinline__ uint32_t pack2bf(float a, float b) {           // rou
 
 // (the body lives in a __device__ function: as in-kernel lambdas around device-only builtins the host pass of hipcc 7.2 silently
 //  fails to emit the kernel stub)
-template <int BN>
+// MFMA with the accumulator pinned to AGPRs (inline asm, "a" constraint): in the interleaved block the compiler otherwise selects the
+// VGPR form of the MFMA and wraps every tile in v_accvgpr_read / v_accvgpr_write copies (252 of them per two steps)
+__device__ __forceinline__ void mfma_a(floatx4& c, const bf16x8_t& x, const bf16x8_t& y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(x), "v"(y));
+#endif
+}
+
+template <int BN, int SCHED>
 __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, uint16_t* __restrict__ C, int ldc,
                                           int M, int N, int K, int tiles_n, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -50,10 +59,16 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   // block b lands on XCD b % 8: give every XCD a contiguous run of tiles (row-major: its tiles share A row panels)
+  // SCHED >= 2: PERSISTENT - gridDim.x (a multiple of 8) workgroups, workgroup w walks the tiles base + (w >> 3), + gridDim.x / 8, ...
+  // of its XCD's run; the first three fills of the next tile are issued before the current tile's stores.
+  constexpr bool PERSIST = SCHED >= 2;
+  constexpr bool STORES = SCHED != 3;
   const int q8 = ntiles >> 3, r8 = ntiles & 7, x8 = blockIdx.x & 7;
-  const int tile = ((x8 < r8) ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (blockIdx.x >> 3);
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int xbase = (x8 < r8) ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8, xcnt = q8 + (x8 < r8 ? 1 : 0);
+  const int kstride = PERSIST ? (int)(gridDim.x >> 3) : (1 << 30);
+  int kt = blockIdx.x >> 3;
+  if (kt >= xcnt) return;
+  int m0 = ((xbase + kt) / tiles_n) * BM, n0 = ((xbase + kt) % tiles_n) * BN;
   const int nk = K >> 5;                                                  // K % 32 == 0
 
   // ---- fill: piece p = s * 4 + wave covers rows [16p, 16p + 16) of the [A rows | B rows] stage image; lane i writes LDS bytes
@@ -62,13 +77,16 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
   const int chunk_b = (((lane & 3) ^ ((lrow >> 1) & 3)) << 4);
   uint32_t go[NPW];
   bool isb[NPW];
+  auto set_tile = [&](int tm0, int tn0) {
 #pragma unroll
-  for (int s = 0; s < NPW; ++s) {
-    const int row = (s * 4 + wave) * 16 + lrow;
-    isb[s] = row >= BM;
-    const int grow = isb[s] ? min(n0 + row - BM, N - 1) : min(m0 + row, M - 1);
-    go[s] = (uint32_t)((int64_t)grow * (isb[s] ? ldb : lda) * 2 + chunk_b);
-  }
+    for (int s = 0; s < NPW; ++s) {
+      const int row = (s * 4 + wave) * 16 + lrow;
+      isb[s] = row >= BM;
+      const int grow = isb[s] ? min(tn0 + row - BM, N - 1) : min(tm0 + row, M - 1);
+      go[s] = (uint32_t)((int64_t)grow * (isb[s] ? ldb : lda) * 2 + chunk_b);
+    }
+  };
+  set_tile(m0, n0);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((int64_t)(M - 1) * lda + K) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(((int64_t)(N - 1) * ldb + K) * 2), 0x00020000);
   auto fill = [&](int t) {
@@ -91,10 +109,6 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
     for (int j = 0; j < NT; ++j) bfr[j] = *(const bf16x8_t*)(base + fb + j * 1024);
   };
   floatx4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
   auto mma_all = [&](const bf16x8_t* af, const bf16x8_t* bfr) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -107,11 +121,7 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
   fill(0);
   if (nk > 1) fill(1);
   if (nk > 2) fill(2);
-  if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  read_frags(0, a0, b0);
+  bool first_tile = true;
 
   // ---- steady state, two steps per trip (two statically named fragment sets)
   auto step = [&](int t, const bf16x8_t* af, const bf16x8_t* bfr, bf16x8_t* an, bf16x8_t* bn) {
@@ -132,35 +142,111 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
     mma_all(af, bfr);
     __builtin_amdgcn_s_setprio(0);
   };
-  for (int t = 0; t < nk; t += 2) {
-    step(t, a0, b0, a1, b1);
-    if (t + 1 < nk) step(t + 1, a1, b1, a0, b0);
-  }
-
-  // ---- epilogue: 4 consecutive columns per lane
-  const int row_w = m0 + wm * RM, col_w = n0 + wn * RN;
+  // SCHED 1: the steady-state step as ONE basic block with the memory instructions of the step placed BETWEEN the MFMAs - per column
+  // of tiles g: 4 MFMAs, the A fragment read(s) of step t + 1, 4 MFMAs, its B fragment read, the fill issue(s) of step t + 3 - so the
+  // MFMA pipe never waits for the wave to get through the 24 memory instructions (a v_mfma_16x16x32 occupies the pipe for 16 clk and
+  // the wave's issue slot for 4).  The last four steps run the branchy form above.
+  auto steady = [&](int t, const bf16x8_t* af, const bf16x8_t* bfr, bf16x8_t* an, bf16x8_t* bn) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");          // fill(t + 1) landed (fill(t + 2) may be in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* rbase = smem + ((t + 1) & (NS - 1)) * STAGE;
+    char* wbase = smem + ((t + 3) & (NS - 1)) * STAGE;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int row = row_w + 16 * i + l15;
-    if (row >= M) continue;
+    for (int gq = 0; gq < NT; ++gq) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = col_w + 16 * j + 4 * g;
-      if (col + 3 < N) {
-        uint2 u;
-        u.x = pack2bf(acc[i][j][0], acc[i][j][1]);
-        u.y = pack2bf(acc[i][j][2], acc[i][j][3]);
-        *(uint2*)(C + (int64_t)row * ldc + col) = u;
+      for (int i = 0; i < MT / 2; ++i) mfma_a(acc[i][gq], bfr[gq], af[i]);
+      __builtin_amdgcn_sched_barrier(0);
+      an[gq] = *(const bf16x8_t*)(rbase + fa + gq * 1024);
+      if (gq + NT < MT) an[gq + NT] = *(const bf16x8_t*)(rbase + fa + (gq + NT) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = MT / 2; i < MT; ++i) mfma_a(acc[i][gq], bfr[gq], af[i]);
+      __builtin_amdgcn_sched_barrier(0);
+      bn[gq] = *(const bf16x8_t*)(rbase + fb + gq * 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isb[gq] ? rsB : rsA, (__attribute__((address_space(3))) void*)(wbase + (gq * 4 + wave) * 1024), 16, go[gq],
+                                               (t + 3) * 64, 0, 0);
+      if (gq + NT < NPW)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isb[gq + NT] ? rsB : rsA, (__attribute__((address_space(3))) void*)(wbase + ((gq + NT) * 4 + wave) * 1024), 16,
+                                                 go[gq + NT], (t + 3) * 64, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  for (;;) {
+    // step 0 of this tile landed (the first tile: only fills are outstanding; later tiles: the previous tile's stores were issued after
+    // these fills and retire in order behind them, so everything is waited for)
+    if (first_tile && nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    first_tile = false;
+    read_frags(0, a0, b0);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    int t = 0;
+    if constexpr (SCHED >= 1) {
+      for (; t + 4 < nk; t += 2) {
+        steady(t, a0, b0, a1, b1);
+        steady(t + 1, a1, b1, a0, b0);
       }
     }
+    for (; t < nk; t += 2) {
+      step(t, a0, b0, a1, b1);
+      if (t + 1 < nk) step(t + 1, a1, b1, a0, b0);
+    }
+    // ---- next tile: its first three fills go out before this tile's stores (every wave has read its last fragments: barrier)
+    const int cur_m0 = m0, cur_n0 = n0;
+    kt += kstride;
+    const bool more = kt < xcnt;
+    if (more) {
+      m0 = ((xbase + kt) / tiles_n) * BM; n0 = ((xbase + kt) % tiles_n) * BN;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      set_tile(m0, n0);
+      fill(0);
+      if (nk > 1) fill(1);
+      if (nk > 2) fill(2);
+    }
+    // ---- epilogue: 4 consecutive columns per lane
+    if constexpr (STORES) {
+      const int row_w = cur_m0 + wm * RM, col_w = cur_n0 + wn * RN;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = row_w + 16 * i + l15;
+        if (row >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = col_w + 16 * j + 4 * g;
+          if (col + 3 < N) {
+            uint2 u;
+            u.x = pack2bf(acc[i][j][0], acc[i][j][1]);
+            u.y = pack2bf(acc[i][j][2], acc[i][j][3]);
+            *(uint2*)(C + (int64_t)row * ldc + col) = u;
+          }
+        }
+      }
+    } else {
+      // no-store variant (timing only): keep the accumulators alive
+      float sink = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) sink += acc[i][j][0] + acc[i][j][3];
+      if (sink == 12345.678f) C[0] = 1;
+    }
+    if (!more) break;
   }
 #endif
 }
-template <int BN>
+template <int BN, int SCHED>
 __global__ void __launch_bounds__(256, 1)
 nt1w_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, uint16_t* __restrict__ C, int ldc, int M, int N, int K,
             int tiles_n, int ntiles) {
-  nt1w_body<BN>(A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles);
+  nt1w_body<BN, SCHED>(A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles);
 }
 
 // plain reference: one thread per output, fp32 accumulation in k order
@@ -176,13 +262,14 @@ __global__ void ref_kernel(const uint16_t* A, int lda, const uint16_t* B, int ld
 static uint16_t f2bf(float f) { uint32_t x; memcpy(&x, &f, 4); x += 0x7fffu + ((x >> 16) & 1u); return (uint16_t)(x >> 16); }
 static float bf2f(uint16_t h) { uint32_t x = (uint32_t)h << 16; float f; memcpy(&f, &x, 4); return f; }
 
-template <int BN>
+template <int BN, int SCHED>
 static void launch(hipStream_t st, const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K) {
   const int tiles_m = (M + 255) / 256, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   const size_t lds = (size_t)4 * (256 + BN) * 64;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)nt1w_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((nt1w_kernel<BN>), dim3(ntiles), dim3(256), lds, st, A, K, B, K, C, N, M, N, K, tiles_n, ntiles);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)nt1w_kernel<BN, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  const int grid = SCHED >= 2 ? (ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256) : ntiles;
+  hipLaunchKernelGGL((nt1w_kernel<BN, SCHED>), dim3(grid), dim3(256), lds, st, A, K, B, K, C, N, M, N, K, tiles_n, ntiles);
 }
 
 int main() {
@@ -219,11 +306,18 @@ int main() {
     std::vector<float> href((size_t)nrows * sh.N);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost);
-    for (int bn : {256, 192}) {
+    for (int cfg = 2; cfg < 8; ++cfg) {          // sched 0 (no interleaving) is on record in profiles/round3_nt1w_probe.log
+      const int bn = (cfg & 1) ? 192 : 256, sched = cfg >> 1;
       auto run = [&](int s) {
         uint16_t* base = pool + (size_t)(s % nsets) * set;
-        if (bn == 256) launch<256>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K);
-        else launch<192>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K);
+        switch (cfg) {
+          case 2: launch<256, 1>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K); break;
+          case 3: launch<192, 1>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K); break;
+          case 4: launch<256, 2>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K); break;
+          case 5: launch<192, 2>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K); break;
+          case 6: launch<256, 3>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K); break;
+          default: launch<192, 3>(st, base, base + na, base + na + nb, sh.M, sh.N, sh.K); break;
+        }
       };
       (void)hipMemsetAsync(pool + na + nb, 0xff, nc * 2, st);
       run(0);
@@ -232,7 +326,7 @@ int main() {
       std::vector<uint16_t> hc(nc);
       (void)hipMemcpy(hc.data(), pool + na + nb, nc * 2, hipMemcpyDeviceToHost);
       size_t bad = 0; double worst = 0.0;
-      for (int i = 0; i < nrows; ++i)
+      for (int i = 0; i < (sched == 3 ? 0 : nrows); ++i)
         for (int n = 0; n < (sh.N & ~3); ++n) {
           const float want = href[(size_t)i * sh.N + n], got = bf2f(hc[(size_t)hrows[i] * sh.N + n]);
           const double err = std::fabs((double)got - want), tol = 1e-2 * std::fabs(want) + 2e-2;       // bf16 output + accumulation order
@@ -252,7 +346,7 @@ int main() {
       (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
       float cold = 0.f; (void)hipEventElapsedTime(&cold, e0, e1);
       const double fl = 2.0 * sh.M * sh.N * sh.K;
-      printf("nt1w 256x%d  %5d x %5d x %5d %-18s | warm %7.1f us %5.0f TF | cold %7.1f us %5.0f TF | checked %d rows: %zu mismatches, worst |err| %.3g\n", bn,
+      printf("nt1w 256x%d sched %d  %5d x %5d x %5d %-18s | warm %7.1f us %5.0f TF | cold %7.1f us %5.0f TF | checked %d rows: %zu mismatches, worst |err| %.3g\n", bn, sched,
              sh.M, sh.N, sh.K, sh.what, warm * 1000.0 / reps, fl / (warm * 1e-3 / reps) * 1e-12, cold * 1000.0 / reps, fl / (cold * 1e-3 / reps) * 1e-12,
              nrows, bad, worst);
       fflush(stdout);
