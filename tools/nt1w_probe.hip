@@ -46,7 +46,7 @@ __device__ __forceinline__ void mfma_a(floatx4& c, const bf16x8_t& x, const bf16
 #endif
 }
 
-template <int BN, int SCHED>
+template <int BN, int SCHED, int PR>
 __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, uint16_t* __restrict__ C, int ldc,
                                           int M, int N, int K, int tiles_n, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -148,7 +148,7 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
   // the wave's issue slot for 4).  The last four steps run the branchy form above.
   auto steady = [&](int t, const bf16x8_t* af, const bf16x8_t* bfr, bf16x8_t* an, bf16x8_t* bn) {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NPW) : "memory");          // fill(t + 1) landed (fill(t + 2) may be in flight)
-    __builtin_amdgcn_s_barrier();
+    if constexpr (PR != 1) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const char* rbase = smem + ((t + 1) & (NS - 1)) * STAGE;
     char* wbase = smem + ((t + 3) & (NS - 1)) * STAGE;
@@ -158,18 +158,22 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
 #pragma unroll
       for (int i = 0; i < MT / 2; ++i) mfma_a(acc[i][gq], bfr[gq], af[i]);
       __builtin_amdgcn_sched_barrier(0);
-      an[gq] = *(const bf16x8_t*)(rbase + fa + gq * 1024);
-      if (gq + NT < MT) an[gq + NT] = *(const bf16x8_t*)(rbase + fa + (gq + NT) * 1024);
+      if constexpr (PR < 3) {
+        an[gq] = *(const bf16x8_t*)(rbase + fa + gq * 1024);
+        if (gq + NT < MT) an[gq + NT] = *(const bf16x8_t*)(rbase + fa + (gq + NT) * 1024);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = MT / 2; i < MT; ++i) mfma_a(acc[i][gq], bfr[gq], af[i]);
       __builtin_amdgcn_sched_barrier(0);
-      bn[gq] = *(const bf16x8_t*)(rbase + fb + gq * 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(isb[gq] ? rsB : rsA, (__attribute__((address_space(3))) void*)(wbase + (gq * 4 + wave) * 1024), 16, go[gq],
-                                               (t + 3) * 64, 0, 0);
-      if (gq + NT < NPW)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(isb[gq + NT] ? rsB : rsA, (__attribute__((address_space(3))) void*)(wbase + ((gq + NT) * 4 + wave) * 1024), 16,
-                                                 go[gq + NT], (t + 3) * 64, 0, 0);
+      if constexpr (PR < 3) bn[gq] = *(const bf16x8_t*)(rbase + fb + gq * 1024);
+      if constexpr (PR != 2 && PR != 4) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isb[gq] ? rsB : rsA, (__attribute__((address_space(3))) void*)(wbase + (gq * 4 + wave) * 1024), 16, go[gq],
+                                                 (t + 3) * 64, 0, 0);
+        if (gq + NT < NPW)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(isb[gq + NT] ? rsB : rsA, (__attribute__((address_space(3))) void*)(wbase + ((gq + NT) * 4 + wave) * 1024), 16,
+                                                   go[gq + NT], (t + 3) * 64, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -183,6 +187,12 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
     asm volatile("" ::: "memory");
     first_tile = false;
     read_frags(0, a0, b0);
+    if constexpr (PR >= 3) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a1[i] = a0[i];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b1[j] = b0[j];
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -242,11 +252,12 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
   }
 #endif
 }
-template <int BN, int SCHED>
+// PR (timing-only ablations of the interleaved step, results wrong): 1 no barrier, 2 no fills, 3 no fragment reads, 4 neither fills nor reads
+template <int BN, int SCHED, int PR = 0>
 __global__ void __launch_bounds__(256, 1)
 nt1w_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, uint16_t* __restrict__ C, int ldc, int M, int N, int K,
             int tiles_n, int ntiles) {
-  nt1w_body<BN, SCHED>(A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles);
+  nt1w_body<BN, SCHED, PR>(A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles);
 }
 
 // plain reference: one thread per output, fp32 accumulation in k order
@@ -262,20 +273,22 @@ __global__ void ref_kernel(const uint16_t* A, int lda, const uint16_t* B, int ld
 static uint16_t f2bf(float f) { uint32_t x; memcpy(&x, &f, 4); x += 0x7fffu + ((x >> 16) & 1u); return (uint16_t)(x >> 16); }
 static float bf2f(uint16_t h) { uint32_t x = (uint32_t)h << 16; float f; memcpy(&f, &x, 4); return f; }
 
-template <int BN, int SCHED>
+template <int BN, int SCHED, int PR = 0>
 static void launch(hipStream_t st, const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K) {
   const int tiles_m = (M + 255) / 256, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
   const size_t lds = (size_t)4 * (256 + BN) * 64;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)nt1w_kernel<BN, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  if (!attr) { (void)hipFuncSetAttribute((const void*)nt1w_kernel<BN, SCHED, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   const int grid = SCHED >= 2 ? (ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256) : ntiles;
-  hipLaunchKernelGGL((nt1w_kernel<BN, SCHED>), dim3(grid), dim3(256), lds, st, A, K, B, K, C, N, M, N, K, tiles_n, ntiles);
+  hipLaunchKernelGGL((nt1w_kernel<BN, SCHED, PR>), dim3(grid), dim3(256), lds, st, A, K, B, K, C, N, M, N, K, tiles_n, ntiles);
 }
 
-int main() {
+int main(int argc, char** argv) {
   struct Shape { int M, N, K; const char* what; };
-  const Shape shapes[] = {{8192, 21128, 768, "classifier"}, {8192, 3072, 768, "ffn-up"}, {8192, 2304, 768, "qkv"}, {8192, 768, 3072, "ffn-down"},
-                          {1000, 776, 128, "ragged M, N"}, {8192, 768, 21184, "classifier dgrad"}};
+  const Shape all_shapes[] = {{8192, 21128, 768, "classifier"}, {8192, 3072, 768, "ffn-up"}, {8192, 2304, 768, "qkv"}, {8192, 768, 3072, "ffn-down"},
+                              {1000, 776, 128, "ragged M, N"}, {8192, 768, 21184, "classifier dgrad"}};
+  const bool quick = argc > 1 && !strcmp(argv[1], "quick");          // quick: two shapes + the ablations
+  std::vector<Shape> shapes(all_shapes, all_shapes + (quick ? 2 : 6));
   hipStream_t st; (void)hipStreamCreate(&st);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   size_t total_bad = 0;
@@ -352,6 +365,27 @@ int main() {
       fflush(stdout);
     }
     (void)hipFree(pool); (void)hipFree(drows); (void)hipFree(dref);
+  }
+  {  // timing-only ablations of the interleaved step on the long-K shape (96 / 128 tiles: every workgroup alone on its CU, steady state)
+    const int M = 8192, N = 768, K = 21184;
+    const size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * N;
+    uint16_t* buf; (void)hipMalloc(&buf, (na + nb + nc) * 2);
+    (void)hipMemset(buf, 0, (na + nb + nc) * 2);
+    auto time = [&](auto fn) {
+      for (int i = 0; i < 2; ++i) fn();
+      (void)hipEventRecord(e0, st);
+      for (int i = 0; i < 6; ++i) fn();
+      (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
+      float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+      return ms * 1000.0 / 6;
+    };
+    const double steps = K / 32.0;
+#define RL_ABL(BNV, PRV, what) { const double us = time([&]() { launch<BNV, 1, PRV>(st, buf, buf + na, buf + na + nb, M, N, K); }); \
+      printf("ablation 256x%d %-28s %7.1f us = %6.0f ns per 32-deep step (MFMA issue alone: %d x 16 clk)\n", BNV, what, us, us * 1000.0 / steps, 8 * (BNV / 32)); fflush(stdout); }
+    RL_ABL(256, 0, "full") RL_ABL(256, 1, "no barrier") RL_ABL(256, 2, "no fills") RL_ABL(256, 3, "no fragment reads") RL_ABL(256, 4, "MFMA only")
+    RL_ABL(192, 0, "full") RL_ABL(192, 1, "no barrier") RL_ABL(192, 2, "no fills") RL_ABL(192, 3, "no fragment reads") RL_ABL(192, 4, "MFMA only")
+#undef RL_ABL
+    (void)hipFree(buf);
   }
   printf("TOTAL mismatches: %zu\n", total_bad);
   return total_bad ? 2 : 0;
