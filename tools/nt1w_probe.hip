@@ -48,7 +48,7 @@ __device__ __forceinline__ void mfma_a(floatx4& c, const bf16x8_t& x, const bf16
 
 template <int BN, int SCHED, int PR>
 __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, uint16_t* __restrict__ C, int ldc,
-                                          int M, int N, int K, int tiles_n, int ntiles) {
+                                          int M, int N, int K, int tiles_n, int ntiles, int walk) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = 256, RM = 128, RN = BN / 2, MT = RM / 16, NT = RN / 16;
   constexpr int ROWS = BM + BN, STAGE = ROWS * 64, NS = 4, NPIECE = ROWS / 16, NPW = NPIECE / 4;     // 1-KiB pieces (16 rows) per step, per wave
@@ -68,7 +68,16 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
   const int kstride = PERSIST ? (int)(gridDim.x >> 3) : (1 << 30);
   int kt = blockIdx.x >> 3;
   if (kt >= xcnt) return;
-  int m0 = ((xbase + kt) / tiles_n) * BM, n0 = ((xbase + kt) % tiles_n) * BN;
+  // walk 0: the XCD's run of tile ids is row-major (consecutive tiles share an A row panel, every tile brings its own B panel).
+  // walk 1 (tiles_m % 8 == 0): the XCD owns tiles_m / 8 tile ROWS and walks them column-major - the tiles in flight on its 32 CUs are
+  // (tiles_m / 8) rows x a few columns: B panels are shared by the rows, A panels by the columns, both inside one L2.
+  const int rpx = (ntiles / tiles_n) >> 3;
+  auto tile_mn = [&](int k, int& tm0, int& tn0) {
+    if (walk == 1) { tm0 = (x8 * rpx + k % rpx) * BM; tn0 = (k / rpx) * BN; }
+    else { tm0 = ((xbase + k) / tiles_n) * BM; tn0 = ((xbase + k) % tiles_n) * BN; }
+  };
+  int m0, n0;
+  tile_mn(kt, m0, n0);
   const int nk = K >> 5;                                                  // K % 32 == 0
 
   // ---- fill: piece p = s * 4 + wave covers rows [16p, 16p + 16) of the [A rows | B rows] stage image; lane i writes LDS bytes
@@ -213,7 +222,7 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
     kt += kstride;
     const bool more = kt < xcnt;
     if (more) {
-      m0 = ((xbase + kt) / tiles_n) * BM; n0 = ((xbase + kt) % tiles_n) * BN;
+      tile_mn(kt, m0, n0);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       set_tile(m0, n0);
@@ -256,8 +265,8 @@ __device__ __forceinline__ void nt1w_body(const uint16_t* __restrict__ A, int ld
 template <int BN, int SCHED, int PR = 0>
 __global__ void __launch_bounds__(256, 1)
 nt1w_kernel(const uint16_t* __restrict__ A, int lda, const uint16_t* __restrict__ B, int ldb, uint16_t* __restrict__ C, int ldc, int M, int N, int K,
-            int tiles_n, int ntiles) {
-  nt1w_body<BN, SCHED, PR>(A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles);
+            int tiles_n, int ntiles, int walk) {
+  nt1w_body<BN, SCHED, PR>(A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ntiles, walk);
 }
 
 // plain reference: one thread per output, fp32 accumulation in k order
@@ -273,6 +282,7 @@ __global__ void ref_kernel(const uint16_t* A, int lda, const uint16_t* B, int ld
 static uint16_t f2bf(float f) { uint32_t x; memcpy(&x, &f, 4); x += 0x7fffu + ((x >> 16) & 1u); return (uint16_t)(x >> 16); }
 static float bf2f(uint16_t h) { uint32_t x = (uint32_t)h << 16; float f; memcpy(&f, &x, 4); return f; }
 
+static int g_walk = 0;
 template <int BN, int SCHED, int PR = 0>
 static void launch(hipStream_t st, const uint16_t* A, const uint16_t* B, uint16_t* C, int M, int N, int K) {
   const int tiles_m = (M + 255) / 256, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
@@ -280,7 +290,8 @@ static void launch(hipStream_t st, const uint16_t* A, const uint16_t* B, uint16_
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)nt1w_kernel<BN, SCHED, PR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   const int grid = SCHED >= 2 ? (ntiles < 256 ? ((ntiles + 7) / 8) * 8 : 256) : ntiles;
-  hipLaunchKernelGGL((nt1w_kernel<BN, SCHED, PR>), dim3(grid), dim3(256), lds, st, A, K, B, K, C, N, M, N, K, tiles_n, ntiles);
+  hipLaunchKernelGGL((nt1w_kernel<BN, SCHED, PR>), dim3(grid), dim3(256), lds, st, A, K, B, K, C, N, M, N, K, tiles_n, ntiles,
+                     (g_walk == 1 && tiles_m % 8 == 0) ? 1 : 0);
 }
 
 int main(int argc, char** argv) {
@@ -319,7 +330,10 @@ int main(int argc, char** argv) {
     std::vector<float> href((size_t)nrows * sh.N);
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(href.data(), dref, href.size() * 4, hipMemcpyDeviceToHost);
-    for (int cfg = 2; cfg < 8; ++cfg) {          // sched 0 (no interleaving) is on record in profiles/round3_nt1w_probe.log
+    for (int cfgw = 2; cfgw < (quick ? 16 : 8); ++cfgw) {          // sched 0 (no interleaving) is on record in profiles/round3_nt1w_probe.log
+      if (cfgw >= 8 && cfgw < 10) continue;
+      const int cfg = cfgw & 7;
+      g_walk = cfgw >> 3;                                            // quick mode repeats the configurations with the XCD-owned-rows walk
       const int bn = (cfg & 1) ? 192 : 256, sched = cfg >> 1;
       auto run = [&](int s) {
         uint16_t* base = pool + (size_t)(s % nsets) * set;
@@ -359,7 +373,7 @@ int main(int argc, char** argv) {
       (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
       float cold = 0.f; (void)hipEventElapsedTime(&cold, e0, e1);
       const double fl = 2.0 * sh.M * sh.N * sh.K;
-      printf("nt1w 256x%d sched %d  %5d x %5d x %5d %-18s | warm %7.1f us %5.0f TF | cold %7.1f us %5.0f TF | checked %d rows: %zu mismatches, worst |err| %.3g\n", bn, sched,
+      printf("nt1w 256x%d sched %d walk %d  %5d x %5d x %5d %-18s | warm %7.1f us %5.0f TF | cold %7.1f us %5.0f TF | checked %d rows: %zu mismatches, worst |err| %.3g\n", bn, sched, g_walk,
              sh.M, sh.N, sh.K, sh.what, warm * 1000.0 / reps, fl / (warm * 1e-3 / reps) * 1e-12, cold * 1000.0 / reps, fl / (cold * 1e-3 / reps) * 1e-12,
              nrows, bad, worst);
       fflush(stdout);
@@ -367,6 +381,7 @@ int main(int argc, char** argv) {
     (void)hipFree(pool); (void)hipFree(drows); (void)hipFree(dref);
   }
   {  // timing-only ablations of the interleaved step on the long-K shape (96 / 128 tiles: every workgroup alone on its CU, steady state)
+    g_walk = 0;
     const int M = 8192, N = 768, K = 21184;
     const size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * N;
     uint16_t* buf; (void)hipMalloc(&buf, (na + nb + nc) * 2);
@@ -387,6 +402,7 @@ int main(int argc, char** argv) {
 #undef RL_ABL
     (void)hipFree(buf);
   }
+  g_walk = 0;
   printf("TOTAL mismatches: %zu\n", total_bad);
   return total_bad ? 2 : 0;
 }
