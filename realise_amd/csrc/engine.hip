@@ -478,7 +478,9 @@ template <typename T> struct Engine : EngineBase {
     return p.total;
   }
   int bind(void* shadow, void* workspace, int64_t bytes) override {
-    if (shadow != (void*)sh) { glyph_built = false; descs_built = false; }
+    // everything the engine keeps inside the caller's shadow buffer (operand copies, the cast descriptor table, the chunk table of the
+    // fresh-gradient zero fill) is rebuilt after a re-bind to another buffer
+    if (shadow != (void*)sh) { glyph_built = false; descs_built = false; fill_built = false; n_fill = 0; }
     sh = (char*)shadow; ws = (char*)workspace; ws_bytes = bytes; pl = Plan(); have_fwd = false;
     return RL_OK;
   }

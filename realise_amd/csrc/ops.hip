@@ -737,15 +737,18 @@ template <int NB> struct BnBwd16F {
   }
 };
 
-// One-pass BatchNorm training statistics: S1 = sum w (x - K), S2 = sum w (x - K)^2 about the per-channel pivot K = the running mean
-// (what the mean has been; 0 at initialisation).  mean = K + S1 / n, var = S2 / n - (S1 / n)^2: with fp32 sums the cancellation error
+// One-pass BatchNorm training statistics: S1 = sum w (x - K), S2 = sum w (x - K)^2 about the per-channel pivot K = the first row of
+// the batch itself (round 3 pivoted on the running mean: fresh or foreign running statistics far from the batch mean made the
+// subtraction below cancel - ADVICE round 3).  mean = K + S1 / n, var = S2 / n - (S1 / n)^2: with fp32 sums the cancellation error
 // is ~1e-7 (1 + (mean - K)^2 / var) relative, far inside bf16 activations' own rounding; the fp32 parity mode keeps the two-pass form.
 struct Moments16F {
   static constexpr int NACC = 2;
-  const bf16_t* x; const float* pivot; RowW16 w;
+  const bf16_t* x; RowW16 w;
   struct Item { uint4 x; };
   struct Ctx { floatx4 klo, khi; };
-  __device__ __forceinline__ Ctx prep(int col) const { return Ctx{*(const floatx4*)(pivot + col), *(const floatx4*)(pivot + col + 4)}; }
+  // pivot K = the batch's own first row (a sample of the distribution being measured: |mean - K| is of the order of the standard
+  // deviation whatever the running statistics hold - fresh buffers, buffers loaded from another domain)
+  __device__ __forceinline__ Ctx prep(int col) const { Ctx c; unpack8(*(const uint4*)(x + col), c.klo, c.khi); return c; }
   __device__ __forceinline__ Item load(int64_t e) const { return Item{*(const uint4*)(x + e)}; }
   __device__ __forceinline__ void add(Acc16<2>& a, const Item& it, const Ctx& c, int r) const {
     floatx4 lo, hi; unpack8(it.x, lo, hi);
@@ -760,7 +763,8 @@ struct Moments16F {
 // per 32 channels: mean, rstd, scale, shift, running statistics (unbiased variance, momentum), num_batches_tracked.
 __global__ void __launch_bounds__(256) bn_fold_train_kernel(const float* __restrict__ slots, int slot_stride, int nrec, int C, float inv_n, float unbias,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-                                                             float* rmean, float* rvar, float* mean, float* rstd, float* scale, float* shift, int64_t* nbt) {
+                                                             float* rmean, float* rvar, float* mean, float* rstd, float* scale, float* shift, int64_t* nbt,
+                                                             const bf16_t* __restrict__ x0) {
   __shared__ floatx4 red[2][32][8];
   const int cq = threadIdx.x & 7, kl = threadIdx.x >> 3;
   const int c = (blockIdx.x * 8 + cq) * 4;
@@ -783,7 +787,7 @@ __global__ void __launch_bounds__(256) bn_fold_train_kernel(const float* __restr
     s1 = red[0][0][cq]; s2 = red[1][0][cq];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float d = s1[j] * inv_n, m = rmean[c + j] + d;               // the pivot was the running mean
+      const float d = s1[j] * inv_n, m = to_f<bf16_t>(x0[c + j]) + d;   // the pivot was the batch's first row (Moments16F::prep)
       const float var = fmaxf(s2[j] * inv_n - d * d, 0.f);
       const float rs = 1.0f / sqrtf(var + eps), g = gamma[c + j];
       mean[c + j] = m; rstd[c + j] = rs; scale[c + j] = g * rs; shift[c + j] = beta[c + j] - m * g * rs;
@@ -933,11 +937,11 @@ int bn_stats_train16(hipStream_t st, const bf16_t* x, int P, int C, int n_stat, 
   if (g > max_g) g = max_g;
   if ((int64_t)g * stride > COL_SLOT_FLOATS) g = COL_SLOT_FLOATS / stride;
   if (g < 1) g = 1;
-  Moments16F f{x, rmean, RowW16{rb.counts, pow2_shift(rb.hw)}};
+  Moments16F f{x, RowW16{rb.counts, pow2_shift(rb.hw)}};
   hipLaunchKernelGGL((col_reduce16_kernel<Moments16F>), dim3(g), dim3(256), 0, st, f, P, cs, rb, rb.slots, stride, 0);
   const int n = n_stat > 0 ? n_stat : P;
   hipLaunchKernelGGL(bn_fold_train_kernel, dim3((C + 31) / 32), dim3(256), 0, st, rb.slots, stride, g, C, 1.0f / (float)n,
-                     (float)n / (float)(n > 1 ? n - 1 : 1), gamma, beta, eps, momentum, rmean, rvar, mean, rstd, scale, shift, nbt);
+                     (float)n / (float)(n > 1 ? n - 1 : 1), gamma, beta, eps, momentum, rmean, rvar, mean, rstd, scale, shift, nbt, x);
   return RL_LAUNCH_CHECK();
 }
 // Two normalisations sharing dy and the ReLU mask: sums = [sum g | sum g xhat_a | sum g | sum g xhat_b] (4C floats).  Returns

@@ -60,7 +60,10 @@ def read_label_file(path):
             # LAST prediction was dropped (src/remove_de.py); such a line means "no edits" (deviation from the reference, whose own
             # reader would crash on it - ADVICE round 2)
             parts = [x for x in line.strip().rstrip(",").split(", ") if x != ""]
-            parts = [parts[0].rstrip(",")] + parts[1:] if parts else parts
+            if not parts:                   # a blank line: an unnamed sentence without edits, as before the filter above existed
+                out.append(("", []))
+                continue
+            parts = [parts[0].rstrip(",")] + parts[1:]
             edits = []
             if len(parts) == 1:
                 parts = [parts[0], "0"]

@@ -291,12 +291,14 @@ class RealiseModule(nn.Module):
         """SpellBert.build_batch (src/models.py:46-48): the BERT-only model needs nothing beyond make_features' tensors."""
         return batch
 
-    def zero_grad(self, set_to_none=False):
-        """run.py:211.  On the GPU nothing is zeroed here: the gradients are detached (``p.grad = None``, torch's own default since
-        2.0) and the engine is told that the arena holds nothing to keep - its next backward zero-fills only what it accumulates
-        into and stores the big Linear weight gradients instead of adding to them (no 680 MB memset, no read-modify-write).
-        ``flat_gradients()`` / ``bucket_views()`` / ``clip_grad_norm_()`` materialise the zeros if someone asks before that."""
-        if self._engine is not None and self._grads.is_cuda and self.lazy_zero_grad:
+    def zero_grad(self, set_to_none=True):
+        """run.py:211.  Default (``set_to_none=True``, torch's own default since 2.0): on the GPU nothing is zeroed here - the
+        gradients are detached (``p.grad = None``) and the engine is told that the arena holds nothing to keep: its next backward
+        zero-fills only what it accumulates into and stores the big Linear weight gradients instead of adding to them (no 680 MB
+        memset, no read-modify-write).  ``flat_gradients()`` / ``bucket_views()`` / ``clip_grad_norm_()`` materialise the zeros if
+        someone asks before that.  An explicit ``set_to_none=False`` is the strict form: the arena is zero-filled now and every
+        ``p.grad`` view stays attached (holders of an old view read zeros), as is ``lazy_zero_grad = False`` for every call."""
+        if set_to_none and self._engine is not None and self._grads.is_cuda and self.lazy_zero_grad:
             self._zero_pending = True
             for p in self._grad_params():
                 p.grad = None
@@ -381,6 +383,11 @@ class RealiseModule(nn.Module):
             f.zero_()
             raise IndexError("index out of range in self: a src_idx outside [0, %d) or a pho_idx outside [0, %d) reached the "
                              "model in an earlier forward" % (self.vocab_size, self._ccfg.pho_vocab))
+
+    # strict_ids = True: backward() waits for the forward's range check before it enqueues anything, so a batch with an out-of-range id
+    # raises before a single gradient or weight is touched (the reference's behaviour) at the price of one host synchronisation per
+    # step; the default polls the flag without waiting and may report a bad batch one step late.
+    strict_ids = False
 
     def check_ids(self):
         """wait for the queued steps and raise IndexError now if one of them saw an out-of-range id"""
@@ -575,7 +582,10 @@ class RealiseModule(nn.Module):
 
     def _run_backward(self, grad_out):
         lib = _capi.load()
-        self._raise_on_bad_ids()
+        if self.strict_ids:
+            self.check_ids()
+        else:
+            self._raise_on_bad_ids()
         self._begin_gradient_pass()
         if not self.assume_unit_loss_grad:
             d = self.tap_dlogits()

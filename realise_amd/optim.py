@@ -123,8 +123,10 @@ class FusedAdamW(torch.optim.Optimizer):
         """global L2 norm measured by the last step() (device tensor; reading it synchronises)"""
         return self._norm_sq.sqrt()
 
-    def zero_grad(self, set_to_none=False):
-        self.module.zero_grad(set_to_none=False)
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad: the default detaches (the module's lazy fresh-gradient pass), ``set_to_none=False``
+        zero-fills the arena now and keeps every ``p.grad`` view attached"""
+        self.module.zero_grad(set_to_none=set_to_none)
 
 
 def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, last_epoch=-1):

@@ -78,12 +78,21 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
             loss = wrapped(batch)[0]
             loss.backward()
             tr_loss += loss.detach()
+            # nn.Embedding raises on an out-of-range id before anything is updated (modeling_bert.py:183-186).  The device-side check
+            # of this step ran at the head of its forward; poll its flag (host-mapped, no synchronisation) before the weights move,
+            # or wait for it when the model runs in strict mode
+            if getattr(model, "strict_ids", False):
+                model.check_ids()
+            elif hasattr(model, "_raise_on_bad_ids"):
+                model._raise_on_bad_ids()
             opt.step()
             sched.step()
             model.zero_grad()
             step += 1
             if log_every and step % log_every == 0:
                 print("Step: %d, LR: %.3e, Loss: %.5f" % (step, sched.get_last_lr()[0], tr_loss.item() / step))
+    if hasattr(model, "check_ids"):
+        model.check_ids()                  # a bad id in the last batches must not go unreported
     return tr_loss.item() / max(1, step)
 
 
@@ -116,6 +125,8 @@ def evaluate(model, items, *, batch_size=64, max_seq_length=128, device="cuda", 
     finally:
         if was_static is not None:
             model.static_weights = was_static
+    if hasattr(model, "check_ids"):
+        model.check_ids()
     mean_loss = torch.stack(losses).mean().item()
     if label_path is None:
         return mean_loss, torch.cat(preds)
