@@ -24,8 +24,15 @@ void realise_set_nt_variant(int v);
  * keys 1 / 2 / 3 = priority class of the pinyin-branch / glyph-branch / weight-gradient stream (-1 highest, 0 device default, +1 lowest),
  * read when the engine creates the stream, i.e. to be set before the first forward; key 4 = classifier backward over the rows that
  * enter the loss only (1, default) or over all rows (0); key 5 = the backward skips the rows of padding tokens, whose gradient rows are
- * exact zeros (LayerNorm backward rows, 64-row tiles of the weight-gradient reductions; 1 default, 0 off) */
+ * exact zeros (LayerNorm backward rows, blocks of the weight-gradient reductions; 1 default: live 16-row blocks packed four to a
+ * reduction tile in bf16, 2: whole 64-row tiles only - bit-identical to 0 -, 0 off) */
 void realise_set_engine(int key, int value);
+/* realise_gemm_tn_grouped over a list of live reduction blocks, as the engine's backward calls it: live[k] (device, ascending) = index
+ * of the k-th block of `list_rows` rows that holds anything but exact zeros in the A operands, *n_live (device) = how many; the other
+ * blocks are not read.  list_rows = 64 (bf16) / 32 (fp32): whole reduction tiles; 16 (bf16): four live blocks form a reduction tile.
+ * overwrite != 0: out = result instead of out += result. */
+int realise_gemm_tn_grouped_live(void* stream, int dtype, int n, const realise_tn_problem* problems, int P, const int* live,
+                                 const int* n_live, int list_rows, int overwrite);
 /* LayerNorm backward exactly as the engine calls it (bf16): optional second output dx_drop = dx * dropout mask, per-workgroup
  * [dgamma | dbeta] records in `slots` (8 MiB scratch) folded in a fixed order.  tools/ln_probe.py times it. */
 int realise_layernorm_bwd_ex(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,

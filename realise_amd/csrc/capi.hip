@@ -59,14 +59,15 @@ static int conv_dgrad_s2(hipStream_t st, const realise_conv_geom* a, const T* B,
 }
 
 template <typename T>
-static int tn_grouped(hipStream_t st, int n, const realise_tn_problem* pr, int P) {
+static int tn_grouped(hipStream_t st, int n, const realise_tn_problem* pr, int P, const int* live = nullptr, const int* n_live = nullptr,
+                      int list_rows = 0, int overwrite = 0) {
   if (n < 1 || n > TN_GROUP_MAX || pr == nullptr) return RL_ERR_ARG;
   TnGroupProblem<T> g[TN_GROUP_MAX];
   for (int k = 0; k < n; ++k) {
     g[k].A = (const T*)pr[k].A; g[k].lda = pr[k].lda; g[k].B = (const T*)pr[k].B; g[k].ldb = pr[k].ldb;
     g[k].I = pr[k].I; g[k].J = pr[k].J; g[k].out = pr[k].out; g[k].ldo = pr[k].ldo; g[k].colsum = pr[k].colsum;
   }
-  return gemm_tn_group<T>(st, n, g, P);
+  return gemm_tn_group<T>(st, n, g, P, 1.0f, overwrite, live, n_live, list_rows);
 }
 
 extern "C" {
@@ -109,6 +110,14 @@ int realise_gemm_tn_grouped(void* stream, int dtype, int n, const realise_tn_pro
   hipStream_t st = (hipStream_t)stream;
   if (dtype == REALISE_BF16) return tn_grouped<bf16_t>(st, n, problems, P);
   if (dtype == REALISE_F32) return tn_grouped<float>(st, n, problems, P);
+  return RL_ERR_ARG;
+}
+int realise_gemm_tn_grouped_live(void* stream, int dtype, int n, const realise_tn_problem* problems, int P, const int* live,
+                                 const int* n_live, int list_rows, int overwrite) {
+  hipStream_t st = (hipStream_t)stream;
+  if (live == nullptr || n_live == nullptr) return RL_ERR_ARG;
+  if (dtype == REALISE_BF16) return tn_grouped<bf16_t>(st, n, problems, P, live, n_live, list_rows, overwrite);
+  if (dtype == REALISE_F32) return tn_grouped<float>(st, n, problems, P, live, n_live, list_rows, overwrite);
   return RL_ERR_ARG;
 }
 int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const realise_conv_geom* b, int P, int Co, int Ci,

@@ -47,7 +47,8 @@ void set_fwd_order(int o) { g_fwd_order = o; }
 // Priority classes of the engine-owned streams, applied when a stream is created (realise_set_engine keys 1..3, before the first
 // forward): 0 = the device default, -1 = the highest priority the device offers, +1 = the lowest.  [0] pinyin branch, [1] glyph
 // branch, [2] weight-gradient side stream.
-static int g_skip_dead = 1;       // backward skips the rows of padding tokens: LayerNorm backward rows, 64-row tiles of the weight-gradient reductions (key 5)
+static int g_skip_dead = 1;       // backward skips the rows of padding tokens: LayerNorm backward rows, blocks of the weight-gradient reductions (key 5;
+                                  // 1: 16-row blocks in bf16, 2: whole 64-row tiles - the round-3 form, bit-identical to no skipping -, 0: off)
 void set_skip_dead(int on) { g_skip_dead = on; }
 static int g_cls_compact = 1;     // classifier backward over the rows that enter the loss only (realise_set_engine key 4)
 void set_cls_compact(int on) { g_cls_compact = on; }
@@ -112,7 +113,7 @@ template <typename T> struct Engine : EngineBase {
     BlockAct blk[5];
     int64_t mask_add, out_d, dlogits, count, loss_internal;
     int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc;
-    int64_t row_live, live_t64, live_t32, live_n, live_rlen;          // padding rows: exact-zero gradient rows the backward skips (row_liveness)     // classifier backward over the rows that enter the loss only (stage_head)
+    int64_t row_live, live_t64, live_t32, live_t16, live_n, live_rlen;          // padding rows: exact-zero gradient rows the backward skips (row_liveness)     // classifier backward over the rows that enter the loss only (stage_head)
     int64_t ids_clean = 0, pho_clean = 0;                 // range-checked copies of src_idx / pho_idx (sanitize_ids)
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
     int64_t res_xhat, res_rstd, res_h, gate_mean, gate_msum, gate_g, fused;
@@ -192,8 +193,10 @@ template <typename T> struct Engine : EngineBase {
   bool have_fwd = false;
   bool dead_ok = false;                    // the last forward produced the row-liveness tables (training batch, B * S % 64 == 0)
   const uint8_t* live_rows() const { return dead_ok ? wp<uint8_t>(pl.row_live) : nullptr; }
-  const int* live_tiles() const { return dead_ok ? wp<int>(sizeof(T) == 2 ? pl.live_t64 : pl.live_t32) : nullptr; }
-  const int* live_tile_count() const { return dead_ok ? wp<int>(pl.live_n) + (sizeof(T) == 2 ? 0 : 1) : nullptr; }
+  bool live16() const { return sizeof(T) == 2 && g_skip_dead == 1; }
+  const int* live_tiles() const { return dead_ok ? wp<int>(sizeof(T) == 2 ? (live16() ? pl.live_t16 : pl.live_t64) : pl.live_t32) : nullptr; }
+  const int* live_tile_count() const { return dead_ok ? wp<int>(pl.live_n) + (sizeof(T) == 2 ? (live16() ? 2 : 0) : 1) : nullptr; }
+  int live_list_rows() const { return sizeof(T) == 2 ? (live16() ? 16 : 64) : 32; }
   bool cls_compact = false;                // the last forward wrote compacted classifier-gradient rows (stage_head must match)
 
   template <typename U> U* wp(int64_t off) const { return (U*)(ws + off); }
@@ -378,7 +381,7 @@ template <typename T> struct Engine : EngineBase {
     p.count = b.take(256);
     p.loss_internal = b.take(Tk * 4 + 256);       // per-row loss terms (ordered fold: reproducible loss)
     p.cls_act = b.take(Tk * 4); p.cls_inv = b.take(Tk * 4); p.cls_nact = b.take(256);
-    p.row_live = b.take(Tk + 64); p.live_t64 = b.take((Tk / 32 + 2) * 4); p.live_t32 = b.take((Tk / 32 + 2) * 4); p.live_n = b.take(256); p.live_rlen = b.take(B * 4 + 64);
+    p.row_live = b.take(Tk + 64); p.live_t64 = b.take((Tk / 32 + 2) * 4); p.live_t32 = b.take((Tk / 32 + 2) * 4); p.live_t16 = b.take((Tk / 16 + 4) * 4); p.live_n = b.take(256); p.live_rlen = b.take(B * 4 + 64);
     p.cls_xc = b.take(Tk * H * e); p.cls_gc = b.take(Tk * H * e);
     p.zero_once.push_back({p.cls_xc, Tk * H * e}); p.zero_once.push_back({p.cls_gc, Tk * H * e});
     // shared backward scratch
@@ -669,7 +672,7 @@ template <typename T> struct Engine : EngineBase {
           if (hipEventRecord(ev_ready[p][3], st) != hipSuccess || hipStreamWaitEvent(side, ev_ready[p][3], 0) != hipSuccess) return RL_ERR_LAUNCH;
           ws_ = side;
         }
-        RL_TRY(gemm_tn_group<T>(ws_, 4, gp4, Tk, 1.0f, pass_overwrite ? 1 : 0, live_tiles(), live_tile_count()));
+        RL_TRY(gemm_tn_group<T>(ws_, 4, gp4, Tk, 1.0f, pass_overwrite ? 1 : 0, live_tiles(), live_tile_count(), live_list_rows()));
       }
       {  // d x_in = d s1 + d qkv . W_qkv
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H; ep.accumulate = 1;
@@ -1009,7 +1012,7 @@ template <typename T> struct Engine : EngineBase {
       // activation row there is an exact zero (the embedding scatter has relied on it since round 1).  The backward skips them:
       // LayerNorm backward rows, whole 64-row tiles of the weight-gradient reductions.
       dead_ok = g_skip_dead && b.want_dlogits && b.masks != nullptr && (Tk % 64) == 0;
-      if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_n), wp<int>(pl.live_rlen)));
+      if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_t16), wp<int>(pl.live_n), wp<int>(pl.live_rlen)));
       cls_compact = g_cls_compact && b.want_dlogits && Tk <= 65536;
       CeCompact cc;
       if (cls_compact) { cc.act_idx = wp<int>(pl.cls_act); cc.inv = wp<int>(pl.cls_inv); cc.n_act = wp<int>(pl.cls_nact); }

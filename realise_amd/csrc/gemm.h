@@ -278,6 +278,9 @@ struct TnEpi {
   // rows of the other blocks are skipped - the gradient rows of padding tokens are exact zeros (engine.hip row_liveness).
   const int* tile_list = nullptr;
   const int* n_tiles = nullptr;
+  // rows per list entry: BP (whole reduction tiles), or 16 (bf16, grouped 128 x 128 kernel): entries name live 16-row blocks and a
+  // reduction tile is any four of them (wave w of the workgroup fetches the w-th) - the last tile is padded with zero blocks
+  int list_rows = 0;
 };
 
 // Grouped TN (weight-gradient) launch: problems sharing the reduction length P, one 128x128 tile per workgroup, no reduction split.
@@ -296,10 +299,11 @@ template <typename T> struct TnGroup {
   float alpha = 1.0f;
   const int* tile_list = nullptr;      // live reduction tiles (see TnEpi)
   const int* n_tiles = nullptr;
+  int list_rows = 0;
 };
 template <typename T>
 int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha = 1.0f, int overwrite = 0,
-                  const int* tile_list = nullptr, const int* n_tiles = nullptr);
+                  const int* tile_list = nullptr, const int* n_tiles = nullptr, int list_rows = 0);
 
 // C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)
 template <typename T>

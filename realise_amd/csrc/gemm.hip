@@ -562,6 +562,9 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
   // live-tile list (unsplit dense reductions): the t-th tile of the loop is block tile_list[t] of the rows
   constexpr bool kDenseB0 = sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
   const bool listed = kDenseB0 && ep.tile_list != nullptr && nsplit == 1;
+  // 16-row form of the list (bf16, 128 x 128 tiles: wave w fetches rows 16w .. 16w + 15 of both operand tiles): a reduction tile is
+  // any FOUR live 16-row blocks, wave w takes block list[4 t + w] - 68 % instead of 84 % of the rows of a SIGHAN-shaped batch
+  const bool sub16 = listed && ep.list_rows == 16 && sizeof(T) == 2 && WI == 2 && WJ == 2 && BPD == 1;
 
   // per-lane chunk coordinates are the same for every reduction tile: only the row base moves
   constexpr bool kDenseB = sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos);
@@ -614,7 +617,7 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
   int64_t inca[NA], incb[NB];
 #pragma unroll
   for (int q = 0; q < NA; ++q) {
-    pa[q] = acol[q] != nullptr ? (const char*)(acol[q] + (int64_t)(p_begin + apl[q]) * lda) : (const char*)zero;
+    pa[q] = acol[q] != nullptr ? (const char*)(acol[q] + (int64_t)(p_begin + (sub16 ? apl[q] - 16 * wave : apl[q])) * lda) : (const char*)zero;
     inca[q] = acol[q] != nullptr ? (int64_t)BP * lda * (int64_t)sizeof(T) : 0;
   }
   if constexpr (kDenseB) {
@@ -625,15 +628,32 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
       const char* r0 = (const char*)lb.addr(c0, bq[q], zero);
       const char* r1 = (const char*)lb.addr(c1, bq[q], zero);
       const int64_t ldb_bytes = r1 - r0;                                       // row pitch of the dense B operand
-      pb[q] = bok[q] ? r0 + (int64_t)(p_begin + bpl[q]) * ldb_bytes : (const char*)zero;
+      pb[q] = bok[q] ? r0 + (int64_t)(p_begin + (sub16 ? bpl[q] - 16 * wave : bpl[q])) * ldb_bytes : (const char*)zero;
       incb[q] = bok[q] ? (int64_t)BP * ldb_bytes : 0;
     }
   }
   int ptr_tile = p_begin / BP;           // the reduction tile pa / pb point at (live-tile list mode)
+  int ptr_sub = 0;                       // sub16: the 16-row block this wave's pointers stand on
+  bool sub_ok = true;                    // sub16: this wave has a block in the tile being issued (the last tile may hold fewer than four)
   auto issue = [&](int pt, int stage) {
     if (RL_PROBES && ep.probe == 2) return;
     char* base = smem + stage * STAGE;
-    const bool full = pt + BP <= p_end;
+    const bool full = sub16 || pt + BP <= p_end;
+    if (sub16) {
+      // pt = this wave's block index (wave-uniform) or -1.  Blocks are mostly 4 apart (consecutive tiles of live rows): the running
+      // pointers advance by one tile after every issue and only the difference to that is applied here
+      sub_ok = pt >= 0;
+      const int d = sub_ok ? pt - ptr_sub : 0;
+      if (d != 0) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) pa[q] += (inca[q] >> 2) * (int64_t)d;
+        if constexpr (kDenseB) {
+#pragma unroll
+          for (int q = 0; q < NB; ++q) pb[q] += (incb[q] >> 2) * (int64_t)d;
+        }
+      }
+      ptr_sub = (sub_ok ? pt : ptr_sub) + 4;
+    } else
     // listed tiles are not consecutive: the pointers are rebuilt from the tile's first row (pa / pb hold the addresses of row 0 then)
     if (listed) {
       // listed tiles are mostly consecutive: the running pointers only jump (a wave-uniform number of tiles) over a run of dead blocks
@@ -652,6 +672,7 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
     for (int q = 0; q < NA; ++q) {
       const void* src = pa[q];
       if (!full && pt + apl[q] >= p_end) src = zero;
+      if (sub16 && !sub_ok) src = zero;
       glds16(src, base + (wave * NA + q) * 1024);
       pa[q] += inca[q];
     }
@@ -661,6 +682,7 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
       if constexpr (kDenseB) {
         src = pb[q];
         if (!full && pt + bpl[q] >= p_end) src = zero;
+        if (sub16 && !sub_ok) src = zero;
         pb[q] += incb[q];
       } else {
         const int p = pt + bpl[q];
@@ -672,14 +694,19 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
   };
 
   constexpr int NL = NA + NB;                          // fetch instructions per wave per tile
-  const int nt = listed ? min(*ep.n_tiles, (p_end - p_begin) / BP) : (p_end - p_begin + BP - 1) / BP;
+  const int n_list = listed ? *ep.n_tiles : 0;
+  const int nt = sub16 ? min((n_list + 3) >> 2, (p_end - p_begin) / BP) : listed ? min(n_list, (p_end - p_begin) / BP) : (p_end - p_begin + BP - 1) / BP;
   int issued = 0;
   // the live-tile list is read 64 entries at a time into one register per lane (a load per tile would sit in front of every issue)
-  int list_reg = (listed && lane < nt) ? ep.tile_list[lane] : 0;
+  const int n_ent = sub16 ? min(n_list, 4 * nt) : nt;
+  int list_reg = (listed && lane < n_ent) ? ep.tile_list[lane] : -1;
   auto issue_next = [&]() {
     if (issued < nt) {
       int pt = p_begin + issued * BP;
-      if (listed) {
+      if (sub16) {
+        if (issued != 0 && (issued & 15) == 0) list_reg = (4 * issued + lane < n_ent) ? ep.tile_list[4 * issued + lane] : -1;
+        pt = __builtin_amdgcn_readlane(list_reg, ((issued & 15) << 2) + wave);
+      } else if (listed) {
         if (issued != 0 && (issued & 63) == 0) list_reg = (issued + lane < nt) ? ep.tile_list[issued + lane] : 0;
         pt = __builtin_amdgcn_readlane(list_reg, issued & 63) * BP;
       }
@@ -766,7 +793,7 @@ gemm_tn_group_kernel(TnGroup<T> grp, int P, int pchunk) {
   DenseLoader<T> lb{pr.B, pr.ldb, P, pr.J};
   TnEpi ep;
   ep.out = pr.out; ep.ldo = pr.ldo; ep.colsum = pr.colsum; ep.alpha = grp.alpha; ep.probe = grp.probe; ep.overwrite = grp.overwrite;
-  ep.tile_list = grp.tile_list; ep.n_tiles = grp.n_tiles;
+  ep.tile_list = grp.tile_list; ep.n_tiles = grp.n_tiles; ep.list_rows = grp.list_rows;
   tn_tile_body<T, DenseLoader<T>, TR, 2, 2, NST, BPD>(pr.A, pr.lda, lb, P, pr.I, pr.J, pr.tiles_j, pr.ntiles, 1, pchunk, TN_OUT_DIRECT, ep,
                                                       logical - pr.tile_begin);
 }
@@ -934,12 +961,13 @@ void set_tn_group_ring(int on) { g_tn_group_ring = on; }
 
 template <typename T>
 int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha, int overwrite, const int* tile_list,
-                  const int* n_tiles) {
+                  const int* n_tiles, int list_rows) {
   typedef TnGeo<T> G;
   if (n < 1 || n > TN_GROUP_MAX || P <= 0) return RL_ERR_ARG;
   TnGroup<T> grp;
   grp.n = n; grp.alpha = alpha; grp.probe = g_tn_probe; grp.overwrite = overwrite;
-  if (tile_list != nullptr && n_tiles != nullptr && (P % G::BP) == 0 && !g_tn_group_ring) { grp.tile_list = tile_list; grp.n_tiles = n_tiles; }
+  if (list_rows != 0 && list_rows != G::BP && !(list_rows == 16 && sizeof(T) == 2)) return RL_ERR_ARG;
+  if (tile_list != nullptr && n_tiles != nullptr && (P % G::BP) == 0 && !g_tn_group_ring) { grp.tile_list = tile_list; grp.n_tiles = n_tiles; grp.list_rows = list_rows ? list_rows : G::BP; }
   int total = 0;
   double flops = 0.0;
   for (int k = 0; k < n; ++k) {
@@ -968,8 +996,8 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
 #undef RL_TN_GROUP
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
-template int gemm_tn_group<bf16_t>(hipStream_t, int, const TnGroupProblem<bf16_t>*, int, float, int, const int*, const int*);
-template int gemm_tn_group<float>(hipStream_t, int, const TnGroupProblem<float>*, int, float, int, const int*, const int*);
+template int gemm_tn_group<bf16_t>(hipStream_t, int, const TnGroupProblem<bf16_t>*, int, float, int, const int*, const int*, int);
+template int gemm_tn_group<float>(hipStream_t, int, const TnGroupProblem<float>*, int, float, int, const int*, const int*, int);
 
 template <typename T>
 int gemm_tn(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int P, int I, int J, const TnEpi& ep,

@@ -999,11 +999,11 @@ __device__ __forceinline__ float block_reduce(float v, float* sm, bool is_max) {
   return r;
 }
 
-// row_liveness (ops.h): one workgroup.  Phase 1: last flagged position of every sentence; phase 2: row bytes; phase 3: the 64- and
-// 32-row block lists by ballot + prefix scan (ascending, deterministic).
+// row_liveness (ops.h): one workgroup.  Phase 1: last flagged position of every sentence; phase 2: row bytes; phase 3: the 64-,
+// 32- and 16-row block lists by ballot + prefix scan (ascending, deterministic).
 __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __restrict__ masks, const int64_t* __restrict__ loss_masks, int B, int S,
                                                              uint8_t* __restrict__ row_live, int* __restrict__ tiles64, int* __restrict__ tiles32,
-                                                             int* __restrict__ n_tiles, int* __restrict__ rlen) {
+                                                             int* __restrict__ tiles16, int* __restrict__ n_tiles, int* __restrict__ rlen) {
   __shared__ int wsum[16];
   __shared__ int base_s;
   const int T = B * S, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1021,9 +1021,10 @@ __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __res
   }
   __syncthreads();
   // phase 3: block lists
-  for (int pass = 0; pass < 2; ++pass) {
-    const int bp = pass ? 32 : 64;
-    int* out = pass ? tiles32 : tiles64;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int bp = 64 >> pass;
+    int* out = pass == 0 ? tiles64 : (pass == 1 ? tiles32 : tiles16);
+    if (out == nullptr) continue;
     if (threadIdx.x == 0) base_s = 0;
     __syncthreads();
     const int nblk = T / bp;
@@ -1051,9 +1052,9 @@ __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __res
   }
 }
 int row_liveness(hipStream_t st, const int64_t* masks, const int64_t* loss_masks, int B, int S, uint8_t* row_live, int* tiles64, int* tiles32,
-                 int* n_tiles, int* rlen) {
+                 int* tiles16, int* n_tiles, int* rlen) {
   if (B < 1 || S < 1 || ((int64_t)B * S) % 64 != 0 || masks == nullptr) return RL_ERR_ARG;
-  hipLaunchKernelGGL(row_liveness_kernel, dim3(1), dim3(1024), 0, st, masks, loss_masks, B, S, row_live, tiles64, tiles32, n_tiles, rlen);
+  hipLaunchKernelGGL(row_liveness_kernel, dim3(1), dim3(1024), 0, st, masks, loss_masks, B, S, row_live, tiles64, tiles32, tiles16, n_tiles, rlen);
   return RL_LAUNCH_CHECK();
 }
 

@@ -169,3 +169,11 @@ def test_evaluate_plumbing_writes_label_files_and_scores(tmp_path):
     assert res["sent-detect-f1"] == pytest.approx(100.0)             # positions all found
     assert res["sent-correct-p"] == pytest.approx(50.0) and res["sent-correct-r"] == pytest.approx(50.0)
     assert res["sent-correct-acc"] == pytest.approx(100.0 * 2 / 3)
+
+
+def test_label_reader_keeps_blank_lines_and_trailing_comma_lines(tmp_path):
+    """a blank line is an unnamed sentence without edits (it raised IndexError), ``id, `` / ``id,`` mean: no edits"""
+    from realise_amd.metric import read_label_file
+    f = tmp_path / "labels.txt"
+    f.write_text("A1, 3, x, 1, y\n\nA2, 0\nA3, \nA4,\n", encoding="utf-8")
+    assert read_label_file(str(f)) == [("A1", [(1, "y"), (3, "x")]), ("", []), ("A2", []), ("A3", []), ("A4", [])]

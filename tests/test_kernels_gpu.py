@@ -189,6 +189,47 @@ def test_gemm_tn_grouped(dt, Pn, shapes):
     assert lib.realise_gemm_tn_grouped(stream(), code, 5, probs, Pn) != 0          # more than 4 problems is an argument error
 
 
+@pytest.mark.parametrize("n_live16", [0, 1, 6, 37, 128])
+def test_gemm_tn_grouped_over_live_16_row_blocks(n_live16):
+    """the engine's weight-gradient reduction over the LIVE rows of a padded batch (bf16): the rows of the dead 16-row blocks are exact
+    zeros in dY, the list names the live blocks, four of them (any four) form a reduction tile - equal to the dense reduction; also in
+    the whole-tile form (list_rows = 64) and with overwrite."""
+    lib = _capi.load()
+    code, tdt, tol = DT["bf16"]
+    Pn, shapes = 2048, [(768, 768), (256, 384), (136, 200)]
+    g = torch.Generator().manual_seed(100 + n_live16)
+    live = torch.sort(torch.randperm(Pn // 16, generator=g)[:n_live16]).values.int()
+    rowmask = torch.zeros(Pn, 1)
+    for b in live.tolist():
+        rowmask[16 * b:16 * b + 16] = 1.0
+    for list_rows, overwrite in ((16, 0), (16, 1), (64, 0)):
+        if list_rows == 64:
+            lst = torch.unique(live // 4).int()
+        else:
+            lst = live
+        probs = (_capi.TnProblem * len(shapes))()
+        keep, outs, refs, css = [], [], [], []
+        for k, (I, J) in enumerate(shapes):
+            a = (rnd((Pn, I), 31 + k) * rowmask).to(dev()).to(tdt)
+            b = rnd((Pn, J), 41 + k).to(dev()).to(tdt)
+            base = rnd((I, J), 51 + k).to(dev())
+            out = base.clone()
+            cs = torch.full((I,), 0.25, device=dev())
+            keep += [a, b]
+            outs.append(out); css.append((cs, a))
+            refs.append(a.float().t() @ b.float() + (0.0 if overwrite else 1.0) * base)
+            probs[k].A, probs[k].lda, probs[k].B, probs[k].ldb = a.data_ptr(), I, b.data_ptr(), J
+            probs[k].I, probs[k].J, probs[k].out, probs[k].ldo = I, J, out.data_ptr(), J
+            probs[k].colsum = cs.data_ptr()
+        lst_d = torch.cat([lst, torch.full((8,), 10 ** 6, dtype=torch.int32)]).to(dev())      # poison behind the count: must never be read as a block
+        n_d = torch.tensor([lst.numel()], dtype=torch.int32, device=dev())
+        _capi.check(lib.realise_gemm_tn_grouped_live(stream(), code, len(shapes), probs, Pn, P(lst_d), P(n_d), list_rows, overwrite), "gemm_tn_grouped_live")
+        for k in range(len(shapes)):
+            close(outs[k], refs[k], 3e-3, "live-list problem %d rows %d overwrite %d" % (k, list_rows, overwrite))
+            cs, a = css[k]
+            close(cs, a.float().sum(0) + 0.25, 3e-3, "live-list column sums %d" % k)
+
+
 # ------------------------------------------------------------------------------------------ conv
 def _geom(src, index, rows, Hr, Hs, Cc, k, stride, pad, mode):
     g = _capi.ConvGeom()

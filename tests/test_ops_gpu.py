@@ -172,6 +172,33 @@ def test_batchnorm_engine_form_with_glyph_multiplicities(mode):
         assert (dgam.cpu() - s2).abs().max().item() < 1e-3 * s2.abs().max().item() + 1e-2
 
 
+def test_batchnorm_one_pass_statistics_with_running_mean_far_from_the_batch():
+    """the one-pass statistics (sum (x - K), sum (x - K)^2) must not depend on where the RUNNING mean is.  Activations
+    with |mean| >> std (offsets of +-100, unit spread) and fresh running buffers (0 / 1): pivoted on the running mean, S2 / n - d^2
+    cancels 4 digits and the variance is off by > 10 %; pivoted on a row of the batch itself it matches the two-pass formulas."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(5)
+    images, hw, Cc = 200, 64, 64
+    P = images * hw
+    bf = torch.bfloat16
+    x = (torch.randn(P, Cc, generator=g) * 1.0 + 100.0 * torch.where(torch.arange(Cc) % 2 == 0, 1.0, -1.0)).to(bf)
+    counts = torch.ones(images)
+    xf = x.float()
+    m_ref, var_ref = xf.mean(0), xf.var(0, unbiased=False)
+    gamma, beta = torch.ones(Cc), torch.zeros(Cc)
+    slots = torch.empty(262144, device="cuda")
+    rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    mean, rstd, sc, sh, sq = (torch.empty(Cc, device="cuda") for _ in range(5))
+    nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _capi.check(lib.realise_batchnorm_stats_ex(st(), p(dev(x, bf)), P, Cc, hw, p(dev(counts)), P, p(dev(gamma)), p(dev(beta)), 1e-5, 0.1, p(rm), p(rv), p(nbt),
+                                               p(mean), p(rstd), p(sc), p(sh), p(sq), p(slots)), "bn stats")
+    torch.cuda.synchronize()
+    rs_ref = 1.0 / torch.sqrt(var_ref + 1e-5)
+    assert (mean.cpu() - m_ref).abs().max().item() < 1e-3
+    assert ((rstd.cpu() - rs_ref) / rs_ref).abs().max().item() < 1e-3
+    assert (rv.cpu() - (0.9 + 0.1 * var_ref * P / (P - 1))).abs().max().item() < 1e-3
+
+
 def test_batchnorm_eval_uses_running_statistics():
     lib = _capi.load()
     P, Cc = 4096, 128
