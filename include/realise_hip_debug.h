@@ -25,12 +25,17 @@ void realise_set_nt_variant(int v);
  * read when the engine creates the stream, i.e. to be set before the first forward; key 4 = classifier backward over the rows that
  * enter the loss only (1, default) or over all rows (0); key 5 = the backward skips the rows of padding tokens, whose gradient rows are
  * exact zeros (LayerNorm backward rows, blocks of the weight-gradient reductions; 1 default: live 16-row blocks packed four to a
- * reduction tile in bf16, 2: whole 64-row tiles only - bit-identical to 0 -, 0 off) */
+ * reduction tile in bf16, 2: whole 64-row tiles only - bit-identical to 0 -, 0 off); key 6 = K-ranges of the split-K classifier data
+ * gradient (bf16; default 3, 0 / 1 = one launch over the whole K = 21184) */
 void realise_set_engine(int key, int value);
 /* realise_gemm_tn_grouped over a list of live reduction blocks, as the engine's backward calls it: live[k] (device, ascending) = index
  * of the k-th block of `list_rows` rows that holds anything but exact zeros in the A operands, *n_live (device) = how many; the other
  * blocks are not read.  list_rows = 64 (bf16) / 32 (fp32): whole reduction tiles; 16 (bf16): four live blocks form a reduction tile.
  * overwrite != 0: out = result instead of out += result. */
+/* Split-K form of the 8-wave NT GEMM as the classifier's data gradient uses it (bf16, K % 64 == 0): slab[s][m][n] (fp32, row pitch N,
+ * plane pitch slab_stride floats) = A[m, K-range s] . B[n, K-range s]^T; rows at or beyond *m_dev (device, nullable) are not computed. */
+int realise_gemm_nt_splitk(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int nsplit,
+                           float* slab, int64_t slab_stride, const int* m_dev);
 int realise_gemm_tn_grouped_live(void* stream, int dtype, int n, const realise_tn_problem* problems, int P, const int* live,
                                  const int* n_live, int list_rows, int overwrite);
 /* LayerNorm backward exactly as the engine calls it (bf16): optional second output dx_drop = dx * dropout mask, per-workgroup

@@ -112,6 +112,10 @@ int realise_gemm_tn_grouped(void* stream, int dtype, int n, const realise_tn_pro
   if (dtype == REALISE_F32) return tn_grouped<float>(st, n, problems, P);
   return RL_ERR_ARG;
 }
+int realise_gemm_nt_splitk(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int nsplit,
+                           float* slab, int64_t slab_stride, const int* m_dev) {
+  return gemm_nt8_splitk((hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, nsplit, slab, slab_stride, m_dev);
+}
 int realise_gemm_tn_grouped_live(void* stream, int dtype, int n, const realise_tn_problem* problems, int P, const int* live,
                                  const int* n_live, int list_rows, int overwrite) {
   hipStream_t st = (hipStream_t)stream;
@@ -139,7 +143,7 @@ void realise_set_nt_group_m(int g) { set_nt8_group_m(g); }
 void realise_set_ln(int key, int value) {
   if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); else if (key == 2) set_bn_fast(value); else if (key == 3) set_bn_chunks(value);
 }
-void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); else if (key >= 1 && key <= 3) set_stream_priority(key - 1, value); else if (key == 4) set_cls_compact(value); else if (key == 5) set_skip_dead(value); }
+void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); else if (key >= 1 && key <= 3) set_stream_priority(key - 1, value); else if (key == 4) set_cls_compact(value); else if (key == 5) set_skip_dead(value); else if (key == 6) set_cls_splitk(value); }
 void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); else if (key == 2) set_nt8_single_round(value); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }

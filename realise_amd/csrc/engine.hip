@@ -52,6 +52,11 @@ static int g_skip_dead = 1;       // backward skips the rows of padding tokens: 
 void set_skip_dead(int on) { g_skip_dead = on; }
 static int g_cls_compact = 1;     // classifier backward over the rows that enter the loss only (realise_set_engine key 4)
 void set_cls_compact(int on) { g_cls_compact = on; }
+// Split-K of the classifier's data gradient (realise_set_engine key 6; bf16, compacted rows): K = 21184 vocabulary columns, N = 768,
+// ~4.9 k live rows are 156 tiles of 128 x 192 on 512 workgroup slots - three K-ranges fill them (468), the fp32 partial planes are
+// folded in plane order by the scatter that follows anyway.  0 = off (one launch over the whole K).
+static int g_cls_splitk = 3;
+void set_cls_splitk(int n) { g_cls_splitk = n < 0 ? 0 : (n > 4 ? 4 : n); }
 static int g_stream_pri[3] = {0, 0, 0};
 void set_stream_priority(int which, int pri) { if (which >= 0 && which < 3) g_stream_pri[which] = pri < 0 ? -1 : (pri > 0 ? 1 : 0); }
 static hipError_t create_stream(hipStream_t* s, int which) {
@@ -112,7 +117,7 @@ template <typename T> struct Engine : EngineBase {
     StackAct bert, pho, outb;
     BlockAct blk[5];
     int64_t mask_add, out_d, dlogits, count, loss_internal;
-    int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc;
+    int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc, cls_slab;
     int64_t row_live, live_t64, live_t32, live_t16, live_n, live_rlen;          // padding rows: exact-zero gradient rows the backward skips (row_liveness)     // classifier backward over the rows that enter the loss only (stage_head)
     int64_t ids_clean = 0, pho_clean = 0;                 // range-checked copies of src_idx / pho_idx (sanitize_ids)
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
@@ -384,6 +389,7 @@ template <typename T> struct Engine : EngineBase {
     p.row_live = b.take(Tk + 64); p.live_t64 = b.take((Tk / 32 + 2) * 4); p.live_t32 = b.take((Tk / 32 + 2) * 4); p.live_t16 = b.take((Tk / 16 + 4) * 4); p.live_n = b.take(256); p.live_rlen = b.take(B * 4 + 64);
     p.cls_xc = b.take(Tk * H * e); p.cls_gc = b.take(Tk * H * e);
     p.zero_once.push_back({p.cls_xc, Tk * H * e}); p.zero_once.push_back({p.cls_gc, Tk * H * e});
+    p.cls_slab = (!glyph_only && sizeof(T) == 2) ? b.take(4 * Tk * H * 4) : 0;      // fp32 planes of the split-K classifier data gradient
     // shared backward scratch
     p.gA = b.take(Tk * H * e); p.gB = b.take(Tk * H * e); p.gC = b.take(Tk * H * e); p.gE = b.take(Tk * H * e);
     const int64_t Tw = glyph_only ? 1 : Tk;               // the wide BERT scratch is not needed by the glyph-only plan
@@ -1111,6 +1117,12 @@ template <typename T> struct Engine : EngineBase {
       const int* n_act = wp<int>(pl.cls_nact);
       { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(L.cls_b); te.out = gp(L.cls_w); te.ldo = H;
         RL_TRY(gemm_tn<T>(st, dl, Vp, wp<T>(pl.cls_xc), H, Tk, V, H, te, n_act)); }
+      if constexpr (sizeof(T) == 2) {
+        const int ns = g_cls_splitk;
+        if (ns >= 2 && pl.cls_slab != 0 && Tk >= 1024 &&
+            gemm_nt8_splitk(st, dl, Vp, sp<T>(sh_cls_wT), Vp, Tk, H, Vp, ns, wp<float>(pl.cls_slab), (int64_t)Tk * H, n_act) == RL_OK)
+          return scatter_rows_drop_slab<T>(st, wp<float>(pl.cls_slab), ns, (int64_t)Tk * H, wp<int>(pl.cls_inv), Tk, H, gA, dfin);
+      }
       { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = wp<T>(pl.cls_gc); ep.ldo = H; ep.m_dev = n_act;
         RL_TRY(gemm_nt<T>(st, dl, Vp, sp<T>(sh_cls_wT), Vp, Tk, H, Vp, ep)); }
       return scatter_rows_drop<T>(st, wp<T>(pl.cls_gc), wp<int>(pl.cls_inv), Tk, H, gA, dfin);      // rows outside the loss: zero; + the final dropout's map

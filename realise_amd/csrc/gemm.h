@@ -33,6 +33,12 @@ template <typename T> struct EpiParams {
   // live tile beyond the count are still computed and stored: for outputs whose dead rows nobody reads - the compacted classifier
   // data gradient, engine.hip stage_head)
   const int* m_dev = nullptr;
+  // split-K form of the 8-wave kernel (gemm_nt8_splitk): the launch covers ksplit K-ranges of every tile and each workgroup stores its
+  // fp32 partial tile to slab[split][row][col] (row pitch N, plane pitch slab_stride floats) instead of running an epilogue; the
+  // caller folds the planes in a fixed order
+  float* slab = nullptr;
+  int64_t slab_stride = 0;
+  int ksplit = 1;
 };
 
 // ---- operand loaders ---------------------------------------------------------------------------
@@ -304,6 +310,12 @@ template <typename T> struct TnGroup {
 template <typename T>
 int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha = 1.0f, int overwrite = 0,
                   const int* tile_list = nullptr, const int* n_tiles = nullptr, int list_rows = 0);
+
+// Split-K NT GEMM (bf16, K % 64 == 0, nsplit <= K / 64): slab[s][m][n] (fp32, row pitch N, plane pitch slab_stride) = A[m, Ks] . B[n, Ks]^T
+// over the s-th K-range; rows at or beyond *m_dev (nullable) are not computed.  For reductions long enough that the output tiles
+// alone do not fill the chip: the classifier's data gradient (K = 21184, N = 768, ~4.9 k live rows = 156 tiles of 128 x 192).
+int gemm_nt8_splitk(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, int nsplit,
+                    float* slab, int64_t slab_stride, const int* m_dev);
 
 // C[M,N] = A[M,K] . B[N,K]^T   (both operands K-contiguous)
 template <typename T>

@@ -52,7 +52,7 @@ void set_nt8_probe(int mode) { g_nt8_probe = mode; }
 
 template <typename C, int PROBE, bool KTAIL = false>
 __global__ void __launch_bounds__(512, 2 * C::WGS)
-gemm_nt8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int M, int N, int K, int tiles_n,
+gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __restrict__ B_, int64_t ldb, int M, int N, int K, int tiles_n,
                 int ntiles, int group_m, EpiParams<bf16_t> ep) {
   typedef bf16_t T;
   typedef MmaBF16 Mma;
@@ -62,7 +62,20 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
   const int wm = wave / C::WN, wn = wave - wm * C::WN;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
+  // split-K launches (ep.ksplit > 1): ksplit x ntiles workgroups, split-major so that the tiles of one K-range - which share its
+  // operand columns - sit behind the same L2s; the workgroup's K-range becomes its whole problem (operands advanced, K shortened)
+  const bf16_t* __restrict__ A = A_;
+  const bf16_t* __restrict__ B = B_;
+  int tile, split = 0;
+  if (!KTAIL && ep.ksplit > 1) {
+    const int logical = xcd_remap(blockIdx.x, ntiles * ep.ksplit);
+    split = logical / ntiles; tile = logical - split * ntiles;
+    const int per = (((K + 63) >> 6) + ep.ksplit - 1) / ep.ksplit;
+    const int k0 = split * per * 64;
+    A += k0; B += k0; K = min(K - k0, per * 64);
+  } else {
+    tile = xcd_remap(blockIdx.x, ntiles);
+  }
   int tm, tn;
   tile_coords(tile, tiles_n, ntiles, group_m, tm, tn);
   const int m0 = tm * C::BM, n0 = tn * C::BN;
@@ -220,7 +233,15 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
     for (int it = 0; it < NIT; ++it) {
       const int e = lane + 64 * it, r = e / ITEMS, c8 = e - r * ITEMS;
       const floatx4 v0 = *(const floatx4*)(et + r * RS + c8 * 8), v1 = *(const floatx4*)(et + r * RS + c8 * 8 + 4);
-      epilogue8<T>(ep, M, N, row_w + c * ER + r, col_w + c8 * 8, v0, v1);
+      if (!KTAIL && ep.slab != nullptr) {
+        const int row = row_w + c * ER + r, col = col_w + c8 * 8;
+        if (row < M && col < N) {
+          float* o = ep.slab + (int64_t)split * ep.slab_stride + (int64_t)row * N + col;
+          *(floatx4*)o = v0; *(floatx4*)(o + 4) = v1;
+        }
+      } else {
+        epilogue8<T>(ep, M, N, row_w + c * ER + r, col_w + c8 * 8, v0, v1);
+      }
     }
   }
 }
@@ -248,7 +269,7 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
     if (g_nt8_probe == 3) { RL_LAUNCH((gemm_nt8_kernel<C, 3>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
   }
 #endif
-  RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
+  RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL>), dim3(ntiles * (KTAIL || ep.ksplit < 1 ? 1 : ep.ksplit)), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -500,6 +521,18 @@ bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda
   return (K % 8) == 0 && K >= 64 && (N % 8) == 0 && (ep.ldo % 8) == 0 && (ep.aux == nullptr || (ep.ldaux % 8) == 0) &&
          (lda % 8) == 0 && (ldb % 8) == 0 && M >= 1 && N >= 8 &&
          (int64_t)M * lda * 2 < 0xFFFFFF00ll && (int64_t)N * ldb * 2 < 0xFFFFFF00ll;
+}
+
+int gemm_nt8_splitk(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, int nsplit,
+                    float* slab, int64_t slab_stride, const int* m_dev) {
+  EpiParams<bf16_t> ep;
+  ep.mode = EPI_STORE; ep.ldo = N; ep.m_dev = m_dev; ep.slab = slab; ep.slab_stride = slab_stride; ep.ksplit = nsplit;
+  const int nk = K / 64;
+  if (slab == nullptr || (K % 64) != 0 || nsplit < 1 || nsplit > 16 || (N % 8) != 0 || (lda % 8) != 0 || (ldb % 8) != 0 || M < 1 ||
+      (int64_t)M * lda * 2 >= 0xFFFFFF00ll || (int64_t)N * ldb * 2 >= 0xFFFFFF00ll || slab_stride < (int64_t)M * N ||
+      (nsplit - 1) * ((nk + nsplit - 1) / nsplit) >= nk)          // every K-range holds at least one K-tile
+    return RL_ERR_ARG;
+  return launch_nt8_cfg<Cfg128x192q>(st, A, lda, B, ldb, M, N, K, ep);
 }
 
 // tile: 0 = heuristic, 1 = 256x256, 2 = 256x192, 3 = 256x128, 4 = 128x192, 5 / 6 = 128x192 two workgroups per CU;

@@ -109,7 +109,9 @@ int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, 
             float* loss_out, float* count_buf, T* dlogits, float* row_loss = nullptr, int64_t ld_dl = 0, const CeCompact& cc = CeCompact());
 // out[j] = in[idx[j]], j < *n_dev (rows of H elements); out[row] = inv[row] >= 0 ? in[inv[row]] * dropout mask : 0
 template <typename T> int gather_rows(hipStream_t st, const T* in, const int* idx, const int* n_dev, int max_rows, int H, T* out);
-template <typename T> int scatter_rows_drop(hipStream_t st, const T* in, const int* inv, int rows, int H, T* out, DropParams d);   // ld_dl: row pitch of dlogits (0: ld)
+template <typename T> int scatter_rows_drop(hipStream_t st, const T* in, const int* inv, int rows, int H, T* out, DropParams d);
+template <typename T> int scatter_rows_drop_slab(hipStream_t st, const float* slab, int nsplit, int64_t stride, const int* inv, int rows, int H, T* out,
+                                                 DropParams d);      // rows of a split-K GEMM's fp32 planes, folded in plane order   // ld_dl: row pitch of dlogits (0: ld)
 
 // ---- eval decode (run.py:262-263): ids[row] = argmax_v logits[row][v], first maximum wins (numpy / torch semantics), a NaN
 // counts as the maximum.  Only the ids leave the device (32 KB instead of the 692 MB fp32 logits of run.py:262).

@@ -1212,6 +1212,31 @@ template <typename T> int scatter_rows_drop(hipStream_t st, const T* in, const i
   hipLaunchKernelGGL((scatter_rows_drop_kernel<T>), dim3(rows), dim3(192), 0, st, in, inv, H, out, d);
   return RL_LAUNCH_CHECK();
 }
+// the same scatter fed by the fp32 partial planes of a split-K GEMM: out[row] = inv[row] >= 0 ? (sum_s slab[s][inv[row]]) * dropout : 0,
+// planes added in index order (bit-reproducible)
+template <typename T>
+__global__ void scatter_rows_drop_slab_kernel(const float* __restrict__ slab, int nsplit, int64_t stride, const int* __restrict__ inv, int H,
+                                              T* __restrict__ out, DropParams d) {
+  const int row = blockIdx.x, j = inv[row];
+  for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
+    floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (j >= 0) {
+      const float* p = slab + (int64_t)j * H + c;
+      v = *(const floatx4*)p;
+      for (int s = 1; s < nsplit; ++s) v += *(const floatx4*)(p + s * stride);
+      v *= drop_mult4(d.seed, d.thresh, d.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c);
+    }
+    store4<T>(out + (int64_t)row * H + c, v);
+  }
+}
+template <typename T> int scatter_rows_drop_slab(hipStream_t st, const float* slab, int nsplit, int64_t stride, const int* inv, int rows, int H, T* out,
+                                                 DropParams d) {
+  if ((H & 3) || nsplit < 1) return RL_ERR_ARG;
+  hipLaunchKernelGGL((scatter_rows_drop_slab_kernel<T>), dim3(rows), dim3(192), 0, st, slab, nsplit, stride, inv, H, out, d);
+  return RL_LAUNCH_CHECK();
+}
+template int scatter_rows_drop_slab<bf16_t>(hipStream_t, const float*, int, int64_t, const int*, int, int, bf16_t*, DropParams);
+template int scatter_rows_drop_slab<float>(hipStream_t, const float*, int, int64_t, const int*, int, int, float*, DropParams);
 template int scatter_rows_drop<bf16_t>(hipStream_t, const bf16_t*, const int*, int, int, bf16_t*, DropParams);
 template int scatter_rows_drop<float>(hipStream_t, const float*, const int*, int, int, float*, DropParams);
 
