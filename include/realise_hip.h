@@ -198,6 +198,9 @@ int64_t realise_engine_workspace_bytes(const realise_engine* e, int B, int S, in
 int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_t workspace_bytes);
 /* re-derive the compute-dtype operand copies from the fp32 masters (after any parameter update) */
 int realise_engine_refresh_shadows(realise_engine* e, void* stream);
+/* the same, for a caller whose last parameter update was realise_engine_adamw (which wrote the Linear weights' copies itself):
+ * linear_current != 0 re-derives only the conv-weight copies (and the glyph table's image when it changed) */
+int realise_engine_refresh_shadows_ex(realise_engine* e, void* stream, int linear_current);
 /* the frozen glyph table (arena 2) changed: rebuild its NHWC operand image at the next refresh */
 void realise_engine_invalidate_frozen(realise_engine* e);
 /* zero_grad() without the memset: fresh != 0 tells the engine that the gradient arena holds nothing the caller wants kept - the
@@ -276,6 +279,13 @@ int realise_clip_scale(void* stream, float* g, int64_t n, const float* grad_norm
 typedef struct { float lr, beta1, beta2, eps, weight_decay; int32_t correct_bias; } realise_adamw_group;
 int realise_adamw_grouped(void* stream, float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_block64,
                           const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm);
+/* The grouped sweep over the ENGINE's parameter / gradient arenas (transformers/optimization.py:110-169, run.py:207-211), with the
+ * operand copies of the Linear weights written by the pass that updates them: those tensors (90 % of the parameters) are stepped in
+ * the 64 x 64 tiles of the operand-copy kernel, which stores the new fp32 value and its compute-dtype W / W^T copies together; the
+ * rest by the flat sweep.  m / v: the caller's moment arenas (same layout as the parameter arena).  Follow it with
+ * realise_engine_refresh_shadows_ex(e, stream, 1) instead of the full refresh. */
+int realise_engine_adamw(realise_engine* e, void* stream, float* m, float* v, const uint8_t* group_of_block64,
+                         const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm);
 int realise_fill_f32(void* stream, float* p, float value, int64_t n);
 /* widen a compute-dtype tensor to fp32 (the reference returns fp32 logits, src/models.py:859); 16-byte aligned pointers */
 int realise_cast_to_f32(void* stream, int dtype, const void* src, float* dst, int64_t n);

@@ -417,6 +417,9 @@ int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_
   return e ? e->impl->bind(shadow, workspace, workspace_bytes) : RL_ERR_ARG;
 }
 int realise_engine_refresh_shadows(realise_engine* e, void* stream) { return e ? e->impl->refresh_shadows((hipStream_t)stream) : RL_ERR_ARG; }
+int realise_engine_refresh_shadows_ex(realise_engine* e, void* stream, int linear_current) {
+  return e ? e->impl->refresh_shadows_ex((hipStream_t)stream, linear_current) : RL_ERR_ARG;
+}
 void realise_engine_invalidate_frozen(realise_engine* e) { if (e) e->impl->invalidate_frozen(); }
 void realise_engine_set_grads_fresh(realise_engine* e, int fresh) { if (e) e->impl->set_grads_fresh(fresh); }
 void realise_engine_set_id_flag(realise_engine* e, int32_t* flag) { if (e) e->impl->set_id_flag((int*)flag); }
@@ -451,17 +454,28 @@ int realise_adamw(void* stream, float* p, const float* g, float* m, float* v, in
   return adamw_flat((hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_norm_sq, max_grad_norm);
 }
 int realise_clip_scale(void* stream, float* g, int64_t n, const float* grad_norm_sq, float max_grad_norm) { return clip_scale((hipStream_t)stream, g, n, grad_norm_sq, max_grad_norm); }
-int realise_adamw_grouped(void* stream, float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_block64,
-                          const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm) {
-  if (!groups || n_groups < 1 || n_groups > ADAMW_MAX_GROUPS) return RL_ERR_ARG;
-  AdamwGroups gs; gs.n = n_groups;
+static bool make_adamw_groups(const realise_adamw_group* groups, int n_groups, int64_t step, AdamwGroups& gs) {
+  if (!groups || n_groups < 1 || n_groups > ADAMW_MAX_GROUPS) return false;
+  gs.n = n_groups;
   for (int i = 0; i < n_groups; ++i) {
     const realise_adamw_group& h = groups[i];
     double bc1 = 1.0, bc2 = 1.0;
     if (h.correct_bias) { bc1 = 1.0 - pow((double)h.beta1, (double)step); bc2 = 1.0 - pow((double)h.beta2, (double)step); }
     gs.g[i] = AdamwGroup{h.lr, h.beta1, h.beta2, h.eps, h.weight_decay, (float)(h.lr * sqrt(bc2) / bc1)};
   }
+  return true;
+}
+int realise_adamw_grouped(void* stream, float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_block64,
+                          const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm) {
+  AdamwGroups gs;
+  if (!make_adamw_groups(groups, n_groups, step, gs)) return RL_ERR_ARG;
   return adamw_grouped((hipStream_t)stream, p, g, m, v, n, group_of_block64, gs, grad_norm_sq, max_grad_norm);
+}
+int realise_engine_adamw(realise_engine* e, void* stream, float* m, float* v, const uint8_t* group_of_block64,
+                         const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm) {
+  AdamwGroups gs;
+  if (!e || !make_adamw_groups(groups, n_groups, step, gs)) return RL_ERR_ARG;
+  return e->impl->adamw_step((hipStream_t)stream, m, v, group_of_block64, gs, grad_norm_sq, max_grad_norm);
 }
 int realise_profile_enable(int max_launches) { return prof_enable(max_launches); }
 void realise_profile_pause(int paused) { prof_pause(paused); }

@@ -5,6 +5,7 @@
 #include "../../include/realise_hip.h"
 
 namespace rl {
+struct AdamwGroups;
 void set_wgrad_overlap(int on);
 void set_wgrad_group(int on);     // the four wgrad GEMMs of a transformer layer as one grouped launch (default on)
 void set_dgrad_parity(int on);    // stride-2 conv data gradients by input-pixel parity classes (default on)
@@ -21,6 +22,9 @@ struct EngineBase {
   virtual int64_t workspace_bytes(int B, int S, int Tp) = 0;
   virtual int bind(void* shadow, void* workspace, int64_t bytes) = 0;
   virtual int refresh_shadows(hipStream_t st) = 0;
+  virtual int refresh_shadows_ex(hipStream_t st, int skip_linear) = 0;
+  virtual int adamw_step(hipStream_t st, float* m, float* v, const uint8_t* group_of_block, const struct AdamwGroups& gs, const float* norm_sq,
+                         float max_norm) = 0;
   virtual void invalidate_frozen() = 0;
   virtual void set_id_flag(int* flag) = 0;
   virtual void set_grads_fresh(int fresh) = 0;

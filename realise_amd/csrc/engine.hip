@@ -101,7 +101,9 @@ template <typename T> struct Engine : EngineBase {
   int64_t sh_cls_w = 0, sh_cls_wT = 0, sh_gru_hh = 0, sh_gru_hhT = 0, sh_glyph = 0;
   int64_t shadow_total = 0;
   bool glyph_built = false, descs_built = false;
-  int64_t sh_descs = 0, sh_fill = 0;
+  int64_t sh_descs = 0, sh_fill = 0, sh_skip = 0;
+  bool skip_built = false;
+  std::vector<uint8_t> skip_host;
   static constexpr int FILL_MAX = 2048;
   int n_descs = 0, desc_tiles = 0;
   std::vector<CastDesc> desc_host;
@@ -254,70 +256,87 @@ template <typename T> struct Engine : EngineBase {
     }
     sh_descs = b.take(256 * (int64_t)sizeof(CastDesc));      // device table for the one-launch refresh of the Linear weights
     sh_fill = b.take(FILL_MAX * (int64_t)sizeof(FillChunk));  // chunk table of the fresh-gradient zero fill
+    sh_skip = b.take((L.arena_elems[AR_TRAIN] + 63) / 64);    // a byte per 64 parameters: stepped by the tiled AdamW (adamw_step)
     shadow_total = b.off;
   }
 
   int64_t shadow_bytes() const override { return shadow_total; }
 
-  int refresh_shadows(hipStream_t st) override {
-    if (!sh) return RL_ERR_ARG;
-    if (!descs_built) {          // every Linear weight -> (W, W^T) operand copies, one launch per refresh
-      std::vector<CastDesc>& d = desc_host;       // member: stays alive while the async upload is in flight
-      d.clear();
-      int tiles = 0;
-      auto add = [&](int64_t src, int R, int C, int64_t dst, int64_t dstT, int ldT = 0) {
-        CastDesc x;
-        x.src = pp(src); x.dst = sp<T>(dst); x.dstT = sp<T>(dstT); x.R = R; x.C = C; x.ldT = ldT > 0 ? ldT : R;
-        x.tile_begin = tiles; x.tiles_c = (C + 63) / 64;
-        tiles += x.tiles_c * ((R + 63) / 64);
-        d.push_back(x);
-      };
-      auto add_stack = [&](const StackOff& so, const std::vector<LayerSh>& v) {
-        for (size_t l = 0; l < v.size(); ++l) {
-          const LayerOff& o = so.layers[l];
-          add(o.qkv_w, 3 * H, H, v[l].qkv_w, v[l].qkv_wT);
-          add(o.ao_w, H, H, v[l].ao_w, v[l].ao_wT);
-          add(o.in_w, I, H, v[l].in_w, v[l].in_wT);
-          add(o.out_w, H, I, v[l].out_w, v[l].out_wT);
-        }
-      };
-      add_stack(L.bert, sh_bert);
-      n_descs_a = (int)d.size(); desc_tiles_a = tiles;
-      tiles = 0;                                   // second group: its own launch, tile ids restart
-      add(L.cls_w, V, H, sh_cls_w, sh_cls_wT, Vp);
-      if (cfg.model_type == 1) {
-        add_stack(L.pho, sh_pho);
-        add_stack(L.outb, sh_out);
-        add(L.gru_w_hh, 3 * H, H, sh_gru_hh, sh_gru_hhT);
+  // descriptor table of the Linear weights -> (W, W^T) operand copies: group A = the bert stack (what the forward needs first), group
+  // B = classifier, pinyin / output stacks, GRU; tile ids restart per group (one launch each)
+  int ensure_descs(hipStream_t st) {
+    if (descs_built) return RL_OK;
+    std::vector<CastDesc>& d = desc_host;       // member: stays alive while the async upload is in flight
+    d.clear();
+    int tiles = 0;
+    auto add = [&](int64_t src, int R, int C, int64_t dst, int64_t dstT, int ldT = 0) {
+      CastDesc x;
+      x.src = pp(src); x.dst = sp<T>(dst); x.dstT = sp<T>(dstT); x.R = R; x.C = C; x.ldT = ldT > 0 ? ldT : R;
+      x.tile_begin = tiles; x.tiles_c = (C + 63) / 64;
+      tiles += x.tiles_c * ((R + 63) / 64);
+      d.push_back(x);
+    };
+    auto add_stack = [&](const StackOff& so, const std::vector<LayerSh>& v) {
+      for (size_t l = 0; l < v.size(); ++l) {
+        const LayerOff& o = so.layers[l];
+        add(o.qkv_w, 3 * H, H, v[l].qkv_w, v[l].qkv_wT);
+        add(o.ao_w, H, H, v[l].ao_w, v[l].ao_wT);
+        add(o.in_w, I, H, v[l].in_w, v[l].in_wT);
+        add(o.out_w, H, I, v[l].out_w, v[l].out_wT);
       }
-      if (d.size() > 256) return RL_ERR_ARG;
-      if (hipMemcpyAsync(sh + sh_descs, d.data(), d.size() * sizeof(CastDesc), hipMemcpyHostToDevice, st) != hipSuccess) return RL_ERR_LAUNCH;
-      n_descs = (int)d.size(); desc_tiles = tiles; descs_built = true;
+    };
+    add_stack(L.bert, sh_bert);
+    n_descs_a = (int)d.size(); desc_tiles_a = tiles;
+    tiles = 0;                                   // second group: its own launch, tile ids restart
+    add(L.cls_w, V, H, sh_cls_w, sh_cls_wT, Vp);
+    if (cfg.model_type == 1) {
+      add_stack(L.pho, sh_pho);
+      add_stack(L.outb, sh_out);
+      add(L.gru_w_hh, 3 * H, H, sh_gru_hh, sh_gru_hhT);
     }
+    if (d.size() > 256) return RL_ERR_ARG;
+    if (hipMemcpyAsync(sh + sh_descs, d.data(), d.size() * sizeof(CastDesc), hipMemcpyHostToDevice, st) != hipSuccess) return RL_ERR_LAUNCH;
+    n_descs = (int)d.size(); desc_tiles = tiles; descs_built = true;
+    return RL_OK;
+  }
+  int refresh_shadows(hipStream_t st) override { return refresh_shadows_ex(st, 0); }
+  // skip_linear != 0: the Linear weights' copies are current (adamw_step wrote them from the values it stored); only the conv-weight
+  // copies (and the glyph table's image when it changed) are re-derived
+  int refresh_shadows_ex(hipStream_t st, int skip_linear) override {
+    if (!sh) return RL_ERR_ARG;
+    RL_TRY(ensure_descs(st));
     // Three independent pieces on three streams (when the branch streams exist): the bert stack's copies on the caller's stream -
     // the forward that follows needs nothing else for its first 12 layers -, classifier + pinyin / output stacks + GRU on the pinyin
-    // stream, the 20 small conv-weight launches (+ the glyph table when it changed) on the glyph stream, where the glyph branch of the
-    // forward queues up behind them by itself.  ev_shadow[k] orders any OTHER consumer (a forward without branch streams, the
+    // stream, the conv-weight launch (+ the glyph table when it changed) on the glyph stream, where the glyph branch of the
+    // forward queues up behind it by itself.  ev_shadow[k] orders any OTHER consumer (a forward without branch streams, the
     // glyph-only entry points): wait_shadows().
     const bool ovl = cfg.model_type == 1 && g_branch_overlap && branches_ok() && shadow_events_ok();
     hipStream_t s_b = ovl ? bst[0] : st, s_c = ovl ? bst[1] : st;
     if (ovl) RL_TRY(fork(st));
     const CastDesc* dd = (const CastDesc*)(sh + sh_descs);
-    RL_TRY(cast_transpose_multi<T>(st, dd, n_descs_a, desc_tiles_a));
-    RL_TRY(cast_transpose_multi<T>(s_b, dd + n_descs_a, n_descs - n_descs_a, desc_tiles));
+    if (!skip_linear) {
+      RL_TRY(cast_transpose_multi<T>(st, dd, n_descs_a, desc_tiles_a));
+      RL_TRY(cast_transpose_multi<T>(s_b, dd + n_descs_a, n_descs - n_descs_a, desc_tiles));
+    }
     if (cfg.model_type == 1) {
+      ConvShadowDescs cd;
+      auto addc = [&](const float* w, int Co, int Ci, int KHW, int Cpad, T* fwd, T* dgrad, const TapOrder& ord = TapOrder()) {
+        ConvShadowDesc& x = cd.d[cd.n++];
+        x.w = w; x.fwd = fwd; x.dgrad = dgrad; x.Co = Co; x.Ci = Ci; x.KHW = KHW; x.Cpad = Cpad; x.CiRows = Cpad; x.block_begin = 0; x.order = ord;
+      };
       for (int k = 0; k < 5; ++k) {
         const BlockOff& o = L.blocks[k];
         const BlockSh& s = sh_blk[k];
-        RL_TRY(conv_weight_shadow<T>(s_c, pp(o.w1), o.cout, o.cin, 9, s.cin_pad, s.cin_pad, sp<T>(s.w1f), sp<T>(s.w1d)));
+        addc(pp(o.w1), o.cout, o.cin, 9, s.cin_pad, sp<T>(s.w1f), sp<T>(s.w1d));
         {   // second data-gradient copy of the stride-2 conv with its taps stored parity class by parity class
           TapOrder ord; ord.n = 9; int first = 0;
           (void)conv_s2_class(3, 3, 1, 0, &first, ord.t);
-          RL_TRY(conv_weight_shadow<T>(s_c, pp(o.w1), o.cout, o.cin, 9, s.cin_pad, s.cin_pad, (T*)nullptr, sp<T>(s.w1p), ord));
+          addc(pp(o.w1), o.cout, o.cin, 9, s.cin_pad, (T*)nullptr, sp<T>(s.w1p), ord);
         }
-        RL_TRY(conv_weight_shadow<T>(s_c, pp(o.w2), o.cout, o.cout, 9, o.cout, o.cout, sp<T>(s.w2f), sp<T>(s.w2d)));
-        RL_TRY(conv_weight_shadow<T>(s_c, pp(o.ws), o.cout, o.cin, 1, s.cin_pad, s.cin_pad, sp<T>(s.wsf), sp<T>(s.wsd)));
+        addc(pp(o.w2), o.cout, o.cout, 9, o.cout, sp<T>(s.w2f), sp<T>(s.w2d));
+        addc(pp(o.ws), o.cout, o.cin, 1, s.cin_pad, sp<T>(s.wsf), sp<T>(s.wsd));
       }
+      RL_TRY(conv_weight_shadow_multi<T>(s_c, cd));
       // the glyph table is frozen (requires_grad=False, models.py:679): its NHWC image is rebuilt only after
       // invalidate_frozen() (load_state_dict / build_glyce_embed*)
       if (!glyph_built) {
@@ -331,6 +350,30 @@ template <typename T> struct Engine : EngineBase {
       shadows_pending = true;
     }
     return RL_OK;
+  }
+  // FusedAdamW's step as the engine runs it: the Linear weights (90 % of the parameters) in the tiles of the operand-copy kernel,
+  // which stores the new fp32 value AND its compute-dtype W / W^T copies in the same pass; everything else by the flat grouped
+  // kernel, told by a byte per 64 parameters what the tiled launches own.  The next forward then calls refresh_shadows_ex(st, 1).
+  int adamw_step(hipStream_t st, float* m, float* v, const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq,
+                 float max_norm) override {
+    if (!sh || !m || !v || !group_of_block) return RL_ERR_ARG;
+    RL_TRY(ensure_descs(st));
+    const int64_t n = L.arena_elems[AR_TRAIN];
+    if (!skip_built) {
+      skip_host.assign((size_t)((n + 63) / 64), 0);
+      for (const CastDesc& d : desc_host) {
+        const int64_t off = d.src - P, cnt = (int64_t)d.R * d.C;
+        if ((off % 64) != 0 || (cnt % 64) != 0 || (d.C % 4) != 0) return RL_ERR_ARG;
+        for (int64_t b = off / 64; b < (off + cnt) / 64; ++b) skip_host[(size_t)b] = 1;
+      }
+      if (hipMemcpyAsync(sh + sh_skip, skip_host.data(), skip_host.size(), hipMemcpyHostToDevice, st) != hipSuccess) return RL_ERR_LAUNCH;
+      skip_built = true;
+    }
+    RL_TRY(wait_shadows(st));           // (the previous refresh may still be writing the copies on the branch streams)
+    const CastDesc* dd = (const CastDesc*)(sh + sh_descs);
+    RL_TRY(adamw_cast_multi<T>(st, dd, n_descs_a, desc_tiles_a, P, G, m, v, group_of_block, gs, norm_sq, max_norm));
+    RL_TRY(adamw_cast_multi<T>(st, dd + n_descs_a, n_descs - n_descs_a, desc_tiles, P, G, m, v, group_of_block, gs, norm_sq, max_norm));
+    return adamw_grouped(st, P, G, m, v, n, group_of_block, gs, norm_sq, max_norm, (const uint8_t*)(sh + sh_skip));
   }
   // operand copies refreshed on the branch streams: order `s` behind them (no-op when they ran on the caller's stream)
   hipEvent_t ev_shadow[2] = {nullptr, nullptr};
@@ -489,7 +532,7 @@ template <typename T> struct Engine : EngineBase {
   int bind(void* shadow, void* workspace, int64_t bytes) override {
     // everything the engine keeps inside the caller's shadow buffer (operand copies, the cast descriptor table, the chunk table of the
     // fresh-gradient zero fill) is rebuilt after a re-bind to another buffer
-    if (shadow != (void*)sh) { glyph_built = false; descs_built = false; fill_built = false; n_fill = 0; }
+    if (shadow != (void*)sh) { glyph_built = false; descs_built = false; fill_built = false; n_fill = 0; skip_built = false; }
     sh = (char*)shadow; ws = (char*)workspace; ws_bytes = bytes; pl = Plan(); have_fwd = false;
     return RL_OK;
   }

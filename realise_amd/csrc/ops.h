@@ -234,6 +234,11 @@ template <typename T> int cast_transpose_multi(hipStream_t st, const CastDesc* d
 // conv weight [Co][Ci][KH][KW] fp32 -> fwd [Co][KH*KW][Cpad] and dgrad [Ci_rows][KH*KW][Co] (rows >= Ci zero)
 template <typename T>
 int conv_weight_shadow(hipStream_t st, const float* w, int Co, int Ci, int KHW, int Cpad, int CiRows, T* fwd, T* dgrad, const TapOrder& order = TapOrder());
+// every conv weight of the glyph ResNet in one launch
+constexpr int CONV_SHADOW_MAX = 20;
+struct ConvShadowDesc { const float* w; void* fwd; void* dgrad; int Co, Ci, KHW, Cpad, CiRows, block_begin; TapOrder order; };
+struct ConvShadowDescs { int n = 0; ConvShadowDesc d[CONV_SHADOW_MAX]; };
+template <typename T> int conv_weight_shadow_multi(hipStream_t st, ConvShadowDescs& ds);      // fills block_begin
 // glyph table [V][F][HW] fp32 -> NHWC [V][HW][Cpad]
 template <typename T> int glyph_shadow(hipStream_t st, const float* tbl, int V, int F, int HW, int Cpad, T* out);
 
@@ -247,8 +252,14 @@ int adamw_flat(hipStream_t st, float* p, const float* g, float* m, float* v, int
 constexpr int ADAMW_MAX_GROUPS = 8;
 struct AdamwGroup { float lr, beta1, beta2, eps, weight_decay, step_size; };      // step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t) (or lr)
 struct AdamwGroups { int n; AdamwGroup g[ADAMW_MAX_GROUPS]; };
+// skip_block (nullable): a byte per 64 elements, != 0 = stepped elsewhere (adamw_cast_multi)
 int adamw_grouped(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_block,
-                  const AdamwGroups& gs, const float* norm_sq, float max_norm);
+                  const AdamwGroups& gs, const float* norm_sq, float max_norm, const uint8_t* skip_block = nullptr);
+// AdamW over the Linear weights named by the cast descriptors (tile ids restart at 0 for this launch) + their compute-dtype W / W^T
+// copies from the updated values, one pass; P0 / G0 / M0 / V0 = bases of the parameter / gradient / moment arenas
+template <typename T>
+int adamw_cast_multi(hipStream_t st, const CastDesc* descs, int n, int total_tiles, float* P0, const float* G0, float* M0, float* V0,
+                     const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq, float max_norm);
 int clip_scale(hipStream_t st, float* g, int64_t n, const float* norm_sq, float max_norm);
 int fill_f32(hipStream_t st, float* p, float v, int64_t n);
 struct FillChunk { int64_t off; int32_t len, pad; };     // off: 4-element aligned

@@ -1,5 +1,6 @@
 // HBM-bound kernels, part 2: pinyin-GRU gate math (K6), BatchNorm finalize/apply (K9),
 // operand shadows (compute-dtype copies of the fp32 master weights), optimizer (K15/K16).
+#include <algorithm>
 #include "ops.h"
 
 namespace rl {
@@ -631,6 +632,53 @@ int conv_weight_shadow(hipStream_t st, const float* w, int Co, int Ci, int KHW, 
 template int conv_weight_shadow<bf16_t>(hipStream_t, const float*, int, int, int, int, int, bf16_t*, bf16_t*, const TapOrder&);
 template int conv_weight_shadow<float>(hipStream_t, const float*, int, int, int, int, int, float*, float*, const TapOrder&);
 
+// All conv-weight operand copies of the glyph ResNet in ONE launch (was 20 launches of ~13 us on the glyph stream): the blocks of
+// the grid are dealt to the descriptors in proportion to their element counts (block_begin), each descriptor's blocks stride over it.
+template <typename T>
+__global__ void __launch_bounds__(256) conv_weight_shadow_multi_kernel(ConvShadowDescs ds) {
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < ds.n; ++i) if ((int)blockIdx.x >= ds.d[i].block_begin) k = i;
+  const ConvShadowDesc& d = ds.d[k];
+  const int nb = (k + 1 < ds.n ? ds.d[k + 1].block_begin : (int)gridDim.x) - d.block_begin;
+  T* fwd = (T*)d.fwd;
+  T* dgrad = (T*)d.dgrad;
+  const int Co = d.Co, Ci = d.Ci, KHW = d.KHW, Cpad = d.Cpad;
+  const int64_t nf = (int64_t)Co * KHW * Cpad, nd = (int64_t)d.CiRows * KHW * Co;
+  for (int64_t i = (int64_t)(blockIdx.x - d.block_begin) * 256 + threadIdx.x; i < nf + nd; i += (int64_t)nb * 256) {
+    if (i < nf) {
+      if (fwd == nullptr) continue;
+      const int ci = (int)(i % Cpad);
+      const int tap = (int)((i / Cpad) % KHW);
+      const int co = (int)(i / ((int64_t)Cpad * KHW));
+      fwd[i] = from_f<T>(ci < Ci ? d.w[((int64_t)co * Ci + ci) * KHW + tap] : 0.f);
+    } else {
+      if (dgrad == nullptr) continue;
+      const int64_t q = i - nf;
+      const int co = (int)(q % Co);
+      const int tap = (int)((q / Co) % KHW);
+      const int ci = (int)(q / ((int64_t)Co * KHW));
+      const int src_tap = d.order.n ? d.order.t[tap] : tap;
+      dgrad[q] = from_f<T>(ci < Ci ? d.w[((int64_t)co * Ci + ci) * KHW + src_tap] : 0.f);
+    }
+  }
+}
+template <typename T> int conv_weight_shadow_multi(hipStream_t st, ConvShadowDescs& ds) {
+  if (ds.n < 1 || ds.n > CONV_SHADOW_MAX) return RL_ERR_ARG;
+  int blocks = 0;
+  for (int k = 0; k < ds.n; ++k) {
+    const ConvShadowDesc& d = ds.d[k];
+    if (d.order.n != 0 && d.order.n != d.KHW) return RL_ERR_ARG;
+    const int64_t n = (int64_t)d.Co * d.KHW * d.Cpad + (int64_t)d.CiRows * d.KHW * d.Co;
+    ds.d[k].block_begin = blocks;
+    blocks += (int)std::min<int64_t>(64, std::max<int64_t>(1, (n + 2047) / 2048));      // ~8 elements per thread, at most 64 blocks per tensor
+  }
+  hipLaunchKernelGGL((conv_weight_shadow_multi_kernel<T>), dim3(blocks), dim3(256), 0, st, ds);
+  return RL_LAUNCH_CHECK();
+}
+template int conv_weight_shadow_multi<bf16_t>(hipStream_t, ConvShadowDescs&);
+template int conv_weight_shadow_multi<float>(hipStream_t, ConvShadowDescs&);
+
 template <typename T>
 __global__ void glyph_shadow_kernel(const float* __restrict__ tbl, int64_t V, int F, int HW, int Cpad, T* __restrict__ out) {
   const int64_t n = V * HW * Cpad;
@@ -703,7 +751,7 @@ int adamw_flat(hipStream_t st, float* p, const float* g, float* m, float* v, int
 // of the arena starts on a 64-element boundary), 255 = not optimised.
 __global__ void adamw_grouped_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                      int64_t n, const uint8_t* __restrict__ group_of_block, AdamwGroups gs,
-                                     const float* __restrict__ norm_sq, float max_norm) {
+                                     const float* __restrict__ norm_sq, float max_norm, const uint8_t* __restrict__ skip_block) {
   float clip = 1.0f;
   if (norm_sq != nullptr) {
     const float c = max_norm / (sqrtf(norm_sq[0]) + 1e-6f);
@@ -712,6 +760,7 @@ __global__ void adamw_grouped_kernel(float* __restrict__ p, const float* __restr
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int gid = group_of_block[i >> 6];
     if (gid >= gs.n) continue;
+    if (skip_block != nullptr && skip_block[i >> 6]) continue;      // stepped by adamw_cast_multi_kernel (the Linear weights)
     const AdamwGroup h = gs.g[gid];
     const float gi = g[i] * clip;
     const float mi = m[i] * h.beta1 + (1.0f - h.beta1) * gi;
@@ -722,12 +771,94 @@ __global__ void adamw_grouped_kernel(float* __restrict__ p, const float* __restr
   }
 }
 int adamw_grouped(hipStream_t st, float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of_block,
-                  const AdamwGroups& gs, const float* norm_sq, float max_norm) {
+                  const AdamwGroups& gs, const float* norm_sq, float max_norm, const uint8_t* skip_block) {
   if (n <= 0) return RL_OK;
   if (gs.n < 1 || gs.n > ADAMW_MAX_GROUPS || group_of_block == nullptr) return RL_ERR_ARG;
-  hipLaunchKernelGGL(adamw_grouped_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, p, g, m, v, n, group_of_block, gs, norm_sq, max_norm);
+  hipLaunchKernelGGL(adamw_grouped_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, p, g, m, v, n, group_of_block, gs, norm_sq, max_norm, skip_block);
   return RL_LAUNCH_CHECK();
 }
+
+// AdamW over the Linear weights in the 64 x 64 tiles of cast_transpose_multi: the pass that reads and writes every parameter anyway
+// also emits the compute-dtype operand copies W and W^T the next forward / backward multiply with (the transposed copy through a
+// padded LDS tile, 128-byte row segments on both sides) - the separate refresh (8 B / parameter of reads + writes, two launches)
+// disappears from a FusedAdamW step.  Element (r, c) of descriptor d sits at arena offset (d.src - P0) + r * C + c in p / g / m / v.
+template <typename T>
+__global__ void __launch_bounds__(256) adamw_cast_multi_kernel(const CastDesc* __restrict__ descs, int n, float* __restrict__ P0,
+                                                               const float* __restrict__ G0, float* __restrict__ M0, float* __restrict__ V0,
+                                                               const uint8_t* __restrict__ group_of_block, AdamwGroups gs,
+                                                               const float* __restrict__ norm_sq, float max_norm) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = n - 1;                               // last descriptor with tile_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = descs[lo];
+  const int t = blockIdx.x - d.tile_begin;
+  const int r0 = (t / d.tiles_c) * 64, c0 = (t % d.tiles_c) * 64;
+  const int q = threadIdx.x & 15, y = threadIdx.x >> 4;     // 16 quads x 16 rows per pass
+  T* dst = (T*)d.dst;
+  T* dstT = (T*)d.dstT;
+  const int64_t base = d.src - P0;
+  float clip = 1.0f;
+  if (norm_sq != nullptr) {
+    const float c = max_norm / (sqrtf(norm_sq[0]) + 1e-6f);
+    clip = c < 1.0f ? c : 1.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + y + 16 * k, c = c0 + 4 * q;
+    floatx4 pv = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (r < d.R && c < d.C) {                           // C % 4 == 0
+      const int64_t e = base + (int64_t)r * d.C + c;
+      pv = *(const floatx4*)(P0 + e);
+      const int gid = group_of_block[e >> 6];           // a quad never straddles a 64-element block (base % 64 == 0, C % 4 == 0)
+      if (gid < gs.n) {
+        const AdamwGroup h = gs.g[gid];
+        const floatx4 gv = *(const floatx4*)(G0 + e) * clip;
+        floatx4 mv = *(const floatx4*)(M0 + e), vv = *(const floatx4*)(V0 + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          mv[j] = mv[j] * h.beta1 + (1.0f - h.beta1) * gv[j];
+          vv[j] = vv[j] * h.beta2 + (1.0f - h.beta2) * gv[j] * gv[j];
+          float pi = pv[j] - h.step_size * (mv[j] / (sqrtf(vv[j]) + h.eps));
+          if (h.weight_decay > 0.f) pi -= h.lr * h.weight_decay * pi;
+          pv[j] = pi;
+        }
+        *(floatx4*)(M0 + e) = mv; *(floatx4*)(V0 + e) = vv; *(floatx4*)(P0 + e) = pv;
+      }
+      if (dst != nullptr) store4<T>(dst + (int64_t)r * d.C + c, pv);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[y + 16 * k][4 * q + j] = pv[j];
+  }
+  __syncthreads();
+  if (dstT == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + y + 16 * k, r = r0 + 4 * q;
+    if (c < d.C && r < d.R) {
+      if (r + 3 < d.R && (d.R & 3) == 0) {
+        floatx4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = tile[4 * q + j][y + 16 * k];
+        store4<T>(dstT + (int64_t)c * d.ldT + r, v);
+      } else {
+        for (int j = 0; j < 4 && r + j < d.R; ++j) dstT[(int64_t)c * d.ldT + r + j] = from_f<T>(tile[4 * q + j][y + 16 * k]);
+      }
+    }
+  }
+}
+template <typename T>
+int adamw_cast_multi(hipStream_t st, const CastDesc* descs, int n, int total_tiles, float* P0, const float* G0, float* M0, float* V0,
+                     const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq, float max_norm) {
+  if (n <= 0 || total_tiles <= 0) return RL_OK;
+  if (gs.n < 1 || gs.n > ADAMW_MAX_GROUPS || group_of_block == nullptr) return RL_ERR_ARG;
+  hipLaunchKernelGGL((adamw_cast_multi_kernel<T>), dim3(total_tiles), dim3(256), 0, st, descs, n, P0, G0, M0, V0, group_of_block, gs, norm_sq, max_norm);
+  return RL_LAUNCH_CHECK();
+}
+template int adamw_cast_multi<bf16_t>(hipStream_t, const CastDesc*, int, int, float*, const float*, float*, float*, const uint8_t*, const AdamwGroups&, const float*, float);
+template int adamw_cast_multi<float>(hipStream_t, const CastDesc*, int, int, float*, const float*, float*, float*, const uint8_t*, const AdamwGroups&, const float*, float);
 
 // g *= min(1, max_norm / (sqrt(*norm_sq) + 1e-6)) - the in-place half of clip_grad_norm_ (run.py:207) for callers that step with a
 // stock optimizer (FusedAdamW applies the coefficient inside its own sweep instead)

@@ -85,6 +85,7 @@ class RealiseModule(nn.Module):
         self._ws = None
         self._ws_key = None
         self._shadow_version = None
+        self._linear_copies_current = False
         self._step_seed = int(seed) * 1000003 + 12345
         self.assume_unit_loss_grad = False
         self.grad_sync = None               # optional object with bucket_ready(i) / finish(), set by the DDP wrapper
@@ -167,6 +168,7 @@ class RealiseModule(nn.Module):
         self._ws = None
         self._ws_key = None
         self._shadow_version = None
+        self._linear_copies_current = False
         self._frozen_version = None
 
     def __del__(self):
@@ -221,6 +223,7 @@ class RealiseModule(nn.Module):
         if strict and (missing or unexpected):
             raise RuntimeError("load_state_dict: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
         self._shadow_version = None
+        self._linear_copies_current = False
         self._frozen_version = None
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
@@ -254,6 +257,7 @@ class RealiseModule(nn.Module):
         with torch.no_grad():
             p.copy_(torch.as_tensor(np.asarray(table), dtype=torch.float32).reshape(p.shape))
         self._shadow_version = None
+        self._linear_copies_current = False
         self._frozen_version = None
 
     def build_glyce_embed(self, vocab_dir, font_path, font_size=32):
@@ -372,7 +376,12 @@ class RealiseModule(nn.Module):
             lib.realise_engine_invalidate_frozen(self._engine)
             self._frozen_version = ver[1]
         if self.training or not self.static_weights or self._shadow_version != ver:
-            _capi.check(lib.realise_engine_refresh_shadows(self._engine, self._stream()), "realise_engine_refresh_shadows")
+            # FusedAdamW's step wrote the Linear weights' operand copies in the pass that updated them (realise_engine_adamw): what is
+            # left to re-derive is the conv-weight copies.  Anything else that touched the parameters since (a raw p.data write) must
+            # call mark_parameters_updated(), or the module run with trust_fused_optimizer = False (the full refresh, every forward).
+            linear_current = 1 if (self._linear_copies_current and self.trust_fused_optimizer) else 0
+            _capi.check(lib.realise_engine_refresh_shadows_ex(self._engine, self._stream(), linear_current), "realise_engine_refresh_shadows")
+            self._linear_copies_current = False
             self._shadow_version = ver
 
     def _raise_on_bad_ids(self):
@@ -394,13 +403,17 @@ class RealiseModule(nn.Module):
         torch.cuda.synchronize(self.device)
         self._raise_on_bad_ids()
 
-    def mark_parameters_updated(self, frozen=True):
+    trust_fused_optimizer = True        # False: every forward re-derives all operand copies, also right after a FusedAdamW step
+    _linear_copies_current = False
+
+    def mark_parameters_updated(self, frozen=True, linear_copies_current=False):
         """call after mutating parameters through a path torch's version counter cannot see: raw pointers, or ``p.data.copy_()``
         on a parameter view (``.data`` carries its own version counter).  Weight operands are re-derived at the next forward and
         so is the NHWC image of the frozen glyph table - the one tensor that is NOT refreshed on every forward (65 M floats), so
         writing ``char_images_multifonts.data`` by hand instead of ``set_glyph_table()`` / ``build_glyce_embed*()`` needs this call.
         ``frozen=False`` (what FusedAdamW passes every step) leaves the glyph table's image alone: an optimizer never writes it."""
         self._shadow_version = None
+        self._linear_copies_current = bool(linear_copies_current)
         if frozen:
             self._frozen_version = None
 

@@ -32,6 +32,9 @@ class FusedAdamW(torch.optim.Optimizer):
         self._norm_sq = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self._step = 0
         self._ranges = None
+        # True: step through realise_engine_adamw once the module owns an engine (after its first forward): AdamW + the Linear weights'
+        # operand copies in one pass.  False: the arena-level kernels, and the module re-derives every copy at its next forward.
+        self.fused_operand_copies = True
 
     def _param_ranges(self):
         """(offset, numel) of every trainable parameter of each group inside the arena"""
@@ -80,6 +83,18 @@ class FusedAdamW(torch.optim.Optimizer):
         # the whole-arena launch is only valid when the groups hold EVERY trainable tensor of the arena exactly once
         covered = sorted(r for rng in self._param_ranges() for r in rng)
         wanted = sorted({(o, p.numel()) for name, (a, o, s, p) in mod._views.items() if a == 0 and p is not None})
+        fused = self.fused_operand_copies and len(self.param_groups) <= 8 and getattr(mod, "_engine", None) is not None \
+            and getattr(mod, "_shadow", None) is not None and mod.trust_fused_optimizer
+        if fused:
+            # the engine's form of the grouped sweep: the Linear weights are stepped in the tiles of the operand-copy kernel, which stores
+            # the new fp32 value and its bf16 W / W^T copies in one pass - the next forward skips that part of the refresh
+            groups = (_capi.AdamwGroup * len(self.param_groups))()
+            for k, g in enumerate(self.param_groups):
+                groups[k] = _capi.AdamwGroup(g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], 1 if g["correct_bias"] else 0)
+            _capi.check(lib.realise_engine_adamw(mod._engine, st, self._m.data_ptr(), self._v.data_ptr(), self._group_map(flat_p).data_ptr(), groups,
+                                                 len(self.param_groups), self._step, norm_ptr, max_norm), "realise_engine_adamw")
+            mod.mark_parameters_updated(frozen=False, linear_copies_current=True)
+            return
         if uniform and covered == wanted:
             _capi.check(lib.realise_adamw(st, flat_p.data_ptr(), flat_g.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
                                           flat_p.numel(), g0["lr"], g0["betas"][0], g0["betas"][1], g0["eps"], g0["weight_decay"],

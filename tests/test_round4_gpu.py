@@ -83,3 +83,49 @@ def test_split_k_classifier_gradient_matches_the_single_launch():
             continue
         cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
         assert cos > 0.999, (n, cos)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_fused_adamw_writes_the_operand_copies_it_updates(dtype):
+    """FusedAdamW through realise_engine_adamw (the Linear weights stepped in the tiles of the operand-copy kernel, bf16 W / W^T copies
+    written in the same pass; the refresh of the next forward skips them): (1) three steps give the same parameters and moments as the
+    arena-level kernels + full refresh; (2) the copies the step wrote ARE the copies a full refresh derives - logits of the forward
+    right after the step are bit-identical to the logits after mark_parameters_updated(); (3) decay / no-decay groups with a real
+    weight decay go through the same path."""
+    from realise_amd.optim import FusedAdamW
+    cfg = RealiseConfig(num_hidden_layers=2, pho_layers=1, out_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = init_state_dict_numpy(cfg, seed=3)
+    batch = synthetic_batch(4, 32, seed=9)
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def run(fused):
+        m = build(cfg, sd, dtype, train=True)
+        no_decay = ["bias", "LayerNorm.weight"]
+        groups = [{"params": [p for n, p in m.named_parameters() if p.requires_grad and not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+                  {"params": [p for n, p in m.named_parameters() if p.requires_grad and any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+        opt = FusedAdamW(m, groups, lr=1e-3, eps=1e-6, max_grad_norm=1.0)
+        opt.fused_operand_copies = fused
+        losses = []
+        for _ in range(3):
+            m.zero_grad()
+            loss, _ = m(batch)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        m.eval()
+        with torch.no_grad():
+            _, logits_a = m(batch)
+            m.mark_parameters_updated()
+            _, logits_b = m(batch)
+        torch.cuda.synchronize()
+        return losses, m.flat_parameters().clone(), opt._m.clone(), opt._v.clone(), logits_a.clone(), logits_b.clone()
+
+    lf, pf, mf, vf, la_f, lb_f = run(True)
+    lu, pu, mu, vu, la_u, lb_u = run(False)
+    assert torch.equal(la_f, lb_f), "operand copies written by the optimizer differ from a full refresh"
+    assert torch.equal(la_u, lb_u)
+    tol = 1e-6 if dtype == "fp32" else 2e-3          # bf16: the steps see each other's copies only through bf16 forward passes
+    for a, b in zip(lf, lu):
+        assert abs(a - b) <= tol * max(1.0, abs(b)), (lf, lu)
+    assert (mf - mu).abs().max().item() <= 1e-3 * mu.abs().max().item() + 1e-12
+    assert (pf - pu).abs().max().item() <= 5e-3 * 1e-3 * 3 + 1e-7 if dtype == "bf16" else (pf - pu).abs().max().item() <= 1e-6
