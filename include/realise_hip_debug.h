@@ -108,6 +108,12 @@ void realise_profile_pause(int paused);
 int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work);
 /* per-launch records of one family in launch order (host arrays of max_records entries); returns the number written */
 int realise_profile_dump(int kernel_family, int max_records, float* ms_out, double* work_out);
+/* the same with the EXECUTED work next to the booked (nominal) one: launches bounded by a device-side row count (the loss rows of the
+ * classifier's gradients, the live blocks of a padded batch in the weight-gradient reductions, the GRU's alive sequences) book
+ * 2.M.N.K for the nominal M and execute fewer rows; the counters are read from the device when the records are read (valid while
+ * the batch shape does not change between the sampled steps and the read) */
+int realise_profile_read_ex(int kernel_family, long long* count, double* total_ms, double* total_work, double* total_work_executed);
+int realise_profile_dump_ex(int kernel_family, int max_records, float* ms_out, double* work_out, double* work_executed_out);
 
 
 #ifdef __cplusplus

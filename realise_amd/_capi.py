@@ -154,6 +154,8 @@ SYMBOLS = {
     "realise_profile_mode": (None, [_I]),
     "realise_profile_dump": (_I, [_I, _I, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
     "realise_profile_read": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "realise_profile_read_ex": (_I, [_I, C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "realise_profile_dump_ex": (_I, [_I, _I, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

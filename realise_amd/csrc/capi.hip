@@ -482,6 +482,13 @@ void realise_profile_pause(int paused) { prof_pause(paused); }
 void realise_profile_mode(int attached) { prof_set_mode(attached); }
 void realise_profile_disable(void) { prof_disable(); }
 int realise_profile_dump(int kernel_family, int max_records, float* ms_out, double* work_out) { return prof_dump(kernel_family, max_records, ms_out, work_out); }
+int realise_profile_dump_ex(int kernel_family, int max_records, float* ms_out, double* work_out, double* work_exec_out) {
+  return prof_dump(kernel_family, max_records, ms_out, work_out, work_exec_out);
+}
+int realise_profile_read_ex(int kernel_family, long long* count, double* total_ms, double* total_work, double* total_work_executed) {
+  if (kernel_family < 0 || kernel_family >= PK_COUNT || !count || !total_ms || !total_work || !total_work_executed) return RL_ERR_ARG;
+  return prof_read(kernel_family, count, total_ms, total_work, total_work_executed);
+}
 int realise_profile_read(int kernel_family, long long* count, double* total_ms, double* total_work) {
   if (kernel_family < 0 || kernel_family >= PK_COUNT || !count || !total_ms || !total_work) return RL_ERR_ARG;
   return prof_read(kernel_family, count, total_ms, total_work);

@@ -403,6 +403,8 @@ static int launch_nt_tile(hipStream_t st, const ALoader& la, const DenseLoader<T
     attr_set = true;
   }
   ProfScope ps(st, sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos) ? PK_GEMM_NT : PK_CONV_NT, 2.0 * M * N * K);
+  if constexpr (sizeof(typename ALoader::KPos) == sizeof(typename DenseLoader<T>::KPos))      // (the conv families are scaled by the live-glyph fraction in bench.py)
+    if (la.rows_dev != nullptr) prof_set_exec(la.rows_dev, 2.0 * N * K, BM_, M);   // device-side row bound: surplus tiles exit at once
   EpiParams<T> epp = ep;
   epp.probe = g_nt_probe;
   epp.wide = g_nt_wide && (N % 8 == 0) && (ep.ldo % 8 == 0) && (ep.aux == nullptr || ep.ldaux % 8 == 0);
@@ -930,6 +932,8 @@ static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader
   dim3 grid(ntiles * nsplit);
   {
     ProfScope ps(st, sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos) ? PK_GEMM_TN : PK_CONV_TN, 2.0 * P * I * J);
+    if constexpr (sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos))
+      if (lb.rows_dev != nullptr) prof_set_exec(lb.rows_dev, 2.0 * I * J, G::BP, P);       // the reduction stops at the device-side row bound
     if (sizeof(T) == 2 && g_tn_tr) {
       static bool a1 = false;
       if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, true, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
@@ -984,6 +988,7 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
   const int pchunk = ((P + G::BP - 1) / G::BP) * G::BP;
   const size_t lds = 2 * (size_t)G::BP * 256 * sizeof(T);
   ProfScope ps(st, PK_GEMM_TN, flops);
+  if (grp.tile_list != nullptr) prof_set_exec(grp.n_tiles, flops / P * grp.list_rows, sizeof(T) == 2 && grp.list_rows == 16 ? 4 : 1, P / grp.list_rows);   // live blocks only
   // ring: the 2 full stages of the single-problem kernel (default) or 4 stages of half tiles (three tiles in flight per workgroup,
   // g_tn_group_ring = 1: built to test the fetch-latency hypothesis - 11 % slower)
 #define RL_TN_GROUP(TRV, NSTV, BPDV) do { \

@@ -263,6 +263,7 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
     attr_set = true;
   }
   ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
+  if (ep.m_dev != nullptr) prof_set_exec(ep.m_dev, 2.0 * N * K, C::BM, M);      // tiles that start at or beyond the count leave at once
 #if RL_PROBES
   if constexpr (!KTAIL) {
     if (g_nt8_probe == 2) { RL_LAUNCH((gemm_nt8_kernel<C, 2>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }

@@ -13,8 +13,26 @@ CLS, SEP, PAD = 101, 102, 0
 PHO_UNK = 32  # 'U' in Pinyin2's vocab (src/utils.py:61-67)
 
 
+def synthetic_pinyin_table(vocab_size=21128, seed=0, id_lo=670):
+    """A per-vocabulary pinyin table with the statistics of the synthetic batches (tone first, 2..7 symbols per character, 'U' for
+    the ids below ``id_lo``: specials, ASCII, word pieces): the stand-in for ``PinyinTable.build(tokenizer vocabulary)`` when neither
+    vocab.txt nor pypinyin is at hand.  ``synthetic_batch(..., pinyin_table=t)`` and ``model.set_pinyin_table(t)`` then describe the
+    same batch through the host and the device ``build_batch``."""
+    from .pinyin import MAX_LEN, PinyinTable
+    g = np.random.Generator(np.random.Philox(key=[0x91A71E, seed]))
+    lens = g.integers(2, MAX_LEN + 1, size=vocab_size).astype(np.int32)
+    table = g.integers(6, 32, size=(vocab_size, MAX_LEN)).astype(np.int64)
+    table[:, 0] = g.integers(1, 6, size=vocab_size)
+    table[np.arange(MAX_LEN)[None, :] >= lens[:, None]] = 0
+    special = np.arange(vocab_size) < id_lo
+    table[special] = 0
+    table[special, 0] = PHO_UNK
+    lens[special] = 1
+    return PinyinTable(table, lens)
+
+
 def synthetic_batch(batch_size, seq_len, vocab_size=21128, seed=0, with_pho=True, full_length=False,
-                    id_lo=670, id_hi=7992):
+                    id_lo=670, id_hi=7992, pinyin_table=None):
     g = np.random.Generator(np.random.Philox(key=[0x5EA115E, seed]))
     id_hi = min(id_hi, vocab_size)
     id_lo = min(id_lo, max(1, id_hi - 1))
@@ -43,7 +61,11 @@ def synthetic_batch(batch_size, seq_len, vocab_size=21128, seed=0, with_pho=True
         "lengths": lengths, "tokens_size": [[1] * l for l in lengths],
         "id": list(range(batch_size)), "src": [""] * batch_size, "tgt": [""] * batch_size,
     }
-    if with_pho:
+    if with_pho and pinyin_table is not None:       # the reference's build_batch: pinyin as a function of the token (models.py:797-804)
+        pho, lens = pinyin_table.convert(src)
+        batch["pho_idx"] = torch.from_numpy(np.ascontiguousarray(pho))
+        batch["pho_lens"] = [int(x) for x in lens]
+    elif with_pho:
         flat = src.reshape(-1)
         is_char = (flat != CLS) & (flat != SEP) & (flat != PAD)
         n = flat.shape[0]

@@ -17,7 +17,7 @@ class _GradSync:
     """grad_dtype "bf16": the buckets cross the wire as bf16 copies (half the bytes of the 679 MB fp32 exchange, SURVEY.md
     section 5); the fp32 arena receives the reduced values back.  Pre-division by the world size happens in fp32 first."""
 
-    def __init__(self, buckets, world, group, use_side_stream, grad_dtype="fp32"):
+    def __init__(self, buckets, world, group, use_side_stream, grad_dtype="fp32", bucket_cap_mb=None, collect_stats=False):
         if grad_dtype not in ("fp32", "bf16"):
             raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
         self.buckets, self.world, self.group = buckets, world, group
@@ -25,19 +25,73 @@ class _GradSync:
         self.wire = [torch.empty_like(b, dtype=torch.bfloat16) for b in buckets] if grad_dtype == "bf16" else None
         self.avg_op = dist.get_backend(group) == "nccl"
         self.works = []
+        # bucket_cap_mb: an engine bucket (one backward stage: 60-230 MB in fp32) goes out as several collectives of at most this
+        # many MB of wire bytes each (None: one collective per bucket).  On a point-to-point xGMI mesh a ring all-reduce is
+        # per-link bound, so the knob trades launch count against how early the first bytes of a stage move.
+        self.bucket_cap_mb = bucket_cap_mb
+        self.collect_stats = bool(collect_stats) and use_side_stream
+        self._ev = None
+        self.last_stats = None
+
+    def _chunks(self, t):
+        if not self.bucket_cap_mb:
+            return [t]
+        n = max(1, int(self.bucket_cap_mb * (1 << 20)) // t.element_size())
+        return [t[o:o + n] for o in range(0, t.numel(), n)]
+
+    def wire_bytes(self):
+        """bytes every rank hands to the collectives per step, bucket by bucket (communication order is the caller's)"""
+        return [(self.wire[i] if self.wire is not None else b).numel() * (2 if self.wire is not None else 4) for i, b in enumerate(self.buckets)]
 
     def _launch(self, i):
         buf = self.buckets[i]
+        if self.collect_stats:
+            self._mark(i, 0)
         if self.wire is not None:
             # pre-divide and narrow in ONE pass over the bucket: SUM of bf16(g / W) == mean, overflow-safe
             torch.mul(buf, 1.0 / self.world, out=self.wire[i])
-            self.works.append((i, dist.all_reduce(self.wire[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            for c in self._chunks(self.wire[i]):
+                self.works.append((i, dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
         elif self.avg_op:
             # RCCL averages inside the collective (ncclAvg): no pre-divide pass over the 679 MB arena
-            self.works.append((i, dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)))
+            for c in self._chunks(buf):
+                self.works.append((i, dist.all_reduce(c, op=dist.ReduceOp.AVG, group=self.group, async_op=True)))
         else:
             buf.div_(self.world)                           # gloo has no AVG: pre-divide, then SUM
-            self.works.append((i, dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            for c in self._chunks(buf):
+                self.works.append((i, dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+
+    # ---- per-bucket timeline of the last step (collect_stats): when each bucket became ready on the communication stream, when its
+    # collectives had completed, and when the backward itself was done - what says whether the exchange hides under the backward
+    def _mark(self, i, which):
+        if self._ev is None:
+            self._ev = {"ready": [torch.cuda.Event(enable_timing=True) for _ in self.buckets],
+                        "done": [torch.cuda.Event(enable_timing=True) for _ in self.buckets],
+                        "bwd_done": torch.cuda.Event(enable_timing=True), "order": []}
+        if which == 0:
+            if not self._ev["order"] or len(self._ev["order"]) >= len(self.buckets):
+                self._ev["order"] = []
+            self._ev["order"].append(i)
+            self._ev["ready"][i].record()
+        else:
+            self._ev["done"][i].record()
+
+    def read_stats(self):
+        """milliseconds relative to the first bucket's ready time; synchronises.  None before the first collected step."""
+        if not self.collect_stats or self._ev is None or len(self._ev["order"]) != len(self.buckets):
+            return None
+        torch.cuda.synchronize()
+        order = list(self._ev["order"])
+        t0 = self._ev["ready"][order[0]]
+        ready = [t0.elapsed_time(self._ev["ready"][i]) for i in order]
+        done = [t0.elapsed_time(self._ev["done"][i]) for i in order]
+        bwd = t0.elapsed_time(self._ev["bwd_done"])
+        wb = self.wire_bytes()
+        self.last_stats = {"comm_order": order, "bucket_wire_bytes": [wb[i] for i in order], "bucket_ready_ms": [round(x, 3) for x in ready],
+                           "bucket_done_ms": [round(x, 3) for x in done], "backward_done_ms": round(bwd, 3),
+                           "exposed_tail_ms": round(max(0.0, done[-1] - bwd), 3), "tail_bucket_wire_bytes": wb[order[-1]],
+                           "bucket_cap_mb": self.bucket_cap_mb, "collectives_per_step": sum(len(self._chunks(self.wire[i] if self.wire is not None else self.buckets[i])) for i in order)}
+        return self.last_stats
 
     # ---- event-driven form: the engine runs the whole (branch-overlapped) backward in one call and records events[i] when
     # bucket i is final; the communication stream waits on each event in a FIXED order (identical on every rank, as the
@@ -68,13 +122,19 @@ class _GradSync:
             self._launch(i)
 
     def _drain(self):
-        for i, w in self.works:
+        last = {i: k for k, (i, w) in enumerate(self.works)}
+        for k, (i, w) in enumerate(self.works):
             w.wait()
-            if self.wire is not None:
-                self.buckets[i].copy_(self.wire[i])
+            if last[i] == k:                    # the bucket's last collective
+                if self.wire is not None:
+                    self.buckets[i].copy_(self.wire[i])
+                if self.collect_stats:
+                    self._mark(i, 1)
         self.works = []
 
     def finish(self):
+        if self.collect_stats and self._ev is not None:
+            self._ev["bwd_done"].record(torch.cuda.current_stream())
         if self.stream is not None:
             with torch.cuda.stream(self.stream):
                 self._drain()
@@ -87,7 +147,7 @@ class DistributedDataParallel(nn.Module):
     """``DistributedDataParallel(model)`` for a RealiseModule (or any module exposing
     ``bucket_views()``, ``flat_parameters()``, ``flat_bn_buffers()`` and a ``grad_sync`` slot)."""
 
-    def __init__(self, module, process_group=None, broadcast_buffers=True, grad_dtype="fp32"):
+    def __init__(self, module, process_group=None, broadcast_buffers=True, grad_dtype="fp32", bucket_cap_mb=None, collect_stats=False):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -100,7 +160,7 @@ class DistributedDataParallel(nn.Module):
                 if a.numel() > 1:
                     dist.broadcast(a, src=0, group=process_group)
             module.mark_parameters_updated()
-        module.grad_sync = _GradSync(module.bucket_views(), self.world, process_group, flat.is_cuda, grad_dtype)
+        module.grad_sync = _GradSync(module.bucket_views(), self.world, process_group, flat.is_cuda, grad_dtype, bucket_cap_mb, collect_stats)
 
     def forward(self, *args, **kw):
         if self.broadcast_buffers and self.module.training:
