@@ -32,6 +32,11 @@ void realise_set_engine(int key, int value);
  * of the k-th block of `list_rows` rows that holds anything but exact zeros in the A operands, *n_live (device) = how many; the other
  * blocks are not read.  list_rows = 64 (bf16) / 32 (fp32): whole reduction tiles; 16 (bf16): four live blocks form a reduction tile.
  * overwrite != 0: out = result instead of out += result. */
+/* realise_gemm_nt bounded by a DEVICE-side row count, as the GRU steps of a device-built batch launch it: rows at or beyond
+ * *rows_dev contribute zeros (an accumulating epilogue leaves them unchanged, a storing one writes bias-only rows in the last live
+ * tile and nothing beyond it). */
+int realise_gemm_nt_rows(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                         const realise_epilogue* ep, const int* rows_dev);
 /* Split-K form of the 8-wave NT GEMM as the classifier's data gradient uses it (bf16, K % 64 == 0): slab[s][m][n] (fp32, row pitch N,
  * plane pitch slab_stride floats) = A[m, K-range s] . B[n, K-range s]^T; rows at or beyond *m_dev (device, nullable) are not computed. */
 int realise_gemm_nt_splitk(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int nsplit,

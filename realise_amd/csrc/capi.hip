@@ -112,6 +112,14 @@ int realise_gemm_tn_grouped(void* stream, int dtype, int n, const realise_tn_pro
   if (dtype == REALISE_F32) return tn_grouped<float>(st, n, problems, P);
   return RL_ERR_ARG;
 }
+int realise_gemm_nt_rows(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                         const realise_epilogue* ep, const int* rows_dev) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!ep || !ep->out || !rows_dev) return RL_ERR_ARG;
+  if (dtype == REALISE_BF16) return gemm_nt<bf16_t>(st, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, to_epi<bf16_t>(ep), rows_dev);
+  if (dtype == REALISE_F32) return gemm_nt<float>(st, (const float*)A, lda, (const float*)B, ldb, M, N, K, to_epi<float>(ep), rows_dev);
+  return RL_ERR_ARG;
+}
 int realise_gemm_nt_splitk(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int nsplit,
                            float* slab, int64_t slab_stride, const int* m_dev) {
   return gemm_nt8_splitk((hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, nsplit, slab, slab_stride, m_dev);

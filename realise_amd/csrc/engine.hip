@@ -103,7 +103,9 @@ template <typename T> struct Engine : EngineBase {
   bool glyph_built = false, descs_built = false;
   int64_t sh_descs = 0, sh_fill = 0, sh_skip = 0;
   bool skip_built = false;
-  std::vector<uint8_t> skip_host;
+  static constexpr int ACHUNK_MAX = 8192, ACHUNK_LEN = 32768;
+  std::vector<FillChunk> achunk_host;
+  int n_achunks = 0;
   static constexpr int FILL_MAX = 2048;
   int n_descs = 0, desc_tiles = 0;
   std::vector<CastDesc> desc_host;
@@ -256,7 +258,7 @@ template <typename T> struct Engine : EngineBase {
     }
     sh_descs = b.take(256 * (int64_t)sizeof(CastDesc));      // device table for the one-launch refresh of the Linear weights
     sh_fill = b.take(FILL_MAX * (int64_t)sizeof(FillChunk));  // chunk table of the fresh-gradient zero fill
-    sh_skip = b.take((L.arena_elems[AR_TRAIN] + 63) / 64);    // a byte per 64 parameters: stepped by the tiled AdamW (adamw_step)
+    sh_skip = b.take(ACHUNK_MAX * (int64_t)sizeof(FillChunk));   // chunk list of the parameters the tiled AdamW does NOT own (adamw_step)
     shadow_total = b.off;
   }
 
@@ -360,20 +362,32 @@ template <typename T> struct Engine : EngineBase {
     RL_TRY(ensure_descs(st));
     const int64_t n = L.arena_elems[AR_TRAIN];
     if (!skip_built) {
-      skip_host.assign((size_t)((n + 63) / 64), 0);
+      // everything outside the Linear weights, as chunks of at most ACHUNK_LEN floats (all boundaries are multiples of 64 elements)
+      std::vector<std::pair<int64_t, int64_t>> own;
       for (const CastDesc& d : desc_host) {
         const int64_t off = d.src - P, cnt = (int64_t)d.R * d.C;
         if ((off % 64) != 0 || (cnt % 64) != 0 || (d.C % 4) != 0) return RL_ERR_ARG;
-        for (int64_t b = off / 64; b < (off + cnt) / 64; ++b) skip_host[(size_t)b] = 1;
+        own.push_back({off, off + cnt});
       }
-      if (hipMemcpyAsync(sh + sh_skip, skip_host.data(), skip_host.size(), hipMemcpyHostToDevice, st) != hipSuccess) return RL_ERR_LAUNCH;
+      std::sort(own.begin(), own.end());
+      achunk_host.clear();
+      int64_t at = 0;
+      auto emit = [&](int64_t b, int64_t e) {
+        for (int64_t o = b; o < e; o += ACHUNK_LEN) achunk_host.push_back(FillChunk{o, (int32_t)std::min<int64_t>(ACHUNK_LEN, e - o), 0});
+      };
+      for (auto& r : own) { if (r.first > at) emit(at, r.first); at = std::max(at, r.second); }
+      if (at < n) emit(at, n);
+      if ((int)achunk_host.size() > ACHUNK_MAX) return RL_ERR_ARG;
+      if (!achunk_host.empty() &&
+          hipMemcpyAsync(sh + sh_skip, achunk_host.data(), achunk_host.size() * sizeof(FillChunk), hipMemcpyHostToDevice, st) != hipSuccess) return RL_ERR_LAUNCH;
+      n_achunks = (int)achunk_host.size();
       skip_built = true;
     }
     RL_TRY(wait_shadows(st));           // (the previous refresh may still be writing the copies on the branch streams)
     const CastDesc* dd = (const CastDesc*)(sh + sh_descs);
     RL_TRY(adamw_cast_multi<T>(st, dd, n_descs_a, desc_tiles_a, P, G, m, v, group_of_block, gs, norm_sq, max_norm));
     RL_TRY(adamw_cast_multi<T>(st, dd + n_descs_a, n_descs - n_descs_a, desc_tiles, P, G, m, v, group_of_block, gs, norm_sq, max_norm));
-    return adamw_grouped(st, P, G, m, v, n, group_of_block, gs, norm_sq, max_norm, (const uint8_t*)(sh + sh_skip));
+    return adamw_chunks(st, P, G, m, v, (const FillChunk*)(sh + sh_skip), n_achunks, group_of_block, gs, norm_sq, max_norm);
   }
   // operand copies refreshed on the branch streams: order `s` behind them (no-op when they ran on the caller's stream)
   hipEvent_t ev_shadow[2] = {nullptr, nullptr};

@@ -33,6 +33,10 @@ template <typename T> struct EpiParams {
   // live tile beyond the count are still computed and stored: for outputs whose dead rows nobody reads - the compacted classifier
   // data gradient, engine.hip stage_head)
   const int* m_dev = nullptr;
+  // m_exact != 0 (with m_dev): the A rows at or beyond the count read as zeros (their fetches park out of range), so a partly live
+  // tile stores bias-only rows / leaves accumulated rows unchanged - what a launch bounded by a device-side row count needs when its
+  // output rows beyond the count ARE read later (the GRU's recurrent data gradient, accumulated into dh)
+  int m_exact = 0;
   // split-K form of the 8-wave kernel (gemm_nt8_splitk): the launch covers ksplit K-ranges of every tile and each workgroup stores its
   // fp32 partial tile to slab[split][row][col] (row pitch N, plane pitch slab_stride floats) instead of running an epilogue; the
   // caller folds the planes in a fixed order

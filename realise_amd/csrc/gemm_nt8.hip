@@ -79,7 +79,9 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   int tm, tn;
   tile_coords(tile, tiles_n, ntiles, group_m, tm, tn);
   const int m0 = tm * C::BM, n0 = tn * C::BN;
-  if (ep.m_dev != nullptr && m0 >= *ep.m_dev) return;      // device-side live-row count: the whole workgroup leaves before any barrier
+  const int mlive = ep.m_dev != nullptr ? *ep.m_dev : M;
+  if (m0 >= mlive) return;                                  // device-side live-row count: the whole workgroup leaves before any barrier
+  const int mzero = ep.m_exact ? mlive : M;                 // A rows at or beyond it read as zeros
   const int nk = (K + 63) >> 6;
   const int ktail = KTAIL ? (K & 63) : 0;   // elements of a ragged last K-tile (multiple of 8); KTAIL = false: K % 64 == 0
 
@@ -101,6 +103,7 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
     lo[s] = (is_b ? C::A_BYTES : 0) + row * 128;
     const int grow = is_b ? min(n0 + row + lrow, N - 1) : min(m0 + row + lrow, M - 1);
     go[s] = (uint32_t)((int64_t)grow * (is_b ? ldb : lda) * 2 + kchunk_b);
+    if (!is_b && m0 + row + lrow >= mzero) go[s] = 0xFFFFFF00u;     // beyond num_records: the buffer range check returns zeros
   }
   // Fetches are raw-buffer LDS-DMA loads: resource descriptor + K-tile byte offset in SGPRs, the per-lane row/chunk offset in
   // ONE 32-bit VGPR per piece - no vector ALU work per fetch (a 64-bit flat address costs two v_lshl_add_u64 each, which showed

@@ -264,6 +264,9 @@ int clip_scale(hipStream_t st, float* g, int64_t n, const float* norm_sq, float 
 int fill_f32(hipStream_t st, float* p, float v, int64_t n);
 struct FillChunk { int64_t off; int32_t len, pad; };     // off: 4-element aligned
 int zero_chunks(hipStream_t st, float* base, const FillChunk* chunks_dev, int n);
+// the grouped AdamW sweep over a chunk list (off, len multiples of 64 elements; one workgroup per chunk)
+int adamw_chunks(hipStream_t st, float* p, const float* g, float* m, float* v, const FillChunk* chunks_dev, int n_chunks,
+                 const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq, float max_norm);
 int add_i64(hipStream_t st, int64_t* p, int64_t v, int n);
 
 }  // namespace rl

@@ -69,15 +69,23 @@ __global__ void __launch_bounds__(1024) pho_prepare_kernel(const int64_t* __rest
     const int l = (v >= 0 && v < V) ? vlens[v] : 1;
     return min(max(l, 1), Tw);
   };
-  for (int t = t0; t < t1; ++t) {                         // gather the per-vocabulary rows
-    const int64_t v = src[t];
-    for (int k = 0; k < Tw; ++k) pho_idx[(int64_t)t * Tw + k] = (v >= 0 && v < V) ? table[v * Tw + k] : (k == 0 ? 32 : 0);
-  }
+  // (the per-vocabulary rows are gathered by pho_gather_kernel, one thread per symbol: this workgroup only sorts)
+  constexpr int CACHE = 16;                               // lengths of the thread's run, read once (T_ <= 16384; longer runs re-read)
+  int myl[CACHE];
+#pragma unroll
+  for (int k = 0; k < CACHE; ++k) myl[k] = (per <= CACHE && t0 + k < t1) ? len_of(t0 + k) : 0;
+  auto len_at = [&](int t) {
+    if (per > CACHE) return len_of(t);
+    int l = 0;
+#pragma unroll
+    for (int k = 0; k < CACHE; ++k) if (k == t - t0) l = myl[k];
+    return l;
+  };
   if (tid == 0) base_s = 0;
   __syncthreads();
   for (int L = Tw; L >= 1; --L) {                         // longest first
     int c = 0;
-    for (int t = t0; t < t1; ++t) c += len_of(t) == L;
+    for (int t = t0; t < t1; ++t) c += len_at(t) == L;
     int incl = c;                                         // inclusive scan inside the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
@@ -88,7 +96,7 @@ __global__ void __launch_bounds__(1024) pho_prepare_kernel(const int64_t* __rest
     const int base = base_s;
     int pos = base + before + incl - c;
     for (int t = t0; t < t1; ++t)
-      if (len_of(t) == L) { perm[pos] = t; lens_sorted[pos] = L; ++pos; }
+      if (len_at(t) == L) { perm[pos] = t; lens_sorted[pos] = L; ++pos; }
     __syncthreads();
     if (tid == 0) {
       base_s = base + total;
@@ -96,6 +104,14 @@ __global__ void __launch_bounds__(1024) pho_prepare_kernel(const int64_t* __rest
     }
     __syncthreads();
   }
+}
+__global__ void __launch_bounds__(256) pho_gather_kernel(const int64_t* __restrict__ src, int T_, const int64_t* __restrict__ table, int V, int Tw,
+                                                         int64_t* __restrict__ pho_idx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)T_ * Tw) return;
+  const int t = (int)(i / Tw), k = (int)(i - (int64_t)t * Tw);
+  const int64_t v = src[t];
+  pho_idx[i] = (v >= 0 && v < V) ? table[v * Tw + k] : (k == 0 ? 32 : 0);
 }
 // Token-id range check (nn.Embedding raises on an id outside its table, modeling_bert.py:183-186; models.py:818,831): the engine
 // reads CLEAN copies - ids clamped into [0, V) so that nothing downstream can index past a table - and a sticky flag (device- or
@@ -117,6 +133,7 @@ int pho_prepare(hipStream_t st, const int64_t* src, int T_, const int64_t* table
                 int64_t* pho_idx, int32_t* perm, int32_t* lens_sorted, int32_t* n_alive) {
   if (T_ <= 0) return RL_OK;
   if (Tw < 1 || Tw > 16 || V < 1) return RL_ERR_ARG;
+  hipLaunchKernelGGL(pho_gather_kernel, dim3((unsigned)(((int64_t)T_ * Tw + 255) / 256)), dim3(256), 0, st, src, T_, table, V, Tw, pho_idx);
   hipLaunchKernelGGL(pho_prepare_kernel, dim3(1), dim3(1024), 0, st, src, T_, table, vlens, V, Tw, pho_idx, perm, lens_sorted, n_alive);
   return RL_LAUNCH_CHECK();
 }
@@ -644,22 +661,20 @@ __global__ void __launch_bounds__(256) conv_weight_shadow_multi_kernel(ConvShado
   T* fwd = (T*)d.fwd;
   T* dgrad = (T*)d.dgrad;
   const int Co = d.Co, Ci = d.Ci, KHW = d.KHW, Cpad = d.Cpad;
-  const int64_t nf = (int64_t)Co * KHW * Cpad, nd = (int64_t)d.CiRows * KHW * Co;
-  for (int64_t i = (int64_t)(blockIdx.x - d.block_begin) * 256 + threadIdx.x; i < nf + nd; i += (int64_t)nb * 256) {
+  const int nf = Co * KHW * Cpad, nd = d.CiRows * KHW * Co;           // < 2^31 (checked by the launcher): 32-bit index arithmetic
+  for (int i = (int)(blockIdx.x - d.block_begin) * 256 + (int)threadIdx.x; i < nf + nd; i += nb * 256) {
     if (i < nf) {
       if (fwd == nullptr) continue;
-      const int ci = (int)(i % Cpad);
-      const int tap = (int)((i / Cpad) % KHW);
-      const int co = (int)(i / ((int64_t)Cpad * KHW));
-      fwd[i] = from_f<T>(ci < Ci ? d.w[((int64_t)co * Ci + ci) * KHW + tap] : 0.f);
+      const int ci = i % Cpad, rest = i / Cpad;
+      const int tap = rest % KHW, co = rest / KHW;
+      fwd[i] = from_f<T>(ci < Ci ? d.w[(co * Ci + ci) * KHW + tap] : 0.f);
     } else {
       if (dgrad == nullptr) continue;
-      const int64_t q = i - nf;
-      const int co = (int)(q % Co);
-      const int tap = (int)((q / Co) % KHW);
-      const int ci = (int)(q / ((int64_t)Co * KHW));
+      const int q = i - nf;
+      const int co = q % Co, rest = q / Co;
+      const int tap = rest % KHW, ci = rest / KHW;
       const int src_tap = d.order.n ? d.order.t[tap] : tap;
-      dgrad[q] = from_f<T>(ci < Ci ? d.w[((int64_t)co * Ci + ci) * KHW + src_tap] : 0.f);
+      dgrad[q] = from_f<T>(ci < Ci ? d.w[(co * Ci + ci) * KHW + src_tap] : 0.f);
     }
   }
 }
@@ -670,8 +685,9 @@ template <typename T> int conv_weight_shadow_multi(hipStream_t st, ConvShadowDes
     const ConvShadowDesc& d = ds.d[k];
     if (d.order.n != 0 && d.order.n != d.KHW) return RL_ERR_ARG;
     const int64_t n = (int64_t)d.Co * d.KHW * d.Cpad + (int64_t)d.CiRows * d.KHW * d.Co;
+    if (n >= (1ll << 30)) return RL_ERR_ARG;
     ds.d[k].block_begin = blocks;
-    blocks += (int)std::min<int64_t>(64, std::max<int64_t>(1, (n + 2047) / 2048));      // ~8 elements per thread, at most 64 blocks per tensor
+    blocks += (int)std::max<int64_t>(1, (n + 1023) / 1024);      // 4 elements per thread (the index arithmetic is a few integer divisions per element)
   }
   hipLaunchKernelGGL((conv_weight_shadow_multi_kernel<T>), dim3(blocks), dim3(256), 0, st, ds);
   return RL_LAUNCH_CHECK();
@@ -775,6 +791,56 @@ int adamw_grouped(hipStream_t st, float* p, const float* g, float* m, float* v, 
   if (n <= 0) return RL_OK;
   if (gs.n < 1 || gs.n > ADAMW_MAX_GROUPS || group_of_block == nullptr) return RL_ERR_ARG;
   hipLaunchKernelGGL(adamw_grouped_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, p, g, m, v, n, group_of_block, gs, norm_sq, max_norm, skip_block);
+  return RL_LAUNCH_CHECK();
+}
+
+// the grouped sweep over a chunk list (block b steps chunk b: [off, off + len), len <= 64 Ki floats, 64-element aligned): what the
+// tiled launches below do not own
+__global__ void __launch_bounds__(256) adamw_chunks_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                           const FillChunk* __restrict__ chunks, const uint8_t* __restrict__ group_of_block, AdamwGroups gs,
+                                                           const float* __restrict__ norm_sq, float max_norm) {
+  float clip = 1.0f;
+  if (norm_sq != nullptr) {
+    const float c = max_norm / (sqrtf(norm_sq[0]) + 1e-6f);
+    clip = c < 1.0f ? c : 1.0f;
+  }
+  const FillChunk ch = chunks[blockIdx.x];
+  if (threadIdx.x == 0)
+    for (int k = ch.len & ~3; k < ch.len; ++k) {          // a tensor whose length is not a multiple of 4 ends the arena
+      const int64_t i = ch.off + k;
+      const int gid = group_of_block[i >> 6];
+      if (gid >= gs.n) continue;
+      const AdamwGroup h = gs.g[gid];
+      const float gi = g[i] * clip;
+      const float mi = m[i] * h.beta1 + (1.0f - h.beta1) * gi;
+      const float vi = v[i] * h.beta2 + (1.0f - h.beta2) * gi * gi;
+      float pi = p[i] - h.step_size * (mi / (sqrtf(vi) + h.eps));
+      if (h.weight_decay > 0.f) pi -= h.lr * h.weight_decay * pi;
+      m[i] = mi; v[i] = vi; p[i] = pi;
+    }
+  for (int k = threadIdx.x * 4; k + 3 < ch.len; k += 1024) {
+    const int64_t i = ch.off + k;
+    const int gid = group_of_block[i >> 6];
+    if (gid >= gs.n) continue;
+    const AdamwGroup h = gs.g[gid];
+    floatx4 pv = *(const floatx4*)(p + i), mv = *(const floatx4*)(m + i), vv = *(const floatx4*)(v + i);
+    const floatx4 gv = *(const floatx4*)(g + i) * clip;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mv[j] = mv[j] * h.beta1 + (1.0f - h.beta1) * gv[j];
+      vv[j] = vv[j] * h.beta2 + (1.0f - h.beta2) * gv[j] * gv[j];
+      float pi = pv[j] - h.step_size * (mv[j] / (sqrtf(vv[j]) + h.eps));
+      if (h.weight_decay > 0.f) pi -= h.lr * h.weight_decay * pi;
+      pv[j] = pi;
+    }
+    *(floatx4*)(m + i) = mv; *(floatx4*)(v + i) = vv; *(floatx4*)(p + i) = pv;
+  }
+}
+int adamw_chunks(hipStream_t st, float* p, const float* g, float* m, float* v, const FillChunk* chunks_dev, int n_chunks,
+                 const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq, float max_norm) {
+  if (n_chunks <= 0) return RL_OK;
+  if (gs.n < 1 || gs.n > ADAMW_MAX_GROUPS || group_of_block == nullptr) return RL_ERR_ARG;
+  hipLaunchKernelGGL(adamw_chunks_kernel, dim3(n_chunks), dim3(256), 0, st, p, g, m, v, chunks_dev, group_of_block, gs, norm_sq, max_norm);
   return RL_LAUNCH_CHECK();
 }
 

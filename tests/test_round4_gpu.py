@@ -79,7 +79,7 @@ def test_split_k_classifier_gradient_matches_the_single_launch():
     assert not moved, moved[:6]
     for n in g3:
         a, b = g3[n].float().reshape(-1), g1[n].float().reshape(-1)
-        if b.abs().max().item() < 1e-9:
+        if b.abs().max().item() < 1e-9 or n.endswith("attention.self.key.bias"):     # (softmax is shift-invariant: a key bias gradient is rounding noise)
             continue
         cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
         assert cos > 0.999, (n, cos)
@@ -132,5 +132,33 @@ def test_fused_adamw_writes_the_operand_copies_it_updates(dtype):
     # bias - move by +-lr per step in either run whatever the kernel: Adam normalises the noise; they are not compared.)
     lin = [n for n in pf if n.endswith(".weight") and (".layer." in n or "rnn" in n or n.startswith("classifier")) and "LayerNorm" not in n]
     assert len(lin) >= 4 * 6
+    # (Adam normalises: an element whose gradient is rounding noise moves by +-lr per step whichever kernel stepped it, so single
+    # elements may differ by a few lr; the bulk must agree to rounding)
     for n in lin:
-        assert (pf[n] - pu[n]).abs().max().item() <= (1e-6 if dtype == "fp32" else 2e-5), n
+        d = (pf[n] - pu[n]).abs()
+        assert d.mean().item() <= (1e-8 if dtype == "fp32" else 2e-7), (n, d.mean().item())
+        assert (d > 2e-5).float().mean().item() <= 1e-3, (n, (d > 2e-5).float().mean().item())
+
+
+@pytest.mark.parametrize("M,N,K,live,accumulate", [(8192, 2304, 768, 5300, 0), (8192, 768, 2304, 4411, 1), (2048, 768, 768, 1, 1), (512, 256, 128, 300, 1)])
+def test_nt_gemm_bounded_by_a_device_side_row_count(M, N, K, live, accumulate):
+    """the GRU steps of a device-built batch: nominal M rows, the alive count on the device.  Rows below the count equal the dense product;
+    rows at or beyond it keep their old values under an accumulating epilogue (the recurrent data gradient is accumulated into dh, whose
+    rows beyond the count belong to sequences that are still to be visited) - also in the 8-wave kernel the large shapes now take."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(M + N + live)
+    a = (torch.randn(M, K, generator=g) * 0.1).bfloat16().cuda()
+    a[live:] = float("nan")                                   # stale rows of sequences that ended: must never reach a live output
+    b = (torch.randn(N, K, generator=g) * 0.1).bfloat16().cuda()
+    old = (torch.randn(M, N, generator=g)).bfloat16().cuda()
+    out = old.clone()
+    ep = _capi.Epilogue()
+    ep.mode, ep.accumulate, ep.out, ep.ldo, ep.alpha, ep.drop_scale = 0, accumulate, out.data_ptr(), N, 1.0, 1.0
+    cnt = torch.tensor([live], dtype=torch.int32, device="cuda")
+    _capi.check(lib.realise_gemm_nt_rows(stream(), _capi.BF16, P(a), K, P(b), K, M, N, K, C.byref(ep), P(cnt)), "gemm_nt_rows")
+    torch.cuda.synchronize()
+    ref = a[:live].float() @ b.float().t() + (old[:live].float() if accumulate else 0.0)
+    assert (out[:live].float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+    assert torch.isfinite(out.float()).all()
+    if accumulate:
+        assert torch.equal(out[live:], old[live:])
