@@ -968,6 +968,8 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb,
 static int g_tn_variant = 0;      // 0 production (the 4-wave kernel), 8 the experimental 8-wave ping-pong kernel (gemm_tn8.hip: correct, 7-16 % slower)
 void set_tn_variant(int v) { g_tn_variant = RL_PROBES ? v : 0; }
 
+static int g_tn_group8 = 1;          // grouped weight gradients on the 8-wave 256 x 128 kernel (gemm_tn8_group) where it applies
+void set_tn_group8(int on) { g_tn_group8 = on; }
 static int g_tn_group_ring = 0;      // measured: 4 x 32-row stages 3.76 ms/step vs 3.39 for 2 x 64-row stages (more barriers, smaller DMA batches)
 void set_tn_group_ring(int on) { g_tn_group_ring = on; }
 
@@ -976,6 +978,12 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
                   const int* n_tiles, int list_rows) {
   typedef TnGeo<T> G;
   if (n < 1 || n > TN_GROUP_MAX || P <= 0) return RL_ERR_ARG;
+  if constexpr (sizeof(T) == 2) {
+    if (g_tn_group8 && g_tn_tr && !g_tn_group_ring && g_tn_probe == 0 && (tile_list == nullptr || list_rows == 16)) {
+      const int rc = gemm_tn8_group(st, n, probs, P, alpha, overwrite, tile_list, n_tiles, list_rows);
+      if (rc != RL_ERR_ARG) return rc;
+    }
+  }
   TnGroup<T> grp;
   grp.n = n; grp.alpha = alpha; grp.probe = g_tn_probe; grp.overwrite = overwrite;
   if (list_rows != 0 && list_rows != G::BP && !(list_rows == 16 && sizeof(T) == 2)) return RL_ERR_ARG;

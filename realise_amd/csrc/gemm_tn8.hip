@@ -1,6 +1,7 @@
-// EXPERIMENTAL (realise_set_tn_variant(8); the production weight-gradient path is the 4-wave kernel of gemm.hip and its grouped
-// launch): correct on every probe shape (tools/tn8_probe.cpp) but 7-16 % slower - one workgroup per CU loses more overlap than the
-// 256 x 128 tile's lower fill volume returns.  Kept as the starting point for a deeper-ring TN kernel.
+// Round 2-3: a variant for single problems (realise_set_tn_variant(8), probe build) - with a reduction split + slab fold it came
+// out 7-16 % slower than the 4-wave kernel.  Round 4: its GROUPED form (gemm_tn8_group: the four weight gradients of a transformer
+// layer, 216 tiles of 256 x 128 = one per CU, no split, live 16-row blocks of the padded batch) is the production path of the
+// transformer-layer weight gradients (realise_set_engine(7, 0) switches back to the 4-wave grouped launch).
 //
 // Ping-pong 8-wave TN GEMM for gfx950 (bf16, dense operands): the weight gradients of the Linear layers,
 //   C[I,J] (+)= sum_p A[p,i] * B[p,j]      A = dY [P, lda], B = X [P, ldb], both row-major with the reduction index p slowest.
@@ -54,9 +55,12 @@ template <int = 0> struct Tn8T {      // a template only so that the constexpr s
 };
 typedef Tn8T<> Tn8;
 
-__global__ void __launch_bounds__(512)
-gemm_tn8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int P, int I, int J, int tiles_j,
-                int ntiles, int nsplit, int pchunk, int how, TnEpi ep) {
+// `logical` = split * ntiles + tile of this workgroup.  ep.tile_list / ep.n_tiles with ep.list_rows == 16 (unsplit launches): the
+// reduction runs over the LIVE 16-row blocks of the rows only, four of them (any four) per K-tile.  Every 1-KiB piece lies inside
+// one 16-row quarter of the tile (A piece s of a wave: quarter s; its two B pieces: quarters wave / 4 and 2 + wave / 4), so a listed
+// tile differs from a dense one in the SCALAR offset of the fetch alone: block index x 16 rows instead of tile index x 64 rows.
+__device__ __forceinline__ void tn8_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int P, int I, int J,
+                                         int tiles_j, int ntiles, int nsplit, int pchunk, int how, TnEpi ep, int logical) {
   typedef Tn8 C;
   typedef MmaBF16 Mma;
   constexpr int NPW = C::NPW, NPH = C::NPH, NS = C::NS, SQ = C::SQ, MT = C::MT, NT = C::NT;
@@ -65,13 +69,14 @@ gemm_tn8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;
   const int wi = wave & 3, wj = wave >> 2;                 // waves w and w+4 (the two groups on one SIMD) own the two j halves
-  const int logical = xcd_remap(blockIdx.x, ntiles * nsplit);
   const int split = logical / ntiles, tile = logical - split * ntiles;
   const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
   const int i0 = ti * C::BI, j0 = tj * C::BJ;
   const int p_begin = split * pchunk;
   const int p_end = min(P, p_begin + pchunk);
-  const int nk = p_end > p_begin ? (p_end - p_begin + C::BP - 1) / C::BP : 0;
+  const bool listed = ep.tile_list != nullptr && ep.list_rows == 16 && nsplit == 1;
+  const int n_list = listed ? min(*ep.n_tiles, P / 16) : 0;
+  const int nk = listed ? (n_list + 3) >> 2 : (p_end > p_begin ? (p_end - p_begin + C::BP - 1) / C::BP : 0);
 
   // ---- pieces of this wave: s-th piece is global piece s*8 + wave; A pieces hold 2 rows x 512 B, B pieces 4 rows x 256 B
   int lo[NPW], prow[NPW];
@@ -90,16 +95,31 @@ gemm_tn8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
     lo[s] = (is_b ? C::A_BYTES : 0) + k * 1024;
     prow[s] = row;
     colok[s] = col < (is_b ? J : I);
-    go[s] = (uint32_t)((int64_t)row * (is_b ? ldb : lda) * 2 + (int64_t)col * 2);
+    go[s] = (uint32_t)((int64_t)(listed ? (row & 15) : row) * (is_b ? ldb : lda) * 2 + (int64_t)col * 2);
   }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)0xFFFFFE00u, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)0xFFFFFE00u, 0x00020000);
   const uint32_t strideA = (uint32_t)(C::BP * lda * 2), strideB = (uint32_t)(C::BP * ldb * 2);
   const uint32_t baseA = (uint32_t)((int64_t)p_begin * lda * 2), baseB = (uint32_t)((int64_t)p_begin * ldb * 2);
+  // listed mode: 64 list entries (= 16 K-tiles) sit in one register per lane, re-read when an issue crosses into the next group
+  int list_reg = (listed && lane < n_list) ? ep.tile_list[lane] : -1;
+  int list_grp = 0;
   auto issue = [&](auto s_c, int stage, int ktile) {
     constexpr int s = decltype(s_c)::value;
     constexpr bool is_b = (s * 8 >= C::NPA);                // pieces 0..31 are A, 32..47 B: s = 0..3 -> A, 4..5 -> B for every wave
     static_assert(C::NPA % 8 == 0, "operand boundary falls between two piece rounds");
+    if (listed) {
+      if ((ktile >> 4) != list_grp) {                       // (wave-uniform)
+        list_grp = ktile >> 4;
+        list_reg = (list_grp * 64 + lane < n_list) ? ep.tile_list[list_grp * 64 + lane] : -1;
+      }
+      const int quarter = is_b ? (s - 4) * 2 + (wave >> 2) : s;
+      const int blk = __builtin_amdgcn_readlane(list_reg, ((ktile & 15) << 2) + quarter);
+      const uint32_t voff = (colok[s] && blk >= 0) ? go[s] : 0xFFFFFF00u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(is_b ? rsB : rsA, (__attribute__((address_space(3))) void*)(smem + stage * C::STAGE + lo[s]), 16,
+                                               voff, (uint32_t)max(blk, 0) * ((is_b ? strideB : strideA) >> 2), 0, 0);
+      return;
+    }
     const bool live = colok[s] && (p_begin + ktile * C::BP + prow[s] < p_end);
     const uint32_t voff = live ? go[s] : 0xFFFFFF00u;       // rows past the split / columns past the matrix read zeros
     __builtin_amdgcn_raw_ptr_buffer_load_lds(is_b ? rsB : rsA, (__attribute__((address_space(3))) void*)(smem + stage * C::STAGE + lo[s]), 16,
@@ -201,6 +221,59 @@ gemm_tn8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restr
       if (i < I) atomicAdd(ep.colsum + i, csum[f][0] * ep.alpha);
     }
   }
+}
+
+__global__ void __launch_bounds__(512)
+gemm_tn8_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int P, int I, int J, int tiles_j,
+                int ntiles, int nsplit, int pchunk, int how, TnEpi ep) {
+  tn8_body(A, lda, B, ldb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep, xcd_remap(blockIdx.x, ntiles * nsplit));
+}
+
+// Grouped form (the four weight gradients of a transformer layer in one launch, one 256 x 128 tile per workgroup over the whole
+// reduction - 216 tiles, one per CU): the 8-wave three-stage body keeps two K-tiles (96 KB) in flight per CU where the two co-resident
+// 4-wave workgroups of gemm_tn_group_kernel keep one each (64 KB), and a fetched byte feeds a third more flops (85 vs 64 per byte).
+__global__ void __launch_bounds__(512)
+gemm_tn8_group_kernel(TnGroup<bf16_t> grp, int P, int pchunk) {
+  const int logical = xcd_remap(blockIdx.x, grp.total_tiles);
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < TN_GROUP_MAX; ++i) if (i < grp.n && logical >= grp.p[i].tile_begin) k = i;
+  const TnGroupProblem<bf16_t>& pr = grp.p[k];
+  TnEpi ep;
+  ep.out = pr.out; ep.ldo = pr.ldo; ep.colsum = pr.colsum; ep.alpha = grp.alpha; ep.overwrite = grp.overwrite;
+  ep.tile_list = grp.tile_list; ep.n_tiles = grp.n_tiles; ep.list_rows = grp.list_rows;
+  tn8_body(pr.A, pr.lda, pr.B, pr.ldb, P, pr.I, pr.J, pr.tiles_j, pr.ntiles, 1, pchunk, TN_OUT_DIRECT, ep, logical - pr.tile_begin);
+}
+
+// RL_ERR_ARG when a problem does not fit the 8-wave kernel (the caller then takes the 4-wave grouped launch)
+int gemm_tn8_group(hipStream_t st, int n, const TnGroupProblem<bf16_t>* probs, int P, float alpha, int overwrite, const int* tile_list,
+                   const int* n_tiles, int list_rows) {
+  typedef Tn8 C;
+  if (n < 1 || n > TN_GROUP_MAX || P < 1024 || (P % C::BP) != 0) return RL_ERR_ARG;
+  if (tile_list != nullptr && (n_tiles == nullptr || list_rows != 16)) return RL_ERR_ARG;      // (whole-tile lists: the 4-wave kernel)
+  TnGroup<bf16_t> grp;
+  grp.n = n; grp.alpha = alpha; grp.overwrite = overwrite;
+  if (tile_list != nullptr) { grp.tile_list = tile_list; grp.n_tiles = n_tiles; grp.list_rows = 16; }
+  int total = 0;
+  double flops = 0.0;
+  for (int k = 0; k < n; ++k) {
+    TnGroupProblem<bf16_t> pr = probs[k];
+    TnEpi te; te.ldo = pr.ldo;
+    if (!tn8_supported(pr.lda, pr.ldb, P, pr.I, pr.J, te)) return RL_ERR_ARG;
+    pr.tiles_j = (pr.J + C::BJ - 1) / C::BJ;
+    pr.ntiles = ((pr.I + C::BI - 1) / C::BI) * pr.tiles_j;
+    pr.tile_begin = total;
+    total += pr.ntiles;
+    flops += 2.0 * P * pr.I * pr.J;
+    grp.p[k] = pr;
+  }
+  grp.total_tiles = total;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_tn8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_set = true; }
+  ProfScope ps(st, PK_GEMM_TN, flops);
+  if (grp.tile_list != nullptr) prof_set_exec(grp.n_tiles, flops / P * 16, 4, P / 16);
+  RL_LAUNCH(gemm_tn8_group_kernel, dim3(total), dim3(512), C::LDS, st, grp, P, P);
+  return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
 bool tn8_supported(int64_t lda, int64_t ldb, int P, int I, int J, const TnEpi& ep) {

@@ -189,14 +189,16 @@ def test_gemm_tn_grouped(dt, Pn, shapes):
     assert lib.realise_gemm_tn_grouped(stream(), code, 5, probs, Pn) != 0          # more than 4 problems is an argument error
 
 
-@pytest.mark.parametrize("n_live16", [0, 1, 6, 37, 128])
-def test_gemm_tn_grouped_over_live_16_row_blocks(n_live16):
+@pytest.mark.parametrize("shapes", [[(768, 768), (256, 384), (136, 200)], [(768, 768), (256, 384), (520, 128)]], ids=["4wave", "8wave"])
+@pytest.mark.parametrize("n_live16", [0, 1, 6, 37, 70, 128])
+def test_gemm_tn_grouped_over_live_16_row_blocks(n_live16, shapes):
     """the engine's weight-gradient reduction over the LIVE rows of a padded batch (bf16): the rows of the dead 16-row blocks are exact
     zeros in dY, the list names the live blocks, four of them (any four) form a reduction tile - equal to the dense reduction; also in
     the whole-tile form (list_rows = 64) and with overwrite."""
     lib = _capi.load()
     code, tdt, tol = DT["bf16"]
-    Pn, shapes = 2048, [(768, 768), (256, 384), (136, 200)]
+    # (every problem with I >= 256 and J >= 128: the 8-wave 256 x 128 kernel, gemm_tn8_group; otherwise the 4-wave 128 x 128 one)
+    Pn = 2048
     g = torch.Generator().manual_seed(100 + n_live16)
     live = torch.sort(torch.randperm(Pn // 16, generator=g)[:n_live16]).values.int()
     rowmask = torch.zeros(Pn, 1)
