@@ -227,6 +227,9 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     models, BertConfig = import_reference()
+    if "--only-spellbert-b8s64-train" in sys.argv:      # round 4: BASELINE configs[0] at its stated size, training step
+        case_model(models, BertConfig, "spellbert_b8s64_train", "bert", 8, 64, True, seed=8, n_layers=12, with_grads=True)
+        return
     case_gru(models, BertConfig)
     case_optim()
     case_model(models, BertConfig, "spellbert_b2s16_eval", "bert", 2, 16, False, seed=1, n_layers=2)
@@ -236,6 +239,7 @@ def main():
     case_model(models, BertConfig, "arch3_b3s40_train", "arch3", 3, 40, True, seed=5, n_layers=12, with_grads=True)
     case_model(models, BertConfig, "spellbert_b8s64_eval", "bert", 8, 64, False, seed=6, n_layers=12)
     case_model(models, BertConfig, "arch3_b4s128_eval", "arch3", 4, 128, False, seed=7, n_layers=12)
+    case_model(models, BertConfig, "spellbert_b8s64_train", "bert", 8, 64, True, seed=8, n_layers=12, with_grads=True)
 
 
 if __name__ == "__main__":

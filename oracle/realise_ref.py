@@ -259,7 +259,10 @@ def arch3_forward(sd, cfg, batch, training=False, new_buffers=None, taps=None):
         taps["pho_gru"] = pho_h
     pho_h = bert_model(sd, "pho_model.", 4, nh, mask, inputs_embeds=pho_h,
                        p_drop=p, training=training, taps=taps)                           # :827
-    images = sd["char_images_multifonts"].index_select(0, ids.reshape(-1))                  # :829-834
+    if "char_images.weight" in sd:          # num_fonts == 1: an nn.Embedding [V, 1024] viewed as one 32 x 32 font            # :674-676, :831-832
+        images = sd["char_images.weight"].index_select(0, ids.reshape(-1)).reshape(-1, 1, 32, 32)
+    else:
+        images = sd["char_images_multifonts"].index_select(0, ids.reshape(-1))              # :677-679, :833-834
     res = char_resnet(sd, images, training, new_buffers, taps)                              # :836
     res_h = layer_norm(res.view(B, S, -1), sd["resnet_layernorm.weight"], sd["resnet_layernorm.bias"])  # :838
     fused = gate_fuse(sd, bert_h, pho_h, res_h, mask)                                       # :840-850

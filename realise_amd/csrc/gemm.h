@@ -354,7 +354,7 @@ bool tn8_supported(int64_t lda, int64_t ldb, int P, int I, int J, const TnEpi& e
 // grouped 8-wave form (gemm_tn8.hip): 256 x 128 tiles, one per CU, unsplit, optional list of live 16-row blocks; RL_ERR_ARG = not applicable
 int gemm_tn8_group(hipStream_t st, int n, const TnGroupProblem<bf16_t>* probs, int P, float alpha, int overwrite, const int* tile_list,
                    const int* n_tiles, int list_rows);
-void set_tn_group8(int on);      // transformer-layer weight gradients through gemm_tn8_group (default 1)
+void set_tn_group8(int on);      // transformer-layer weight gradients through gemm_tn8_group (default 0: measured slower)
 int gemm_tn8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int P, int I, int J, const TnEpi& ep, int force_split);
 void tn_fold_launch(hipStream_t st, const TnEpi& ep, int nsplit, int I, int J);     // out += alpha * sum of the split slabs, fixed order
 void set_tn_variant(int v);

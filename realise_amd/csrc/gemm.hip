@@ -968,7 +968,7 @@ static int launch_tn(hipStream_t st, const T* A, int64_t lda, const BLoader& lb,
 static int g_tn_variant = 0;      // 0 production (the 4-wave kernel), 8 the experimental 8-wave ping-pong kernel (gemm_tn8.hip: correct, 7-16 % slower)
 void set_tn_variant(int v) { g_tn_variant = RL_PROBES ? v : 0; }
 
-static int g_tn_group8 = 1;          // grouped weight gradients on the 8-wave 256 x 128 kernel (gemm_tn8_group) where it applies
+static int g_tn_group8 = 0;          // grouped weight gradients on the 8-wave 256 x 128 kernel (gemm_tn8_group): measured, not faster (see gemm_tn8.hip)
 void set_tn_group8(int on) { g_tn_group8 = on; }
 static int g_tn_group_ring = 0;      // measured: 4 x 32-row stages 3.76 ms/step vs 3.39 for 2 x 64-row stages (more barriers, smaller DMA batches)
 void set_tn_group_ring(int on) { g_tn_group_ring = on; }

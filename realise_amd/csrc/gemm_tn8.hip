@@ -1,7 +1,9 @@
-// Round 2-3: a variant for single problems (realise_set_tn_variant(8), probe build) - with a reduction split + slab fold it came
-// out 7-16 % slower than the 4-wave kernel.  Round 4: its GROUPED form (gemm_tn8_group: the four weight gradients of a transformer
-// layer, 216 tiles of 256 x 128 = one per CU, no split, live 16-row blocks of the padded batch) is the production path of the
-// transformer-layer weight gradients (realise_set_engine(7, 0) switches back to the 4-wave grouped launch).
+// MEASURED VARIANT, not the production path.  Round 2-3: for single problems (realise_set_tn_variant(8), probe build) with a reduction
+// split + slab fold it came out 7-16 % slower than the 4-wave kernel.  Round 4: its GROUPED form (gemm_tn8_group: the four weight
+// gradients of a transformer layer, 216 tiles of 256 x 128 = one per CU, no split; realise_set_engine(7, 1)) on cold operands:
+// 210 us against 200 for the 4-wave grouped launch (tools/tn_live_probe.py, profiles/round4_tn_live_probe.log) - the K-tile costs
+// ~1.6 us in both, whatever the number of tiles in flight: not a fetch-latency problem.  Its live-block list form (a per-lane
+// register re-loaded inside the issue path) makes the compiler drain vmcnt before every fetch: 555 us.  Kept for the record.
 //
 // Ping-pong 8-wave TN GEMM for gfx950 (bf16, dense operands): the weight gradients of the Linear layers,
 //   C[I,J] (+)= sum_p A[p,i] * B[p,j]      A = dY [P, lda], B = X [P, ldb], both row-major with the reduction index p slowest.

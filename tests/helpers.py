@@ -48,7 +48,7 @@ def oracle_state_dict(sd_np, requires_grad=False):
     sd = {}
     for k, v in sd_np.items():
         t = torch.from_numpy(np.array(v, copy=True))
-        if requires_grad and t.dtype == torch.float32 and k != "char_images_multifonts" and "running_" not in k:
+        if requires_grad and t.dtype == torch.float32 and k not in ("char_images_multifonts", "char_images.weight") and "running_" not in k:
             t.requires_grad_(True)
         sd[k] = t
     sd["classifier.weight"] = sd["bert.embeddings.word_embeddings.weight"]

@@ -35,6 +35,7 @@ def test_forward_eval_matches_reference(golden_dir, name, model_type):
 @pytest.mark.parametrize("name,model_type", [
     ("spellbert_b2s16_train", "bert"),
     ("arch3_b2s16_train", "arch3"),
+    ("spellbert_b8s64_train", "bert"),          # BASELINE configs[0] at its stated size (B=8, S=64, 12 layers)
 ])
 def test_train_step_grads_match_reference(golden_dir, name, model_type):
     g = load_golden(golden_dir, name)

@@ -69,12 +69,16 @@ def run(name, rows, frac):
     gf = 2.0 * P * sum(i * j for i, j in shapes) * live * 1e-9
     med = ts[len(ts) // 2]
     print("%-8s live rows %5.1f %%  median %7.1f us  min %7.1f  %6.0f TF executed  (%.2f us per 64-row K-tile)"
-          % (name, 100 * live, med, ts[0], gf / med * 1e-3 * 1e3, med / (P * live / 64)))
+          % (name, 100 * live, med, ts[0], gf / med * 1e3, med / (P * live / 64)))
 
 
-run("none", 0, 1.0)
-run("64/100", 64, 1.0)
-run("64/84", 64, 0.84)
-run("16/100", 16, 1.0)
-run("16/68", 16, 0.68)
-run("none", 0, 1.0)
+for g8 in (0, 1):
+    lib.realise_set_engine(7, g8)
+    print("--- %s" % ("8-wave 256x128 tiles, one per CU (gemm_tn8_group)" if g8 else "4-wave 128x128 tiles, two per CU (gemm_tn_group)"))
+    run("none", 0, 1.0)
+    if not g8:
+        run("64/100", 64, 1.0)
+        run("64/84", 64, 0.84)
+    run("16/100", 16, 1.0)
+    run("16/68", 16, 0.68)
+    run("none", 0, 1.0)
