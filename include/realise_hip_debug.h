@@ -51,7 +51,8 @@ int realise_layernorm_bwd_ex(void* stream, const void* dy, const void* xhat, con
 /* LayerNorm kernels: key 0 = bf16 fast path (half a wave per row, 16-byte accesses; default 1), key 1 = workgroups of its backward (default 512);
  * BatchNorm kernels: key 2 = bf16 fast paths (1, default: 16-byte accesses, paired bn2 + shortcut backward, one-pass training
  * statistics; 3: the same with two-pass statistics; 0: generic kernels), key 3 = row chunks of their
- * column reductions (default 1024) */
+ * column reductions (default 1024) ; key 4 = bf16 masked cross-entropy with the logits row read once into registers
+ * (1, default) or the generic three-walk kernel (0) */
 void realise_set_ln(int key, int value);
 /* BatchNorm training statistics and backward exactly as the engine's glyph branch runs them (bf16, NHWC viewed as [P, C];
  * char_cnn.py:15-32): per-row-chunk partial records in `slots` (1 MiB scratch) folded in a fixed order; `counts` (nullable) =

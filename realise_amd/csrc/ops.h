@@ -172,6 +172,7 @@ int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const floa
 // a BasicBlock's bn2 + shortcut BN (shared dy and ReLU mask read once).  *2 functions return RL_ERR_ARG when the fast path does not apply.
 void set_bn_fast(int on);
 void set_bn_chunks(int n);
+void set_ce_fast(int on);           // bf16 masked cross-entropy with the logits row held in registers (default 1)
 int bn_fast();
 // one-pass training statistics of a bf16 [P, C] map + everything bn_finalize_train does (2 launches instead of 5, x read once);
 // RL_ERR_ARG when the fast path does not apply
