@@ -212,7 +212,10 @@ void realise_engine_set_grads_fresh(realise_engine* e, int fresh);
  * models.py:818 pinyin ids, :831 glyph lookup).  The engine never indexes with a caller's id: every forward first copies src_idx /
  * pho_idx into its workspace with out-of-range ids replaced by 0 and sets *flag = 1 (sticky; device memory or host-mapped pinned
  * memory, nullable) when it replaced one.  The caller reads the flag when it next touches the host (the Python module: at the
- * next forward / backward / decode) and raises; results of a flagged step are meaningless, but no memory outside the tables was read. */
+ * next forward / backward / decode) and raises; results of a flagged step are meaningless, but no memory outside the tables was read.
+ * `flag` points to TWO int32: flag[0] = the id-range flag above; flag[1] = set to 1 if a workgroup of the fused dense + LayerNorm
+ * launch gave up waiting for the other column tiles of its rows (never observed; the wait is bounded so that a scheduling surprise
+ * cannot hang the device - the step's results are meaningless then). */
 void realise_engine_set_id_flag(realise_engine* e, int32_t* flag);
 
 typedef struct {

@@ -55,6 +55,11 @@ void set_cls_compact(int on) { g_cls_compact = on; }
 // Split-K of the classifier's data gradient (realise_set_engine key 6; bf16, compacted rows): K = 21184 vocabulary columns, N = 768,
 // ~4.9 k live rows are 156 tiles of 128 x 192 on 512 workgroup slots - three K-ranges fill them (468), the fp32 partial planes are
 // folded in plane order by the scatter that follows anyway.  0 = off (one launch over the whole K).
+// K4 (realise_set_engine key 8): BertSelfOutput / BertOutput as ONE launch - dense + bias + dropout + residual + LayerNorm (bf16,
+// the 128 x 192 two-per-CU kernel: the four column tiles of a row band exchange their LayerNorm partial sums through device-scope
+// stores and an arrival counter).  0 = the GEMM and the LayerNorm as two launches.
+static int g_ln_fuse = 1;
+void set_ln_fuse(int on) { g_ln_fuse = on; }
 static int g_cls_splitk = 3;
 void set_cls_splitk(int n) { g_cls_splitk = n < 0 ? 0 : (n > 4 ? 4 : n); }
 static int g_stream_pri[3] = {0, 0, 0};
@@ -122,6 +127,7 @@ template <typename T> struct Engine : EngineBase {
     BlockAct blk[5];
     int64_t mask_add, out_d, dlogits, count, loss_internal;
     int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc, cls_slab;
+    int64_t ln_part[3] = {0, 0, 0}, ln_flag[3] = {0, 0, 0};       // fused GEMM + LayerNorm: per-row tile partials + arrival counters, one set per stack (= stream)
     int64_t row_live, live_t64, live_t32, live_t16, live_n, live_rlen;          // padding rows: exact-zero gradient rows the backward skips (row_liveness)     // classifier backward over the rows that enter the loss only (stage_head)
     int64_t ids_clean = 0, pho_clean = 0;                 // range-checked copies of src_idx / pho_idx (sanitize_ids)
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
@@ -447,6 +453,13 @@ template <typename T> struct Engine : EngineBase {
     p.cls_xc = b.take(Tk * H * e); p.cls_gc = b.take(Tk * H * e);
     p.zero_once.push_back({p.cls_xc, Tk * H * e}); p.zero_once.push_back({p.cls_gc, Tk * H * e});
     p.cls_slab = (!glyph_only && sizeof(T) == 2) ? b.take(4 * Tk * H * 4) : 0;      // fp32 planes of the split-K classifier data gradient
+    if (!glyph_only && sizeof(T) == 2) {
+      for (int k = 0; k < 3; ++k) {
+        p.ln_part[k] = b.take(Tk * 8 * 2 * 4);
+        p.ln_flag[k] = b.take((Tk / 128 + 8) * 4);
+        p.zero_once.push_back({p.ln_flag[k], (Tk / 128 + 8) * 4});
+      }
+    }
     // shared backward scratch
     p.gA = b.take(Tk * H * e); p.gB = b.take(Tk * H * e); p.gC = b.take(Tk * H * e); p.gE = b.take(Tk * H * e);
     const int64_t Tw = glyph_only ? 1 : Tk;               // the wide BERT scratch is not needed by the glyph-only plan
@@ -601,26 +614,16 @@ template <typename T> struct Engine : EngineBase {
         RL_TRY(attn_fwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), H, wp<float>(t.lse), B, nh, S,
                            d.seed, d.thresh, d.scale));
       }
-      {  // BertSelfOutput: dense -> dropout -> + input -> LayerNorm (modeling_bert.py:273-277)
-        EpiParams<T> ep; ep.mode = EPI_DROP_RESID; ep.out = wp<T>(t.s1); ep.ldo = H; ep.bias = pp(o.ao_b);
-        ep.aux = x; ep.ldaux = H; set_drop(ep, site(sid * 1000 + (int)l * 10 + 2, cfg.hidden_dropout));
-        RL_TRY(gemm_nt<T>(st, wp<T>(t.ctx), H, sp<T>(w.ao_w), H, Tk, H, H, ep));
-        LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = wp<T>(t.s1); ln.gamma = pp(o.ao_ln_g); ln.beta = pp(o.ao_ln_b);
-        ln.eps = cfg.ln_eps; ln.y = wp<T>(t.y1); ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1);
-        RL_TRY(ln_fwd<T>(st, ln));
-      }
+      // BertSelfOutput: dense -> dropout -> + input -> LayerNorm (modeling_bert.py:273-277)
+      RL_TRY(dense_resid_ln(st, sid, wp<T>(t.ctx), H, sp<T>(w.ao_w), pp(o.ao_b), x, site(sid * 1000 + (int)l * 10 + 2, cfg.hidden_dropout),
+                            pp(o.ao_ln_g), pp(o.ao_ln_b), wp<T>(t.s1), wp<float>(t.rstd1), wp<T>(t.y1)));
       {  // BertIntermediate (modeling_bert.py:326-329)
         EpiParams<T> ep; ep.mode = EPI_GELU; ep.out = wp<T>(t.post); ep.out2 = wp<T>(t.pre); ep.ldo = I; ep.bias = pp(o.in_b);
         RL_TRY(gemm_nt<T>(st, wp<T>(t.y1), H, sp<T>(w.in_w), H, Tk, I, H, ep));
       }
-      {  // BertOutput (modeling_bert.py:339-343)
-        EpiParams<T> ep; ep.mode = EPI_DROP_RESID; ep.out = wp<T>(t.s2); ep.ldo = H; ep.bias = pp(o.out_b);
-        ep.aux = wp<T>(t.y1); ep.ldaux = H; set_drop(ep, site(sid * 1000 + (int)l * 10 + 3, cfg.hidden_dropout));
-        RL_TRY(gemm_nt<T>(st, wp<T>(t.post), I, sp<T>(w.out_w), I, Tk, H, I, ep));
-        LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = wp<T>(t.s2); ln.gamma = pp(o.out_ln_g); ln.beta = pp(o.out_ln_b);
-        ln.eps = cfg.ln_eps; ln.y = wp<T>(t.y2); ln.xhat = wp<T>(t.s2); ln.rstd = wp<float>(t.rstd2);
-        RL_TRY(ln_fwd<T>(st, ln));
-      }
+      // BertOutput (modeling_bert.py:339-343)
+      RL_TRY(dense_resid_ln(st, sid, wp<T>(t.post), I, sp<T>(w.out_w), pp(o.out_b), wp<T>(t.y1), site(sid * 1000 + (int)l * 10 + 3, cfg.hidden_dropout),
+                            pp(o.out_ln_g), pp(o.out_ln_b), wp<T>(t.s2), wp<float>(t.rstd2), wp<T>(t.y2)));
       x = wp<T>(t.y2);
     }
     *out = x;
@@ -996,9 +999,33 @@ template <typename T> struct Engine : EngineBase {
 
   // ---------------------------------------------------------------- forward
   // a freshly planned workspace: the self-cleaning LayerNorm-backward accumulators start at zero
+  int ln_epoch[3] = {0, 0, 0};
+  // dense -> dropout -> + residual -> LayerNorm (modeling_bert.py:273-277, 339-343): one launch when the fused form applies
+  int dense_resid_ln(hipStream_t st, int sid, const T* a, int K, const T* w, const float* bias, const T* resid, const DropParams& drop,
+                     const float* gamma, const float* beta, T* s_xhat, float* rstd, T* y) {
+    const int Tk = pl.B * pl.S;
+    EpiParams<T> ep; ep.mode = EPI_DROP_RESID; ep.out = s_xhat; ep.ldo = H; ep.bias = bias; ep.aux = resid; ep.ldaux = H; set_drop(ep, drop);
+    if constexpr (sizeof(T) == 2) {
+      if (g_ln_fuse && sid >= 0 && sid < 3 && pl.ln_part[sid] != 0 && (Tk % 128) == 0 && (H % 192) == 0 && ln_epoch[sid] < (1 << 27)) {
+        EpiParams<T> e2 = ep;
+        e2.ln_gamma = gamma; e2.ln_beta = beta; e2.ln_eps = cfg.ln_eps; e2.ln_y = y; e2.ln_rstd = rstd;
+        e2.ln_part = wp<float>(pl.ln_part[sid]); e2.ln_flag = wp<int>(pl.ln_flag[sid]);
+        e2.ln_target = (ln_epoch[sid] + 1) * (H / 192);
+        e2.ln_timeout = id_flag != nullptr ? id_flag + 1 : nullptr;
+        const int rc = gemm_nt8_ln(st, a, K, w, K, Tk, H, K, e2);
+        if (rc == RL_OK) { ++ln_epoch[sid]; return RL_OK; }
+        if (rc != RL_ERR_ARG) return rc;
+      }
+    }
+    RL_TRY(gemm_nt<T>(st, a, K, w, K, Tk, H, K, ep));
+    LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = s_xhat; ln.gamma = gamma; ln.beta = beta;
+    ln.eps = cfg.ln_eps; ln.y = y; ln.xhat = s_xhat; ln.rstd = rstd;
+    return ln_fwd<T>(st, ln);
+  }
   int install_plan(hipStream_t st, const Plan& p) {
     if (p.total > ws_bytes) { fprintf(stderr, "[realise_hip] workspace too small: need %lld have %lld\n", (long long)p.total, (long long)ws_bytes); return RL_ERR_ARG; }
     pl = p;
+    ln_epoch[0] = ln_epoch[1] = ln_epoch[2] = 0;           // (the arrival counters are zero-filled below)
     for (const auto& z : pl.zero_once)
       if (hipMemsetAsync(ws + z.first, 0, (size_t)z.second, st) != hipSuccess) return RL_ERR_LAUNCH;
     return RL_OK;

@@ -43,6 +43,20 @@ template <typename T> struct EpiParams {
   float* slab = nullptr;
   int64_t slab_stride = 0;
   int ksplit = 1;
+  // K4 (BertSelfOutput / BertOutput, modeling_bert.py:273-277, 339-343): EPI_DROP_RESID followed by the LayerNorm of the row in the SAME
+  // launch (8-wave 128 x 192 kernel, M % 128 == 0, N % 192 == 0, N / 192 <= 8).  A row spans N / 192 column tiles = workgroups: each
+  // leaves (sum, M2) of its 192 columns in ln_part[row][tile] and bumps ln_flag[row tile]; when all tiles of the row band have
+  // arrived (counter >= ln_target: the caller passes launch count x tiles per band - the counters are never reset) every workgroup
+  // combines the partials (Chan), normalises its own columns from LDS and writes xhat -> out, y -> ln_y, rstd -> ln_rstd.
+  const float* ln_gamma = nullptr;
+  const float* ln_beta = nullptr;
+  float ln_eps = 0.f;
+  T* ln_y = nullptr;
+  float* ln_rstd = nullptr;
+  float* ln_part = nullptr;       // [M][N / 192][2]
+  int* ln_flag = nullptr;         // [M / 128]
+  int ln_target = 0;
+  int* ln_timeout = nullptr;      // nullable: set to 1 if a wait gave up (a workgroup of the band never arrived)
 };
 
 // ---- operand loaders ---------------------------------------------------------------------------
@@ -315,6 +329,8 @@ template <typename T>
 int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, float alpha = 1.0f, int overwrite = 0,
                   const int* tile_list = nullptr, const int* n_tiles = nullptr, int list_rows = 0);
 
+// K4: GEMM + bias + dropout + residual + LayerNorm in one launch (gemm_nt8.hip, see EpiParams::ln_*); RL_ERR_ARG = shape not supported
+int gemm_nt8_ln(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
 // Split-K NT GEMM (bf16, K % 64 == 0, nsplit <= K / 64): slab[s][m][n] (fp32, row pitch N, plane pitch slab_stride) = A[m, Ks] . B[n, Ks]^T
 // over the s-th K-range; rows at or beyond *m_dev (nullable) are not computed.  For reductions long enough that the output tiles
 // alone do not fill the chip: the classifier's data gradient (K = 21184, N = 768, ~4.9 k live rows = 156 tiles of 128 x 192).

@@ -50,6 +50,121 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_n, int ntiles, i
 static int g_nt8_probe = 0;
 void set_nt8_probe(int mode) { g_nt8_probe = mode; }
 
+// ---- K4 epilogue: dropout(acc + bias) + residual, then the LayerNorm of the row, whose columns are spread over the N / BN workgroups
+// of a row band (see EpiParams::ln_*).  Same numbers as the unfused pair (GEMM epilogue -> bf16 -> ln_fwd16) up to the order of the
+// fp32 statistics: the statistics are taken from the bf16-rounded sums, two-pass inside a tile, combined across tiles by Chan's rule.
+template <typename C>
+__device__ __forceinline__ void nt8_ln_epilogue(char* smem, const EpiParams<bf16_t>& ep, floatx4 (&acc)[C::MT][C::NT], int M, int N, int m0, int n0,
+                                                int tm, int tn, int tiles_n, int wm, int wn, int lane) {
+  typedef bf16_t T;
+  constexpr int BM = C::BM, BN = C::BN, PITCH = BN * 2 + 16;          // bf16 x tile in LDS, rows padded by 16 B
+  static_assert(BM * PITCH + BM * 8 <= C::LDS && BM == 128 && BN % 64 == 0, "LN epilogue geometry");
+  const int g = lane >> 4, l15 = lane & 15, tid = threadIdx.x;
+  float* rowstat = (float*)(smem + BM * PITCH);                         // [BM][2]: mean, rstd
+  // A. x = bf16(dropout(acc * alpha + bias) + residual), in the MFMA layout (a lane: 4 consecutive columns of a row) -> LDS
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i) {
+    const int rl = wm * C::RM + i * 16 + l15, row = m0 + rl;
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) {
+      const int cl = wn * C::RN + j * 16 + 4 * g, col = n0 + cl;
+      floatx4 a = acc[i][j];
+      if (ep.alpha != 1.0f) a *= ep.alpha;
+      if (ep.bias != nullptr) a += *(const floatx4*)(ep.bias + col);
+      a *= drop_mult4(ep.drop_seed, ep.drop_thresh, ep.drop_scale, (uint32_t)row * (uint32_t)N + (uint32_t)col);
+      a += load4<T>(ep.aux + (int64_t)row * ep.ldaux + col);
+      uint2 pk;
+      pk.x = pack2bf(a[0], a[1]); pk.y = pack2bf(a[2], a[3]);
+      *(uint2*)(smem + rl * PITCH + cl * 2) = pk;
+    }
+  }
+  __syncthreads();
+  // B. per-row statistics of this tile's BN columns: 4 threads per row (BM * 4 = 512 threads), BN / 4 columns each
+  const int srow = tid >> 2, sq = tid & 3;
+  constexpr int QC = BN / 4, QCH = QC / 8;
+  float xs[QC];
+  {
+    const char* p = smem + srow * PITCH + sq * QC * 2;
+#pragma unroll
+    for (int k = 0; k < QCH; ++k) {
+      const uint4 u = *(const uint4*)(p + 16 * k);
+      floatx4 lo, hi;
+      unpack8(u, lo, hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { xs[8 * k + e] = lo[e]; xs[8 * k + 4 + e] = hi[e]; }
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < QC; ++k) sum += xs[k];
+  sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+  const float mean_t = sum * (1.0f / (float)BN);
+  float m2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < QC; ++k) { const float d = xs[k] - mean_t; m2 += d * d; }
+  m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64);
+  float* part = ep.ln_part + ((int64_t)(m0 + srow) * tiles_n) * 2;
+  if (sq == 0) {        // device-scope stores (write through to where the other workgroups' device-scope loads read)
+    __hip_atomic_store(part + tn * 2, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + tn * 2 + 1, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // C. arrival counter of the row band; wait for the other column tiles (bounded: a workgroup that never arrives must not hang the GPU)
+  if (tid == 0) {
+    __hip_atomic_fetch_add(ep.ln_flag + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (__hip_atomic_load(ep.ln_flag + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ep.ln_target < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) { if (ep.ln_timeout != nullptr) *ep.ln_timeout = 1; break; }
+    }
+  }
+  __syncthreads();
+  // D. combine the tiles' partials (Chan's rule, n_t = BN each); the 4 threads of a row take tiles sq and sq + 4
+  float s_a = 0.f, s_b = 0.f, pm2 = 0.f;
+  const bool has_a = sq < tiles_n, has_b = sq + 4 < tiles_n;
+  if (has_a) {
+    s_a = __hip_atomic_load(part + sq * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pm2 = __hip_atomic_load(part + sq * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (has_b) {
+    s_b = __hip_atomic_load(part + (sq + 4) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pm2 += __hip_atomic_load(part + (sq + 4) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  float tsum = s_a + s_b;
+  tsum += __shfl_xor(tsum, 1, 64); tsum += __shfl_xor(tsum, 2, 64);
+  const float mean = tsum / (float)N;
+  const float da = s_a * (1.0f / (float)BN) - mean, db = s_b * (1.0f / (float)BN) - mean;
+  float tot = pm2 + (has_a ? (float)BN * da * da : 0.f) + (has_b ? (float)BN * db * db : 0.f);      // sum_t [M2_t + n_t (mean_t - mean)^2]
+  tot += __shfl_xor(tot, 1, 64); tot += __shfl_xor(tot, 2, 64);
+  const float rstd = 1.0f / sqrtf(tot / (float)N + ep.ln_eps);
+  if (sq == 0) {
+    rowstat[srow * 2] = mean; rowstat[srow * 2 + 1] = rstd;
+    if (tn == 0 && ep.ln_rstd != nullptr) ep.ln_rstd[m0 + srow] = rstd;
+  }
+  __syncthreads();
+  // E. normalise this tile's columns: 8 per item, BN / 8 items per row, 16-byte stores of xhat (over the pre-LN buffer) and y
+  constexpr int IPR = BN / 8, ITEMS = BM * IPR, NIT = (ITEMS + 511) / 512;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = tid + 512 * it;
+    if (e < ITEMS) {
+      const int r = e / IPR, c8 = e - r * IPR;
+      const uint4 u = *(const uint4*)(smem + r * PITCH + c8 * 16);
+      floatx4 lo, hi;
+      unpack8(u, lo, hi);
+      const float mu = rowstat[r * 2], rs = rowstat[r * 2 + 1];
+      const int col = n0 + c8 * 8;
+      const floatx4 g0 = *(const floatx4*)(ep.ln_gamma + col), g1 = *(const floatx4*)(ep.ln_gamma + col + 4);
+      const floatx4 b0 = *(const floatx4*)(ep.ln_beta + col), b1 = *(const floatx4*)(ep.ln_beta + col + 4);
+      const floatx4 h0 = (lo - mu) * rs, h1 = (hi - mu) * rs;
+      const int64_t o = (int64_t)(m0 + r) * ep.ldo + col;
+      store8<T>(ep.out + o, h0, h1);
+      store8<T>(ep.ln_y + o, h0 * g0 + b0, h1 * g1 + b1);
+    }
+  }
+}
+
 template <typename C, int PROBE, bool KTAIL = false>
 __global__ void __launch_bounds__(512, 2 * C::WGS)
 gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __restrict__ B_, int64_t ldb, int M, int N, int K, int tiles_n,
@@ -222,6 +337,12 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   }
   if (grp == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }     // barrier census: group 1 took one extra up front
 
+  if constexpr (!KTAIL && PROBE == 0 && C::BM == 128 && C::BN == 192 && C::WGS == 2) {
+    if (ep.ln_y != nullptr) {          // (wave-uniform; the ring is dead: both groups passed the loop's last barrier)
+      nt8_ln_epilogue<C>(smem, ep, acc, M, N, m0, n0, tm, tn, tiles_n, wm, wn, lane);
+      return;
+    }
+  }
   // ---------------- epilogue: per-wave fp32 transpose through LDS, 8 consecutive columns (16 B of bf16) per lane
   constexpr int RS = C::RS, ER = C::ER, ITEMS = C::RN / 8, NIT = ER * ITEMS / 64;
   float* et = (float*)smem + wave * (ER * RS);
@@ -525,6 +646,20 @@ bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda
   return (K % 8) == 0 && K >= 64 && (N % 8) == 0 && (ep.ldo % 8) == 0 && (ep.aux == nullptr || (ep.ldaux % 8) == 0) &&
          (lda % 8) == 0 && (ldb % 8) == 0 && M >= 1 && N >= 8 &&
          (int64_t)M * lda * 2 < 0xFFFFFF00ll && (int64_t)N * ldb * 2 < 0xFFFFFF00ll;
+}
+
+// K4: C = dropout(A . B^T + bias) + aux, then LayerNorm over the row (EpiParams::ln_*).  RL_ERR_ARG when the shape does not fit the
+// fused form (the caller then runs the GEMM and the LayerNorm as two launches).
+int gemm_nt8_ln(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep) {
+  if (ep.mode != EPI_DROP_RESID || ep.ln_y == nullptr || ep.ln_gamma == nullptr || ep.ln_beta == nullptr || ep.ln_part == nullptr ||
+      ep.ln_flag == nullptr || ep.aux == nullptr || ep.out == nullptr || ep.accumulate || ep.m_dev != nullptr || ep.slab != nullptr ||
+      (M % 128) != 0 || (N % 192) != 0 || N / 192 > 8 || (K % 64) != 0 || ep.ldo != N || (ep.ldaux % 4) != 0 || ep.rm_hw_shift >= 0 ||
+      (int64_t)M * N >= (1ll << 32) || !nt8_supported(M, N, K, ep, lda, ldb))
+    return RL_ERR_ARG;
+  // every workgroup of a row band must be resident at the same time: the bands' tiles are adjacent in the dispatch order and the
+  // whole launch (M / 128 * N / 192 tiles) has to fit the chip's 512 two-per-CU slots
+  if ((int64_t)(M / 128) * (N / 192) > 512) return RL_ERR_ARG;
+  return launch_nt8_cfg<Cfg128x192q>(st, A, lda, B, ldb, M, N, K, ep);
 }
 
 int gemm_nt8_splitk(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, int nsplit,

@@ -353,7 +353,7 @@ class RealiseModule(nn.Module):
             nbytes = lib.realise_engine_shadow_bytes(self._engine)
             self._shadow = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)      # padded rows rely on zero fill
             # id-range flag in host-mapped pinned memory: the device sets it, the host reads it without a synchronisation
-            self._id_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._id_flag = torch.zeros(2, dtype=torch.int32).pin_memory()        # [0] id range, [1] fused-LayerNorm wait gave up
             lib.realise_engine_set_id_flag(self._engine, self._id_flag.data_ptr())
             self._ws = None
             self._frozen_version = None
@@ -388,6 +388,10 @@ class RealiseModule(nn.Module):
         """nn.Embedding's IndexError, raised lazily: the engine replaced an out-of-range src_idx / pho_idx by 0 in an earlier
         step and flagged it (include/realise_hip.h: realise_engine_set_id_flag)"""
         f = getattr(self, "_id_flag", None)
+        if f is not None and int(f[1]) != 0:
+            f.zero_()
+            raise RuntimeError("a workgroup of the fused dense + LayerNorm launch gave up waiting for the other tiles of its rows in an "
+                               "earlier step (results of that step are invalid); realise_set_engine(8, 0) runs the two-launch form")
         if f is not None and int(f[0]) != 0:
             f.zero_()
             raise IndexError("index out of range in self: a src_idx outside [0, %d) or a pho_idx outside [0, %d) reached the "

@@ -15,6 +15,7 @@ import torch
 import realise_ref as R
 from helpers import check_summary, golden_case_inputs, load_golden, oracle_state_dict
 from realise_amd.config import RealiseConfig
+from realise_amd.data import synthetic_batch
 from realise_amd.modeling import SpellBert, SpellBertPho2ResArch3
 
 pytestmark = pytest.mark.gpu
