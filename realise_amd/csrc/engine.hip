@@ -60,6 +60,10 @@ void set_cls_compact(int on) { g_cls_compact = on; }
 // stores and an arrival counter).  0 = the GEMM and the LayerNorm as two launches.
 static int g_ln_fuse = 1;
 void set_ln_fuse(int on) { g_ln_fuse = on; }
+// K6 (realise_set_engine key 9): a GRU time step t > 0 as ONE launch - the recurrent projection with the gate math in its epilogue
+// (bf16; gemm_nt8_gru).  0 = GEMM + gru_step_fwd.
+static int g_gru_fuse = 1;
+void set_gru_fuse(int on) { g_gru_fuse = on; }
 static int g_cls_splitk = 3;
 void set_cls_splitk(int n) { g_cls_splitk = n < 0 ? 0 : (n > 4 ? 4 : n); }
 static int g_stream_pri[3] = {0, 0, 0};
@@ -948,6 +952,17 @@ template <typename T> struct Engine : EngineBase {
       T* hs_t = wp<T>(pl.gru_hs) + (int64_t)t * N * H;
       T* gh_t = wp<T>(pl.gru_gh) + (int64_t)t * N * 3 * H;
       const T* hs_prev = t > 0 ? wp<T>(pl.gru_hs) + (int64_t)(t - 1) * N * H : nullptr;
+      if constexpr (sizeof(T) == 2) {
+        if (t > 0 && g_gru_fuse && (H % 64) == 0) {      // recurrent projection + gate math in one launch
+          EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = hs_t; ep.ldo = H; ep.bias = pp(L.gru_b_hh); ep.m_dev = nd;
+          ep.gru_table = wp<float>(pl.gru_table); ep.gru_pho_idx = last.pho_idx; ep.gru_perm = last.pho_perm; ep.gru_lens = last.pho_lens_sorted;
+          ep.gru_hprev = hs_prev; ep.gru_rzn = wp<T>(pl.gru_rzn) + (int64_t)t * N * 3 * H; ep.gru_gh = gh_t; ep.gru_out = wp<T>(pl.gru_out);
+          ep.gru_Tp = Tp; ep.gru_t = t;
+          const int rc = gemm_nt8_gru(st, hs_prev, H, sp<T>(sh_gru_hh), H, n, 3 * H, H, ep);
+          if (rc == RL_OK) continue;
+          if (rc != RL_ERR_ARG) return rc;
+        }
+      }
       if (t > 0) {
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gh_t; ep.ldo = 3 * H; ep.bias = pp(L.gru_b_hh);
         RL_TRY(gemm_nt<T>(st, hs_prev, H, sp<T>(sh_gru_hh), H, n, 3 * H, H, ep, nd));

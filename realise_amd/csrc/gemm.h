@@ -57,6 +57,20 @@ template <typename T> struct EpiParams {
   int* ln_flag = nullptr;         // [M / 128]
   int ln_target = 0;
   int* ln_timeout = nullptr;      // nullable: set to 1 if a wait gave up (a workgroup of the band never arrived)
+  // K6 (models.py:818-826, one time step of nn.GRU): the recurrent projection gh = h_prev . W_hh^T + b_hh with the gate math in its
+  // epilogue (8-wave 128 x 192 kernel, N = 3H).  The B rows of a column tile are gathered gate-interleaved - [r | z | n] of 32 hidden
+  // units per wave - so that a wave's staged tile holds all three gates of its units: r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z +
+  // gh_z), n = tanh(gi_n + r gh_n), h = (1 - z) n + z h_prev, gi from the [33][3H] input table.  Stores h, (r, z, n) and gh_n (what
+  // the backward step reads), and the sequence's output row when it ends at this step.
+  const float* gru_table = nullptr;     // != nullptr selects the epilogue; out = h_new [M][H], bias = b_hh [3H]
+  const int64_t* gru_pho_idx = nullptr;
+  const int* gru_perm = nullptr;
+  const int* gru_lens = nullptr;
+  const T* gru_hprev = nullptr;
+  T* gru_rzn = nullptr;                 // [M][3H]
+  T* gru_gh = nullptr;                  // [M][3H]: only the n third is written
+  T* gru_out = nullptr;                 // [N tokens][H], original order
+  int gru_Tp = 0, gru_t = 0;
 };
 
 // ---- operand loaders ---------------------------------------------------------------------------
@@ -331,6 +345,8 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
 
 // K4: GEMM + bias + dropout + residual + LayerNorm in one launch (gemm_nt8.hip, see EpiParams::ln_*); RL_ERR_ARG = shape not supported
 int gemm_nt8_ln(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
+// K6: one GRU time step = recurrent GEMM + gate math in one launch (EpiParams::gru_*); H = N / 3 must be a multiple of 64
+int gemm_nt8_gru(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
 // Split-K NT GEMM (bf16, K % 64 == 0, nsplit <= K / 64): slab[s][m][n] (fp32, row pitch N, plane pitch slab_stride) = A[m, Ks] . B[n, Ks]^T
 // over the s-th K-range; rows at or beyond *m_dev (nullable) are not computed.  For reductions long enough that the output tiles
 // alone do not fill the chip: the classifier's data gradient (K = 21184, N = 768, ~4.9 k live rows = 156 tiles of 128 x 192).

@@ -165,7 +165,63 @@ __device__ __forceinline__ void nt8_ln_epilogue(char* smem, const EpiParams<bf16
   }
 }
 
-template <typename C, int PROBE, bool KTAIL = false>
+// ---- K6 epilogue: the gate math of one GRU time step on the recurrent projection this launch just computed (EpiParams::gru_*).
+// The wave's 32 x 96 tile holds [gh_r | gh_z | gh_n] of 32 hidden units (gate-interleaved B rows); it is staged 16 rows at a time
+// through the wave's LDS transpose tile, a lane then owns one row and 8 units.  gh goes through bf16 like the two-launch form
+// (GEMM stores bf16(acc + b_hh), gru_step_fwd reads it back), so both forms give the same bits.
+template <typename C>
+__device__ __forceinline__ void nt8_gru_epilogue(char* smem, const EpiParams<bf16_t>& ep, floatx4 (&acc)[C::MT][C::NT], int mlive, int H, int m0, int tn,
+                                                 int wave, int wm, int wn, int lane) {
+  typedef bf16_t T;
+  constexpr int RS = C::RS, ER = 16;
+  static_assert(C::RN == 96 && C::RM % 16 == 0 && 8 * ER * RS * 4 <= C::LDS, "GRU epilogue geometry");
+  const int g = lane >> 4, l15 = lane & 15;
+  float* et = (float*)smem + wave * (ER * RS);
+  const int r = lane >> 2, o = lane & 3;
+  const int unit0 = tn * 64 + wn * 32 + o * 8;
+#pragma unroll
+  for (int c = 0; c < C::RM / ER; ++c) {
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) *(floatx4*)(et + l15 * RS + j * 16 + 4 * g) = acc[c][j];
+    // (a wave reads back only what it wrote: no barrier, the LDS ops of a wave are in order)
+    const int i = m0 + wm * C::RM + c * ER + r;
+    if (i >= mlive) continue;
+    float hr[8], hz[8], hn[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { hr[e] = et[r * RS + o * 8 + e]; hz[e] = et[r * RS + 32 + o * 8 + e]; hn[e] = et[r * RS + 64 + o * 8 + e]; }
+    const float* b = ep.bias + unit0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {      // bias, then the bf16 round trip of the two-launch form
+      hr[e] = bf2f(f2bf(hr[e] + b[e])); hz[e] = bf2f(f2bf(hz[e] + b[H + e])); hn[e] = bf2f(f2bf(hn[e] + b[2 * H + e]));
+    }
+    const int tok = ep.gru_perm[i];
+    const int64_t v = ep.gru_pho_idx[(int64_t)tok * ep.gru_Tp + ep.gru_t];
+    const float* gi = ep.gru_table + v * 3 * H + unit0;
+    floatx4 p0, p1;
+    load8<T>(ep.gru_hprev + (int64_t)i * H + unit0, p0, p1);
+    float rr[8], zz[8], nn[8], hh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float hp = e < 4 ? p0[e] : p1[e - 4];
+      rr[e] = sigmoidf_(gi[e] + hr[e]);
+      zz[e] = sigmoidf_(gi[H + e] + hz[e]);
+      nn[e] = tanhf(gi[2 * H + e] + rr[e] * hn[e]);
+      hh[e] = (1.0f - zz[e]) * nn[e] + zz[e] * hp;
+    }
+    auto st8 = [&](T* p, const float (&x)[8]) { store8<T>(p, floatx4{x[0], x[1], x[2], x[3]}, floatx4{x[4], x[5], x[6], x[7]}); };
+    if (ep.gru_rzn != nullptr) {
+      T* s = ep.gru_rzn + (int64_t)i * 3 * H + unit0;
+      st8(s, rr); st8(s + H, zz); st8(s + 2 * H, nn);
+    }
+    if (ep.gru_gh != nullptr) st8(ep.gru_gh + (int64_t)i * 3 * H + 2 * H + unit0, hn);
+    st8(ep.out + (int64_t)i * H + unit0, hh);
+    if (ep.gru_lens[i] == ep.gru_t + 1) st8(ep.gru_out + (int64_t)tok * H + unit0, hh);
+  }
+}
+
+// XEPI: 0 = the standard epilogues (EpiParams::mode), 1 = K4 (+ LayerNorm across the row band's tiles), 2 = K6 (GRU gate math on
+// gate-interleaved B rows) - separate instantiations, so that the special epilogues' registers are not the layer GEMMs' problem
+template <typename C, int PROBE, bool KTAIL = false, int XEPI = 0>
 __global__ void __launch_bounds__(512, 2 * C::WGS)
 gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __restrict__ B_, int64_t ldb, int M, int N, int K, int tiles_n,
                 int ntiles, int group_m, EpiParams<bf16_t> ep) {
@@ -216,7 +272,13 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
       row = slice * C::SR + q * SQ * 16 + j * 8; is_b = C::HOLD_B ? 0 : 1;
     }
     lo[s] = (is_b ? C::A_BYTES : 0) + row * 128;
-    const int grow = is_b ? min(n0 + row + lrow, N - 1) : min(m0 + row + lrow, M - 1);
+    int grow = is_b ? min(n0 + row + lrow, N - 1) : min(m0 + row + lrow, M - 1);
+    if constexpr (XEPI == 2) {
+      if (is_b) {                                 // gate-interleaved column tile: [r | z | n] x 32 units for each of the two wave columns
+        const int c = row + lrow, half = c / 96, cc = c - half * 96, gate = cc >> 5;
+        grow = gate * (N / 3) + tn * 64 + half * 32 + (cc & 31);
+      }
+    }
     go[s] = (uint32_t)((int64_t)grow * (is_b ? ldb : lda) * 2 + kchunk_b);
     if (!is_b && m0 + row + lrow >= mzero) go[s] = 0xFFFFFF00u;     // beyond num_records: the buffer range check returns zeros
   }
@@ -337,11 +399,13 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   }
   if (grp == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }     // barrier census: group 1 took one extra up front
 
-  if constexpr (!KTAIL && PROBE == 0 && C::BM == 128 && C::BN == 192 && C::WGS == 2) {
-    if (ep.ln_y != nullptr) {          // (wave-uniform; the ring is dead: both groups passed the loop's last barrier)
-      nt8_ln_epilogue<C>(smem, ep, acc, M, N, m0, n0, tm, tn, tiles_n, wm, wn, lane);
-      return;
-    }
+  if constexpr (XEPI == 1) {             // (the ring is dead: both groups passed the loop's last barrier)
+    nt8_ln_epilogue<C>(smem, ep, acc, M, N, m0, n0, tm, tn, tiles_n, wm, wn, lane);
+    return;
+  }
+  if constexpr (XEPI == 2) {
+    nt8_gru_epilogue<C>(smem, ep, acc, mlive, N / 3, m0, tn, wave, wm, wn, lane);
+    return;
   }
   // ---------------- epilogue: per-wave fp32 transpose through LDS, 8 consecutive columns (16 B of bf16) per lane
   constexpr int RS = C::RS, ER = C::ER, ITEMS = C::RN / 8, NIT = ER * ITEMS / 64;
@@ -371,13 +435,13 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
 }
 
 
-template <typename C, bool KTAIL = false>
+template <typename C, bool KTAIL = false, int XEPI = 0>
 static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K,
                           const EpiParams<bf16_t>& ep) {
   const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (N + C::BN - 1) / C::BN, ntiles = tiles_m * tiles_n;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<C, 0, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<C, 0, KTAIL, XEPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
 #if RL_PROBES
     if constexpr (!KTAIL) {
       (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<C, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
@@ -394,7 +458,7 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
     if (g_nt8_probe == 3) { RL_LAUNCH((gemm_nt8_kernel<C, 3>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
   }
 #endif
-  RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL>), dim3(ntiles * (KTAIL || ep.ksplit < 1 ? 1 : ep.ksplit)), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
+  RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL, XEPI>), dim3(ntiles * (KTAIL || ep.ksplit < 1 ? 1 : ep.ksplit)), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -429,7 +493,13 @@ __device__ __forceinline__ void nt8ws_loader(char* smem, const bf16_t* __restric
       row = slice * C::SR + q * SQ * 16 + j * 8; is_b = C::HOLD_B ? 0 : 1;
     }
     lo[s] = (is_b ? C::A_BYTES : 0) + row * 128;
-    const int grow = is_b ? min(n0 + row + lrow, N - 1) : min(m0 + row + lrow, M - 1);
+    int grow = is_b ? min(n0 + row + lrow, N - 1) : min(m0 + row + lrow, M - 1);
+    if constexpr (XEPI == 2) {
+      if (is_b) {                                 // gate-interleaved column tile: [r | z | n] x 32 units for each of the two wave columns
+        const int c = row + lrow, half = c / 96, cc = c - half * 96, gate = cc >> 5;
+        grow = gate * (N / 3) + tn * 64 + half * 32 + (cc & 31);
+      }
+    }
     go[s] = (uint32_t)((int64_t)grow * (is_b ? ldb : lda) * 2 + kchunk_b);
   }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((int64_t)(M - 1) * lda + K) * 2), 0x00020000);
@@ -659,7 +729,16 @@ int gemm_nt8_ln(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, i
   // every workgroup of a row band must be resident at the same time: the bands' tiles are adjacent in the dispatch order and the
   // whole launch (M / 128 * N / 192 tiles) has to fit the chip's 512 two-per-CU slots
   if ((int64_t)(M / 128) * (N / 192) > 512) return RL_ERR_ARG;
-  return launch_nt8_cfg<Cfg128x192q>(st, A, lda, B, ldb, M, N, K, ep);
+  return launch_nt8_cfg<Cfg128x192q, false, 1>(st, A, lda, B, ldb, M, N, K, ep);
+}
+
+int gemm_nt8_gru(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep) {
+  const int H = N / 3;
+  if (ep.gru_table == nullptr || ep.gru_pho_idx == nullptr || ep.gru_perm == nullptr || ep.gru_lens == nullptr || ep.gru_hprev == nullptr ||
+      ep.out == nullptr || ep.gru_out == nullptr || ep.bias == nullptr || ep.mode != EPI_STORE || ep.accumulate || ep.slab != nullptr ||
+      ep.ln_y != nullptr || N != 3 * H || (H % 64) != 0 || (K % 64) != 0 || M < 1 || !nt8_supported(M, N, K, ep, lda, ldb))
+    return RL_ERR_ARG;
+  return launch_nt8_cfg<Cfg128x192q, false, 2>(st, A, lda, B, ldb, M, N, K, ep);
 }
 
 int gemm_nt8_splitk(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, int nsplit,

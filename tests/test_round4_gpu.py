@@ -208,3 +208,42 @@ def test_fused_dense_residual_layernorm_matches_the_two_launch_form(drop):
         if b.abs().max().item() < 1e-9 or n.endswith("attention.self.key.bias"):
             continue
         assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() > 0.995, n
+
+
+@pytest.mark.parametrize("device_batch", [False, True])
+def test_fused_gru_step_matches_the_two_launch_form(device_batch):
+    """K6 (models.py:818-826): with realise_set_engine(9, 1) a GRU time step t > 0 is one launch - the recurrent projection with the gate
+    math in its epilogue, the W_hh rows gathered gate-interleaved.  gh passes through bf16 exactly as in the two-launch form, so the GRU
+    output (tap pho_gru), the loss and every gradient must be IDENTICAL to the GEMM + gate-kernel form; host-built batches (exact row
+    counts) and device-built ones (nominal counts bounded on the device)."""
+    from realise_amd.data import synthetic_pinyin_table
+    lib = _capi.load()
+    cfg = RealiseConfig(num_hidden_layers=1, pho_layers=1, out_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = init_state_dict_numpy(cfg, seed=33)
+    table = synthetic_pinyin_table(cfg.vocab_size)
+    batch = synthetic_batch(10, 128, seed=6, pinyin_table=table)
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    if device_batch:
+        del batch["pho_idx"], batch["pho_lens"]
+
+    def run(fuse):
+        lib.realise_set_engine(9, fuse)
+        try:
+            m = build(cfg, sd, "bf16", train=True)
+            if device_batch:
+                m.set_pinyin_table(table)
+            loss, logits = m(batch)
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss.item()), m.tap("pho_gru").clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            lib.realise_set_engine(9, 1)
+
+    lf, gf, gradf = run(1)
+    lu, gu, gradu = run(0)
+    assert torch.isfinite(gf.float()).all() and gf.float().abs().max().item() > 0.0
+    assert torch.equal(gf, gu), (gf.float() - gu.float()).abs().max().item()
+    assert lf == lu
+    for n in ("pho_gru.weight_hh_l0", "pho_gru.bias_hh_l0", "pho_gru.weight_ih_l0", "pho_embeddings.weight"):
+        a, b = gradf[n].float(), gradu[n].float()
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-12, n      # (fp32 atomics in the table / bias sums)
