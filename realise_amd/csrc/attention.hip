@@ -46,6 +46,29 @@ __device__ __forceinline__ void stage_rows(const T* __restrict__ src, int64_t st
   }
 }
 
+// bf16: the same image by LDS-DMA (global_load_lds, 16 B per lane): no round trip through registers, and - the point - every piece of
+// every tile a kernel stages is in flight at once; the register path pays a load -> store dependency per 4 KB.  A wave-instruction
+// fills 1 KiB = 8 rows x 128 B of the tile in lane order, so lane l (row 8p + l / 8, slot l % 8) fetches the chunk that BELONGS in its
+// slot under the chunk ^ (row & 7) swizzle.  Rows >= S read a zero page.  The caller waits (stage_wait) before its barrier.
+static __device__ uint4 g_attn_zero[1];
+__device__ __forceinline__ void stage_rows_dma(const bf16_t* __restrict__ src, int64_t stride, int S, char* kt, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int i = 0; i < SMAX / 32; ++i) {
+    const int p = wave + 4 * i;                      // piece = rows 8p .. 8p + 7
+    const int row = 8 * p + (lane >> 3), ch = (lane & 7) ^ (row & 7);
+    const void* g = row < S ? (const void*)(src + (int64_t)row * stride + ch * 8) : (const void*)g_attn_zero;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(kt + p * 1024), 16, 0, 0);
+  }
+}
+template <typename T> __device__ __forceinline__ void stage_tile(const T* __restrict__ src, int64_t stride, int S, char* kt, int tid) {
+  if constexpr (sizeof(T) == 2) stage_rows_dma(src, stride, S, kt, tid);
+  else stage_rows<T>(src, stride, S, kt, tid);
+}
+template <typename T> __device__ __forceinline__ void stage_wait() {
+  if constexpr (sizeof(T) == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // operand fragment loaded straight from global memory: row `row` of a [.,64] matrix, MMA step ks
 template <typename T>
 __device__ __forceinline__ typename MmaOf<T>::type::Frag gfrag(const T* __restrict__ base, int64_t stride, int row, int S, int ks, int g);
@@ -136,9 +159,10 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) qf[m][ks] = gfrag<T>(Q, ldq, q0 + 16 * m + l15, S, ks, g);
-  stage_rows<T>(K, ldq, S, Ks, tid);
-  stage_rows<T>(V, ldq, S, Vs, tid);
+  stage_tile<T>(K, ldq, S, Ks, tid);
+  stage_tile<T>(V, ldq, S, Vs, tid);
   if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
+  stage_wait<T>();
   __syncthreads();
   if (q0 >= S || probe == 1) return;
 
@@ -248,8 +272,8 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
   // query blocks beyond Sl are not visited, key tiles beyond Sl store zeros without being computed.
   const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;
 
-  stage_rows<T>(Q, ldq, Sl, Qs, tid);
-  stage_rows<T>(dO, H, Sl, dOs, tid);
+  stage_tile<T>(Q, ldq, Sl, Qs, tid);
+  stage_tile<T>(dO, H, Sl, dOs, tid);
   {  // rowdot[q] = sum_d dO[q,d] * O[q,d]  (two threads per row)
     const int row = tid >> 1, half = tid & 1;
     float acc = 0.f;
@@ -269,6 +293,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
       if (row < S) rowdot[(int64_t)bh * S + row] = acc;
     }
   }
+  stage_wait<T>();
   __syncthreads();
   const int k0 = wave * 32;
   if (k0 >= S) return;
@@ -375,9 +400,10 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
   const T* dO = dctx + (int64_t)b * S * H + h * HD;
 
   const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;       // see attn_bwd_dkv_kernel: padding keys are not visited, padding queries get dQ = 0
-  stage_rows<T>(K, ldq, Sl, Ks, tid);
-  stage_rows<T>(V, ldq, Sl, Vs, tid);
+  stage_tile<T>(K, ldq, Sl, Ks, tid);
+  stage_tile<T>(V, ldq, Sl, Vs, tid);
   if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
+  stage_wait<T>();
   __syncthreads();
   const int q0 = wave * 32;
   if (q0 >= S) return;
