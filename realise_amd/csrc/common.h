@@ -198,6 +198,15 @@ template <typename T> __device__ __forceinline__ float gelu_bwd(float x) {
   else { float tp, e; gelu_parts_fast(x, tp, e); return fmaf(x * 0.39894228040143267794f, e, 0.5f * tp); }
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// GRU gate nonlinearities: libm forms in parity mode (T = float); in speed mode the v_exp_f32 forms (relative error ~1e-6, far inside
+// bf16 resolution; tanh(x) = 1 - 2 / (exp(2x) + 1) saturates cleanly at +-1 for large |x|).  Shared by gru_step_fwd and the fused
+// GRU epilogue of the 8-wave GEMM, which must give the same bits.
+template <typename T> __device__ __forceinline__ float gru_sigmoid(float x) {
+  if constexpr (sizeof(T) == 4) return sigmoidf_(x); else return __frcp_rn(1.0f + __expf(-x));
+}
+template <typename T> __device__ __forceinline__ float gru_tanh(float x) {
+  if constexpr (sizeof(T) == 4) return tanhf(x); else return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
+}
 
 // XCD-aware bijective block remap (8 XCDs; block b is observed on XCD b % 8): each XCD gets a
 // contiguous run of logical tiles so neighbouring tiles share operand panels in one L2.

@@ -459,9 +459,9 @@ template <typename T> struct Engine : EngineBase {
     p.cls_slab = (!glyph_only && sizeof(T) == 2) ? b.take(4 * Tk * H * 4) : 0;      // fp32 planes of the split-K classifier data gradient
     if (!glyph_only && sizeof(T) == 2) {
       for (int k = 0; k < 3; ++k) {
-        p.ln_part[k] = b.take(Tk * 8 * 2 * 4);
-        p.ln_flag[k] = b.take((Tk / 128 + 8) * 4);
-        p.zero_once.push_back({p.ln_flag[k], (Tk / 128 + 8) * 4});
+        p.ln_part[k] = b.take(Tk * 8 * 2 * 8);
+        p.ln_flag[k] = 0;
+        p.zero_once.push_back({p.ln_part[k], Tk * 8 * 2 * 8});
       }
     }
     // shared backward scratch
@@ -1021,11 +1021,11 @@ template <typename T> struct Engine : EngineBase {
     const int Tk = pl.B * pl.S;
     EpiParams<T> ep; ep.mode = EPI_DROP_RESID; ep.out = s_xhat; ep.ldo = H; ep.bias = bias; ep.aux = resid; ep.ldaux = H; set_drop(ep, drop);
     if constexpr (sizeof(T) == 2) {
-      if (g_ln_fuse && sid >= 0 && sid < 3 && pl.ln_part[sid] != 0 && (Tk % 128) == 0 && (H % 192) == 0 && ln_epoch[sid] < (1 << 27)) {
+      if (g_ln_fuse && sid >= 0 && sid < 3 && pl.ln_part[sid] != 0 && (Tk % 128) == 0 && (H % 192) == 0) {
         EpiParams<T> e2 = ep;
         e2.ln_gamma = gamma; e2.ln_beta = beta; e2.ln_eps = cfg.ln_eps; e2.ln_y = y; e2.ln_rstd = rstd;
-        e2.ln_part = wp<float>(pl.ln_part[sid]); e2.ln_flag = wp<int>(pl.ln_flag[sid]);
-        e2.ln_target = (ln_epoch[sid] + 1) * (H / 192);
+        e2.ln_part = wp<float>(pl.ln_part[sid]);
+        e2.ln_target = (ln_epoch[sid] % 0x7FFFFFF0) + 1;          // launch tag: never 0 (the zero-filled buffer), != the previous launch's
         e2.ln_timeout = id_flag != nullptr ? id_flag + 1 : nullptr;
         const int rc = gemm_nt8_ln(st, a, K, w, K, Tk, H, K, e2);
         if (rc == RL_OK) { ++ln_epoch[sid]; return RL_OK; }

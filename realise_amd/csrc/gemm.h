@@ -45,17 +45,18 @@ template <typename T> struct EpiParams {
   int ksplit = 1;
   // K4 (BertSelfOutput / BertOutput, modeling_bert.py:273-277, 339-343): EPI_DROP_RESID followed by the LayerNorm of the row in the SAME
   // launch (8-wave 128 x 192 kernel, M % 128 == 0, N % 192 == 0, N / 192 <= 8).  A row spans N / 192 column tiles = workgroups: each
-  // leaves (sum, M2) of its 192 columns in ln_part[row][tile] and bumps ln_flag[row tile]; when all tiles of the row band have
-  // arrived (counter >= ln_target: the caller passes launch count x tiles per band - the counters are never reset) every workgroup
-  // combines the partials (Chan), normalises its own columns from LDS and writes xhat -> out, y -> ln_y, rstd -> ln_rstd.
+  // leaves (sum, M2) of its 192 columns in ln_part[row][tile] as two self-validating 64-bit words {value, tag = ln_target} and polls
+  // the other tiles' slots until they carry this launch's tag (the caller passes a tag that differs from the previous launch's on the
+  // same buffer, never 0); then every workgroup combines the partials (Chan), normalises its own columns from LDS and writes
+  // xhat -> out, y -> ln_y, rstd -> ln_rstd.
   const float* ln_gamma = nullptr;
   const float* ln_beta = nullptr;
   float ln_eps = 0.f;
   T* ln_y = nullptr;
   float* ln_rstd = nullptr;
-  float* ln_part = nullptr;       // [M][N / 192][2]
-  int* ln_flag = nullptr;         // [M / 128]
-  int ln_target = 0;
+  float* ln_part = nullptr;       // [M][N / 192][2] 64-bit words (16 B per row and tile), zero-filled once
+  int* ln_flag = nullptr;         // (unused)
+  int ln_target = 0;              // launch tag
   int* ln_timeout = nullptr;      // nullable: set to 1 if a wait gave up (a workgroup of the band never arrived)
   // K6 (models.py:818-826, one time step of nn.GRU): the recurrent projection gh = h_prev . W_hh^T + b_hh with the gate math in its
   // epilogue (8-wave 128 x 192 kernel, N = 3H).  The B rows of a column tile are gathered gate-interleaved - [r | z | n] of 32 hidden

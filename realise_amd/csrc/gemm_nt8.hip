@@ -103,34 +103,33 @@ __device__ __forceinline__ void nt8_ln_epilogue(char* smem, const EpiParams<bf16
 #pragma unroll
   for (int k = 0; k < QC; ++k) { const float d = xs[k] - mean_t; m2 += d * d; }
   m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64);
-  float* part = ep.ln_part + ((int64_t)(m0 + srow) * tiles_n) * 2;
-  if (sq == 0) {        // device-scope stores (write through to where the other workgroups' device-scope loads read)
-    __hip_atomic_store(part + tn * 2, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(part + tn * 2 + 1, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // C. hand the partials to the other column tiles of the row band and collect theirs.  A slot is two 64-bit words {value, tag}:
+  // each word is written by ONE device-scope atomic store and validates itself (tag = this launch's number; the previous content of
+  // a slot is always the previous launch's, whose tag differs) - no fence, no flag, no second round trip: a reader simply polls the
+  // slots it needs.  The wait is bounded: a tile that never arrives must not hang the GPU (ln_timeout tells the host).
+  unsigned long long* part = (unsigned long long*)ep.ln_part + ((int64_t)(m0 + srow) * tiles_n) * 2;
+  const unsigned long long tag = (unsigned long long)(uint32_t)ep.ln_target << 32;
+  if (sq == 0) {
+    __hip_atomic_store(part + tn * 2, tag | (unsigned long long)__float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + tn * 2 + 1, tag | (unsigned long long)__float_as_uint(m2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  // C. arrival counter of the row band; wait for the other column tiles (bounded: a workgroup that never arrives must not hang the GPU)
-  if (tid == 0) {
-    __hip_atomic_fetch_add(ep.ln_flag + tm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int spins = 0;
-    while (__hip_atomic_load(ep.ln_flag + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ep.ln_target < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 22)) { if (ep.ln_timeout != nullptr) *ep.ln_timeout = 1; break; }
-    }
-  }
-  __syncthreads();
-  // D. combine the tiles' partials (Chan's rule, n_t = BN each); the 4 threads of a row take tiles sq and sq + 4
+  // D. combine (Chan's rule, n_t = BN each); the 4 threads of a row take tiles sq and sq + 4
   float s_a = 0.f, s_b = 0.f, pm2 = 0.f;
   const bool has_a = sq < tiles_n, has_b = sq + 4 < tiles_n;
-  if (has_a) {
-    s_a = __hip_atomic_load(part + sq * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pm2 = __hip_atomic_load(part + sq * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (has_b) {
-    s_b = __hip_atomic_load(part + (sq + 4) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pm2 += __hip_atomic_load(part + (sq + 4) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  auto fetch = [&](int t, float& s_out, float& m_out) {
+    unsigned long long w0, w1;
+    int spins = 0;
+    for (;;) {
+      w0 = __hip_atomic_load(part + t * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      w1 = __hip_atomic_load(part + t * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (((w0 ^ tag) >> 32) == 0ull && ((w1 ^ tag) >> 32) == 0ull) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 20)) { if (ep.ln_timeout != nullptr) *ep.ln_timeout = 1; break; }
+    }
+    s_out = __uint_as_float((uint32_t)w0); m_out = __uint_as_float((uint32_t)w1);
+  };
+  if (has_a) fetch(sq, s_a, pm2);
+  if (has_b) { float m_b; fetch(sq + 4, s_b, m_b); pm2 += m_b; }
   float tsum = s_a + s_b;
   tsum += __shfl_xor(tsum, 1, 64); tsum += __shfl_xor(tsum, 2, 64);
   const float mean = tsum / (float)N;
@@ -169,12 +168,31 @@ __device__ __forceinline__ void nt8_ln_epilogue(char* smem, const EpiParams<bf16
 // The wave's 32 x 96 tile holds [gh_r | gh_z | gh_n] of 32 hidden units (gate-interleaved B rows); it is staged 16 rows at a time
 // through the wave's LDS transpose tile, a lane then owns one row and 8 units.  gh goes through bf16 like the two-launch form
 // (GEMM stores bf16(acc + b_hh), gru_step_fwd reads it back), so both forms give the same bits.
+// Row state of the GRU epilogue, fetched at kernel start so that the dependent chain perm -> pho_idx -> table row (three global
+// latencies) and the h_prev rows run under the main loop instead of in front of every 16-row chunk of the epilogue.
+struct GruRows { int tok[2]; int gi_off[2]; bool ends[2]; uint4 hp[2]; };
 template <typename C>
-__device__ __forceinline__ void nt8_gru_epilogue(char* smem, const EpiParams<bf16_t>& ep, floatx4 (&acc)[C::MT][C::NT], int mlive, int H, int m0, int tn,
-                                                 int wave, int wm, int wn, int lane) {
+__device__ __forceinline__ void nt8_gru_prefetch(const EpiParams<bf16_t>& ep, GruRows& gr, int mlive, int H, int m0, int tn, int wm, int wn, int lane) {
+  const int r = lane >> 2, o = lane & 3;
+  const int unit0 = tn * 64 + wn * 32 + o * 8;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int i = m0 + wm * C::RM + c * 16 + r;
+    const bool ok = i < mlive;
+    const int tok = ok ? ep.gru_perm[i] : 0;
+    const int64_t v = ok ? ep.gru_pho_idx[(int64_t)tok * ep.gru_Tp + ep.gru_t] : 0;
+    gr.tok[c] = tok;
+    gr.gi_off[c] = (int)v * 3 * H + unit0;
+    gr.ends[c] = ok && ep.gru_lens[i] == ep.gru_t + 1;
+    gr.hp[c] = ok ? *(const uint4*)(ep.gru_hprev + (int64_t)i * H + unit0) : uint4{0u, 0u, 0u, 0u};
+  }
+}
+template <typename C>
+__device__ __forceinline__ void nt8_gru_epilogue(char* smem, const EpiParams<bf16_t>& ep, floatx4 (&acc)[C::MT][C::NT], const GruRows& gr, int mlive, int H,
+                                                 int m0, int tn, int wave, int wm, int wn, int lane) {
   typedef bf16_t T;
   constexpr int RS = C::RS, ER = 16;
-  static_assert(C::RN == 96 && C::RM % 16 == 0 && 8 * ER * RS * 4 <= C::LDS, "GRU epilogue geometry");
+  static_assert(C::RN == 96 && C::RM == 32 && 8 * ER * RS * 4 <= C::LDS, "GRU epilogue geometry");
   const int g = lane >> 4, l15 = lane & 15;
   float* et = (float*)smem + wave * (ER * RS);
   const int r = lane >> 2, o = lane & 3;
@@ -188,24 +206,31 @@ __device__ __forceinline__ void nt8_gru_epilogue(char* smem, const EpiParams<bf1
     if (i >= mlive) continue;
     float hr[8], hz[8], hn[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { hr[e] = et[r * RS + o * 8 + e]; hz[e] = et[r * RS + 32 + o * 8 + e]; hn[e] = et[r * RS + 64 + o * 8 + e]; }
-    const float* b = ep.bias + unit0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {      // bias, then the bf16 round trip of the two-launch form
-      hr[e] = bf2f(f2bf(hr[e] + b[e])); hz[e] = bf2f(f2bf(hz[e] + b[H + e])); hn[e] = bf2f(f2bf(hn[e] + b[2 * H + e]));
+    for (int e = 0; e < 8; e += 4) {
+      *(floatx4*)&hr[e] = *(const floatx4*)(et + r * RS + o * 8 + e);
+      *(floatx4*)&hz[e] = *(const floatx4*)(et + r * RS + 32 + o * 8 + e);
+      *(floatx4*)&hn[e] = *(const floatx4*)(et + r * RS + 64 + o * 8 + e);
     }
-    const int tok = ep.gru_perm[i];
-    const int64_t v = ep.gru_pho_idx[(int64_t)tok * ep.gru_Tp + ep.gru_t];
-    const float* gi = ep.gru_table + v * 3 * H + unit0;
+    const float* b = ep.bias + unit0;
+    const float* gi = ep.gru_table + gr.gi_off[c];
+    float br[8], bz[8], bn[8], ir[8], iz[8], in[8];
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+      *(floatx4*)&br[e] = *(const floatx4*)(b + e); *(floatx4*)&bz[e] = *(const floatx4*)(b + H + e); *(floatx4*)&bn[e] = *(const floatx4*)(b + 2 * H + e);
+      *(floatx4*)&ir[e] = *(const floatx4*)(gi + e); *(floatx4*)&iz[e] = *(const floatx4*)(gi + H + e); *(floatx4*)&in[e] = *(const floatx4*)(gi + 2 * H + e);
+    }
     floatx4 p0, p1;
-    load8<T>(ep.gru_hprev + (int64_t)i * H + unit0, p0, p1);
+    unpack8(gr.hp[c], p0, p1);
     float rr[8], zz[8], nn[8], hh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+      // bias, then the bf16 round trip of the two-launch form (GEMM stores bf16(acc + b_hh), the gate kernel reads it back)
+      const float xr = bf2f(f2bf(hr[e] + br[e])), xz = bf2f(f2bf(hz[e] + bz[e]));
+      hn[e] = bf2f(f2bf(hn[e] + bn[e]));
       const float hp = e < 4 ? p0[e] : p1[e - 4];
-      rr[e] = sigmoidf_(gi[e] + hr[e]);
-      zz[e] = sigmoidf_(gi[H + e] + hz[e]);
-      nn[e] = tanhf(gi[2 * H + e] + rr[e] * hn[e]);
+      rr[e] = gru_sigmoid<T>(ir[e] + xr);
+      zz[e] = gru_sigmoid<T>(iz[e] + xz);
+      nn[e] = gru_tanh<T>(in[e] + rr[e] * hn[e]);
       hh[e] = (1.0f - zz[e]) * nn[e] + zz[e] * hp;
     }
     auto st8 = [&](T* p, const float (&x)[8]) { store8<T>(p, floatx4{x[0], x[1], x[2], x[3]}, floatx4{x[4], x[5], x[6], x[7]}); };
@@ -215,7 +240,7 @@ __device__ __forceinline__ void nt8_gru_epilogue(char* smem, const EpiParams<bf1
     }
     if (ep.gru_gh != nullptr) st8(ep.gru_gh + (int64_t)i * 3 * H + 2 * H + unit0, hn);
     st8(ep.out + (int64_t)i * H + unit0, hh);
-    if (ep.gru_lens[i] == ep.gru_t + 1) st8(ep.gru_out + (int64_t)tok * H + unit0, hh);
+    if (gr.ends[c]) st8(ep.gru_out + (int64_t)gr.tok[c] * H + unit0, hh);
   }
 }
 
@@ -253,6 +278,8 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   const int mlive = ep.m_dev != nullptr ? *ep.m_dev : M;
   if (m0 >= mlive) return;                                  // device-side live-row count: the whole workgroup leaves before any barrier
   const int mzero = ep.m_exact ? mlive : M;                 // A rows at or beyond it read as zeros
+  GruRows gru_rows;
+  if constexpr (XEPI == 2) nt8_gru_prefetch<C>(ep, gru_rows, mlive, N / 3, m0, tn, wave / C::WN, wave % C::WN, lane);
   const int nk = (K + 63) >> 6;
   const int ktail = KTAIL ? (K & 63) : 0;   // elements of a ragged last K-tile (multiple of 8); KTAIL = false: K % 64 == 0
 
@@ -404,7 +431,7 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
     return;
   }
   if constexpr (XEPI == 2) {
-    nt8_gru_epilogue<C>(smem, ep, acc, mlive, N / 3, m0, tn, wave, wm, wn, lane);
+    nt8_gru_epilogue<C>(smem, ep, acc, gru_rows, mlive, N / 3, m0, tn, wave, wm, wn, lane);
     return;
   }
   // ---------------- epilogue: per-wave fp32 transpose through LDS, 8 consecutive columns (16 B of bf16) per lane
@@ -718,11 +745,12 @@ bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda
          (int64_t)M * lda * 2 < 0xFFFFFF00ll && (int64_t)N * ldb * 2 < 0xFFFFFF00ll;
 }
 
-// K4: C = dropout(A . B^T + bias) + aux, then LayerNorm over the row (EpiParams::ln_*).  RL_ERR_ARG when the shape does not fit the
+// K4: C = dropout(A . B^T + bias) + aux, then LayerNorm over the row (EpiParams::ln_*; ln_target = this launch's tag, != the previous
+// launch's on the same ln_part buffer; ln_flag is not used by this form).  RL_ERR_ARG when the shape does not fit the
 // fused form (the caller then runs the GEMM and the LayerNorm as two launches).
 int gemm_nt8_ln(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep) {
   if (ep.mode != EPI_DROP_RESID || ep.ln_y == nullptr || ep.ln_gamma == nullptr || ep.ln_beta == nullptr || ep.ln_part == nullptr ||
-      ep.ln_flag == nullptr || ep.aux == nullptr || ep.out == nullptr || ep.accumulate || ep.m_dev != nullptr || ep.slab != nullptr ||
+      ep.ln_target == 0 || ep.aux == nullptr || ep.out == nullptr || ep.accumulate || ep.m_dev != nullptr || ep.slab != nullptr ||
       (M % 128) != 0 || (N % 192) != 0 || N / 192 > 8 || (K % 64) != 0 || ep.ldo != N || (ep.ldaux % 4) != 0 || ep.rm_hw_shift >= 0 ||
       (int64_t)M * N >= (1ll << 32) || !nt8_supported(M, N, K, ep, lda, ldb))
     return RL_ERR_ARG;
