@@ -207,6 +207,17 @@ template <typename T> __device__ __forceinline__ float gru_sigmoid(float x) {
 template <typename T> __device__ __forceinline__ float gru_tanh(float x) {
   if constexpr (sizeof(T) == 4) return tanhf(x); else return 1.0f - 2.0f * __frcp_rn(__expf(2.0f * x) + 1.0f);
 }
+// one hidden unit of a GRU step (models.py:818-826, nn.GRU): gi_* = W_ih x + b_ih, gh_* = W_hh h + b_hh.  Contraction is pinned off and
+// the one multiply-add that matters is spelled out, so the gate kernel and the fused GEMM epilogue - two translation units - round alike.
+template <typename T>
+__device__ __forceinline__ void gru_unit(float gi_r, float gi_z, float gi_n, float gh_r, float gh_z, float gh_n, float h_prev, float& r, float& z,
+                                         float& n, float& h) {
+#pragma clang fp contract(off)
+  r = gru_sigmoid<T>(gi_r + gh_r);
+  z = gru_sigmoid<T>(gi_z + gh_z);
+  n = gru_tanh<T>(gi_n + r * gh_n);
+  h = (1.0f - z) * n + z * h_prev;
+}
 
 // XCD-aware bijective block remap (8 XCDs; block b is observed on XCD b % 8): each XCD gets a
 // contiguous run of logical tiles so neighbouring tiles share operand panels in one L2.

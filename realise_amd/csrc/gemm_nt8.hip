@@ -228,10 +228,7 @@ __device__ __forceinline__ void nt8_gru_epilogue(char* smem, const EpiParams<bf1
       const float xr = bf2f(f2bf(hr[e] + br[e])), xz = bf2f(f2bf(hz[e] + bz[e]));
       hn[e] = bf2f(f2bf(hn[e] + bn[e]));
       const float hp = e < 4 ? p0[e] : p1[e - 4];
-      rr[e] = gru_sigmoid<T>(ir[e] + xr);
-      zz[e] = gru_sigmoid<T>(iz[e] + xz);
-      nn[e] = gru_tanh<T>(in[e] + rr[e] * hn[e]);
-      hh[e] = (1.0f - zz[e]) * nn[e] + zz[e] * hp;
+      gru_unit<T>(ir[e], iz[e], in[e], xr, xz, hn[e], hp, rr[e], zz[e], nn[e], hh[e]);
     }
     auto st8 = [&](T* p, const float (&x)[8]) { store8<T>(p, floatx4{x[0], x[1], x[2], x[3]}, floatx4{x[4], x[5], x[6], x[7]}); };
     if (ep.gru_rzn != nullptr) {

@@ -34,10 +34,9 @@ __global__ void gru_step_fwd_kernel(GruStepArgs<T> a) {    // grid (H/4/64, n_al
   floatx4 r, z, n, h;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    r[j] = gru_sigmoid<T>(ir[j] + hr[j]);
-    z[j] = gru_sigmoid<T>(iz[j] + hz[j]);
-    n[j] = gru_tanh<T>(in[j] + r[j] * hn[j]);
-    h[j] = (1.0f - z[j]) * n[j] + z[j] * hp[j];
+    float rj, zj, nj, hj;
+    gru_unit<T>(ir[j], iz[j], in[j], hr[j], hz[j], hn[j], hp[j], rj, zj, nj, hj);
+    r[j] = rj; z[j] = zj; n[j] = nj; h[j] = hj;
   }
   if (a.rzn != nullptr) {
     T* s = a.rzn + (int64_t)i * 3 * H + c;
