@@ -19,7 +19,7 @@
 
 namespace rl {
 
-static int g_attn_probe = 0;       // diagnostics (tools/nt_probe.cpp): 1 stop after staging, 2 skip the softmax
+static int g_attn_probe = 0;       // diagnostics (tools/nt_probe.cpp): 1 stop after staging, 2 skip the softmax; bit 4 (16): tiles staged through registers
 void set_attn_probe(int mode) { g_attn_probe = mode; }
 
 static constexpr int HD = 64;      // head dim
@@ -61,8 +61,8 @@ __device__ __forceinline__ void stage_rows_dma(const bf16_t* __restrict__ src, i
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(kt + p * 1024), 16, 0, 0);
   }
 }
-template <typename T> __device__ __forceinline__ void stage_tile(const T* __restrict__ src, int64_t stride, int S, char* kt, int tid) {
-  if constexpr (sizeof(T) == 2) stage_rows_dma(src, stride, S, kt, tid);
+template <typename T> __device__ __forceinline__ void stage_tile(const T* __restrict__ src, int64_t stride, int S, char* kt, int tid, int via_regs = 0) {
+  if constexpr (sizeof(T) == 2) { if (via_regs) stage_rows<T>(src, stride, S, kt, tid); else stage_rows_dma(src, stride, S, kt, tid); }
   else stage_rows<T>(src, stride, S, kt, tid);
 }
 template <typename T> __device__ __forceinline__ void stage_wait() {
@@ -159,8 +159,9 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) qf[m][ks] = gfrag<T>(Q, ldq, q0 + 16 * m + l15, S, ks, g);
-  stage_tile<T>(K, ldq, S, Ks, tid);
-  stage_tile<T>(V, ldq, S, Vs, tid);
+  stage_tile<T>(K, ldq, S, Ks, tid, probe & 16);
+  stage_tile<T>(V, ldq, S, Vs, tid, probe & 16);
+  probe &= 15;
   if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
   stage_wait<T>();
   __syncthreads();
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(256, 3)
 attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
                     const float* __restrict__ mask_add, const T* __restrict__ ctx, const T* __restrict__ dctx, int64_t ldc,
                     const float* __restrict__ lse, float* __restrict__ rowdot, T* __restrict__ dk_, T* __restrict__ dv_,
-                    int64_t ldd, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* __restrict__ rlen) {
+                    int64_t ldd, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* __restrict__ rlen, int via_regs) {
   typedef typename MmaOf<T>::type Mma;
   typedef AttnGeo<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -272,8 +273,8 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
   // query blocks beyond Sl are not visited, key tiles beyond Sl store zeros without being computed.
   const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;
 
-  stage_tile<T>(Q, ldq, Sl, Qs, tid);
-  stage_tile<T>(dO, H, Sl, dOs, tid);
+  stage_tile<T>(Q, ldq, Sl, Qs, tid, via_regs);
+  stage_tile<T>(dO, H, Sl, dOs, tid, via_regs);
   {  // rowdot[q] = sum_d dO[q,d] * O[q,d]  (two threads per row)
     const int row = tid >> 1, half = tid & 1;
     float acc = 0.f;
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(256, 3)
 attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
                    const float* __restrict__ mask_add, const T* __restrict__ dctx, int64_t ldc,
                    const float* __restrict__ lse, const float* __restrict__ rowdot, T* __restrict__ dq_out, int64_t ldd,
-                   int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* __restrict__ rlen) {
+                   int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* __restrict__ rlen, int via_regs) {
   typedef typename MmaOf<T>::type Mma;
   typedef AttnGeo<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -400,8 +401,8 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
   const T* dO = dctx + (int64_t)b * S * H + h * HD;
 
   const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;       // see attn_bwd_dkv_kernel: padding keys are not visited, padding queries get dQ = 0
-  stage_tile<T>(K, ldq, Sl, Ks, tid);
-  stage_tile<T>(V, ldq, Sl, Vs, tid);
+  stage_tile<T>(K, ldq, Sl, Ks, tid, via_regs);
+  stage_tile<T>(V, ldq, Sl, Vs, tid, via_regs);
   if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
   stage_wait<T>();
   __syncthreads();
@@ -531,12 +532,12 @@ int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
   {
     ProfScope ps(st, PK_ATTN_BWD, 6.0 * B * nh * (double)S * S * 64);
     RL_LAUNCH((attn_bwd_dkv_kernel<T>), dim3(B * nh), dim3(256), lds1, st, q, k, v, ldq, mask_add, ctx, dctx, ldc,
-              lse, rowdot, dk, dv, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale, rlen);
+              lse, rowdot, dk, dv, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale, rlen, g_attn_probe & 16);
   }
   {
     ProfScope ps(st, PK_ATTN_BWD, 4.0 * B * nh * (double)S * S * 64);
     RL_LAUNCH((attn_bwd_dq_kernel<T>), dim3(B * nh), dim3(256), lds2, st, q, k, v, ldq, mask_add, dctx, ldc, lse,
-              rowdot, dq, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale, rlen);
+              rowdot, dq, ldd, B, nh, S, drop_seed, drop_thresh, drop_scale, rlen, g_attn_probe & 16);
   }
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }

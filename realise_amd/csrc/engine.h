@@ -12,7 +12,7 @@ void set_dgrad_parity(int on);    // stride-2 conv data gradients by input-pixel
 void set_fwd_order(int o);        // enqueue order of the forward branches: 0 bert first, 1 bert last
 void set_skip_dead(int on);        // backward skips padding rows (default 1)
 void set_cls_compact(int on);      // classifier backward over the loss rows only (default 1)
-void set_ln_fuse(int on);          // dense + dropout + residual + LayerNorm as one launch (default 1)
+void set_ln_fuse(int on);          // dense + dropout + residual + LayerNorm as one launch (default 0: see engine.hip)
 void set_gru_fuse(int on);         // GRU time step as one launch: recurrent GEMM + gate math (default 1)
 void set_cls_splitk(int n);        // K-ranges of the classifier's data gradient (default 3, 0 / 1: one launch over the whole K)
 void set_stream_priority(int which, int pri);   // 0 pinyin branch, 1 glyph branch, 2 weight-gradient stream; -1 high, 0 default, +1 low (read at stream creation)
