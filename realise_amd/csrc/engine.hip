@@ -945,7 +945,11 @@ template <typename T> struct Engine : EngineBase {
   // ---------------------------------------------------------------- pinyin GRU (models.py:818-826)
   int gru_forward(hipStream_t st) {
     const int N = pl.B * pl.S, Tp = last.Tp;
-    {   // W_ih x + b_ih for the 33 pinyin symbols: one exact-fp32 MFMA GEMM from the fp32 masters ([33,768] x [2304,768]^T)
+    // W_ih x + b_ih for the 33 pinyin symbols, from the fp32 masters.  Parity mode: one exact-fp32 MFMA GEMM ([33,768] x [2304,768]^T,
+    // a k-ordered fmaf chain); speed mode: the dedicated table kernel (W_ih row in registers, 56 -> ~10 us)
+    bool table_done = false;
+    if constexpr (sizeof(T) == 2) table_done = gru_table_fwd(st, pp(L.pho_emb), pp(L.gru_w_ih), pp(L.gru_b_ih), cfg.pho_vocab, H, wp<float>(pl.gru_table)) == RL_OK;
+    if (!table_done) {
       EpiParams<float> ep; ep.mode = EPI_STORE; ep.out = wp<float>(pl.gru_table); ep.ldo = 3 * H; ep.bias = pp(L.gru_b_ih);
       RL_TRY(gemm_nt<float>(st, pp(L.pho_emb), H, pp(L.gru_w_ih), H, cfg.pho_vocab, 3 * H, H, ep));
     }
@@ -996,9 +1000,12 @@ template <typename T> struct Engine : EngineBase {
       a.dgh = wp<T>(pl.gru_dgh); a.onehot = wp<T>(pl.gru_onehot);
       RL_TRY(gru_step_bwd<T>(st, a));
       { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = dtable; te.ldo = 3 * H; RL_TRY(gemm_tn<T>(st, a.onehot, 64, a.dgi, 3 * H, n, 64, 3 * H, te, nd)); }
-      RL_TRY(bias_grad<T>(st, a.dgh, 3 * H, n, 3 * H, gp(L.gru_b_hh), nd));
+      // d b_hh = column sums of dgh: rides along the W_hh weight-gradient GEMM of the step (fused ones-vector MFMA, TnEpi::colsum) -
+      // six column-reduction + fold launch pairs less; step 0 has no recurrent GEMM and keeps the reduction
+      if (t == 0) RL_TRY(bias_grad<T>(st, a.dgh, 3 * H, n, 3 * H, gp(L.gru_b_hh), nd));
       if (t > 0) {
-        { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(L.gru_w_hh); te.ldo = H; RL_TRY(gemm_tn<T>(st, a.dgh, 3 * H, hs_prev, H, n, 3 * H, H, te, nd)); }
+        { TnEpi te; te.slab = wp<float>(pl.sc[cs].tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.out = gp(L.gru_w_hh); te.ldo = H; te.colsum = gp(L.gru_b_hh);
+          RL_TRY(gemm_tn<T>(st, a.dgh, 3 * H, hs_prev, H, n, 3 * H, H, te, nd)); }
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = a.dh; ep.ldo = H; ep.accumulate = 1;
         RL_TRY(gemm_nt<T>(st, a.dgh, 3 * H, sp<T>(sh_gru_hhT), 3 * H, n, H, 3 * H, ep, nd));
       }

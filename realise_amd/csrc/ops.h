@@ -164,6 +164,8 @@ template <typename T> int gru_step_bwd(hipStream_t st, const GruStepArgs<T>& a);
 // len[t] = vlens[src[t]]; tokens stably sorted by decreasing length -> perm / lens_sorted; n_alive[k] = #{len > k}.
 int pho_prepare(hipStream_t st, const int64_t* src, int T_, const int64_t* table, const int32_t* vlens, int V, int Tw,
                 int64_t* pho_idx, int32_t* perm, int32_t* lens_sorted, int32_t* n_alive);
+// table[v][j] = b_ih[j] + emb[v, :] . w_ih[j, :]   (fp32; V x 3H from the 33 pinyin symbols)
+int gru_table_fwd(hipStream_t st, const float* emb, const float* w_ih, const float* b_ih, int V, int H, float* table);
 int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const float* emb, const float* w_ih, int V, int H,
                   float* d_emb, float* d_w_ih, float* d_b_ih);
 

@@ -194,34 +194,89 @@ template <typename T> int gru_step_bwd(hipStream_t st, const GruStepArgs<T>& a) 
 template int gru_step_bwd<bf16_t>(hipStream_t, const GruStepArgs<bf16_t>&);
 template int gru_step_bwd<float>(hipStream_t, const GruStepArgs<float>&);
 
-// dTable [V][3H] -> d b_ih, d W_ih [3H][H], d Emb [V][H]
+// The pinyin alphabet has 33 symbols, so the GRU's input projection W_ih x + b_ih is a [V <= 64][3H] table (models.py:818-826).
+// Forward, speed mode: one wave per output unit j keeps W_ih[j, :] in registers (H / 64 values per lane), and accumulates the V dot
+// products with the embedding rows (L1-resident, 100 KB) - W_ih is read once, 7 MB; the general MFMA GEMM ran the 33-row problem as
+// 18 workgroups of 128 x 128 tiles (56 us).
+template <int NK>
+__global__ void __launch_bounds__(256) gru_table_fwd_kernel(const float* __restrict__ emb, const float* __restrict__ w_ih, const float* __restrict__ b_ih,
+                                                            int V, int H, int J, float* __restrict__ table) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= J) return;
+  float w[NK];
+#pragma unroll
+  for (int i = 0; i < NK; ++i) { const int k = i * 64 + lane; w[i] = k < H ? w_ih[(int64_t)j * H + k] : 0.f; }
+  const float bias = b_ih[j];
+  for (int v = 0; v < V; ++v) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) { const int k = i * 64 + lane; s = fmaf(k < H ? emb[(int64_t)v * H + k] : 0.f, w[i], s); }
+    s = wave_sum(s);
+    if (lane == 0) table[(int64_t)v * J + j] = s + bias;
+  }
+}
+int gru_table_fwd(hipStream_t st, const float* emb, const float* w_ih, const float* b_ih, int V, int H, float* table) {
+  if (H > 1024 || V < 1) return RL_ERR_ARG;
+  const int J = 3 * H, NK = (H + 63) / 64;
+  const dim3 grid((J + 3) / 4), block(256);
+  if (NK <= 4) hipLaunchKernelGGL((gru_table_fwd_kernel<4>), grid, block, 0, st, emb, w_ih, b_ih, V, H, J, table);
+  else if (NK <= 8) hipLaunchKernelGGL((gru_table_fwd_kernel<8>), grid, block, 0, st, emb, w_ih, b_ih, V, H, J, table);
+  else if (NK <= 12) hipLaunchKernelGGL((gru_table_fwd_kernel<12>), grid, block, 0, st, emb, w_ih, b_ih, V, H, J, table);
+  else hipLaunchKernelGGL((gru_table_fwd_kernel<16>), grid, block, 0, st, emb, w_ih, b_ih, V, H, J, table);
+  return RL_LAUNCH_CHECK();
+}
+
+// dTable [V][3H] -> d b_ih, d W_ih [3H][H], d Emb [V][H].  Every element of d W_ih has ONE owner thread (plain add, no atomics: 1.8 M
+// atomics were the whole cost of this kernel); d Emb: a thread owns column k for ALL V rows over a chunk of 64 units, so W_ih is
+// read once (7 MB; it was read once per symbol, 33 x) and the chunks meet in V atomics per thread.
 __global__ void __launch_bounds__(256)
 gru_table_bwd_w_kernel(const float* __restrict__ dt, int ldt, const float* __restrict__ emb, int V, int H,
                        float* d_w_ih, float* d_b_ih) {                  // block per output unit j, thread per k
+  __shared__ float dcol[64];
   const int j = blockIdx.x;
-  float bsum = 0.f;
-  for (int v = 0; v < V; ++v) bsum += dt[(int64_t)v * ldt + j];
-  if (threadIdx.x == 0) atomicAdd(d_b_ih + j, bsum);
+  if (threadIdx.x < 64) dcol[threadIdx.x] = (int)threadIdx.x < V ? dt[(int64_t)threadIdx.x * ldt + j] : 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float bsum = 0.f;
+    for (int v = 0; v < V; ++v) bsum += dcol[v];
+    d_b_ih[j] += bsum;
+  }
   for (int k = threadIdx.x; k < H; k += 256) {
     float s = 0.f;
-    for (int v = 0; v < V; ++v) s += dt[(int64_t)v * ldt + j] * emb[(int64_t)v * H + k];
-    atomicAdd(d_w_ih + (int64_t)j * H + k, s);
+    for (int v = 0; v < V; ++v) s = fmaf(dcol[v], emb[(int64_t)v * H + k], s);
+    d_w_ih[(int64_t)j * H + k] += s;
   }
 }
+constexpr int GRU_TBE_CHUNK = 64, GRU_TBE_VMAX = 64;
 __global__ void __launch_bounds__(256)
 gru_table_bwd_e_kernel(const float* __restrict__ dt, int ldt, const float* __restrict__ w_ih, int V, int H, float* d_emb) {
-  const int v = blockIdx.y;                                              // grid (H/256, V, 3H/128)
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= H || v == 0) return;                                          // padding_idx = 0 row gets no gradient
-  float s = 0.f;
-  const int j0 = blockIdx.z * 128, j1 = min(3 * H, j0 + 128);
-  for (int j = j0; j < j1; ++j) s += dt[(int64_t)v * ldt + j] * w_ih[(int64_t)j * H + k];
-  atomicAdd(d_emb + (int64_t)v * H + k, s);
+  __shared__ float dts[GRU_TBE_VMAX][GRU_TBE_CHUNK];                      // this chunk's [V][64] slice of dTable
+  const int k = blockIdx.x * 256 + threadIdx.x;                           // grid (H / 256, 3H / 64)
+  const int j0 = blockIdx.y * GRU_TBE_CHUNK, nj = min(GRU_TBE_CHUNK, 3 * H - j0);
+  for (int e = threadIdx.x; e < V * GRU_TBE_CHUNK; e += 256) {
+    const int v = e / GRU_TBE_CHUNK, jj = e - v * GRU_TBE_CHUNK;
+    dts[v][jj] = jj < nj ? dt[(int64_t)v * ldt + j0 + jj] : 0.f;
+  }
+  __syncthreads();
+  if (k >= H) return;
+  float acc[GRU_TBE_VMAX];
+#pragma unroll
+  for (int v = 0; v < GRU_TBE_VMAX; ++v) acc[v] = 0.f;
+  for (int jj = 0; jj < nj; ++jj) {
+    const float w = w_ih[(int64_t)(j0 + jj) * H + k];
+#pragma unroll
+    for (int v = 0; v < GRU_TBE_VMAX; ++v) if (v < V) acc[v] = fmaf(dts[v][jj], w, acc[v]);
+  }
+#pragma unroll
+  for (int v = 1; v < GRU_TBE_VMAX; ++v)                                   // padding_idx = 0 row gets no gradient
+    if (v < V) atomicAdd(d_emb + (int64_t)v * H + k, acc[v]);
 }
 int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const float* emb, const float* w_ih, int V, int H,
                   float* d_emb, float* d_w_ih, float* d_b_ih) {
+  if (V > GRU_TBE_VMAX) return RL_ERR_ARG;
   hipLaunchKernelGGL(gru_table_bwd_w_kernel, dim3(3 * H), dim3(256), 0, st, dtable, ld_dtable, emb, V, H, d_w_ih, d_b_ih);
-  hipLaunchKernelGGL(gru_table_bwd_e_kernel, dim3((H + 255) / 256, V, (3 * H + 127) / 128), dim3(256), 0, st, dtable, ld_dtable, w_ih, V, H, d_emb);
+  hipLaunchKernelGGL(gru_table_bwd_e_kernel, dim3((H + 255) / 256, (3 * H + GRU_TBE_CHUNK - 1) / GRU_TBE_CHUNK), dim3(256), 0, st, dtable, ld_dtable, w_ih, V, H, d_emb);
   return RL_LAUNCH_CHECK();
 }
 
