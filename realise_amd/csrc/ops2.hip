@@ -208,12 +208,23 @@ __global__ void __launch_bounds__(256) gru_table_fwd_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < NK; ++i) { const int k = i * 64 + lane; w[i] = k < H ? w_ih[(int64_t)j * H + k] : 0.f; }
   const float bias = b_ih[j];
-  for (int v = 0; v < V; ++v) {
-    float s = 0.f;
+  // three symbols per trip: their 3 * NK embedding loads are in flight together (one symbol per trip paid an L2 latency per symbol: 35 us)
+  for (int v0 = 0; v0 < V; v0 += 3) {
+    float e[3][NK];
 #pragma unroll
-    for (int i = 0; i < NK; ++i) { const int k = i * 64 + lane; s = fmaf(k < H ? emb[(int64_t)v * H + k] : 0.f, w[i], s); }
-    s = wave_sum(s);
-    if (lane == 0) table[(int64_t)v * J + j] = s + bias;
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int i = 0; i < NK; ++i) { const int k = i * 64 + lane; e[u][i] = (k < H && v0 + u < V) ? emb[(int64_t)(v0 + u) * H + k] : 0.f; }
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int i = 0; i < NK; ++i) s[u] = fmaf(e[u][i], w[i], s[u]);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const float t = wave_sum(s[u]);
+      if (lane == 0 && v0 + u < V) table[(int64_t)(v0 + u) * J + j] = t + bias;
+    }
   }
 }
 int gru_table_fwd(hipStream_t st, const float* emb, const float* w_ih, const float* b_ih, int V, int H, float* table) {
@@ -248,35 +259,37 @@ gru_table_bwd_w_kernel(const float* __restrict__ dt, int ldt, const float* __res
     d_w_ih[(int64_t)j * H + k] += s;
   }
 }
-constexpr int GRU_TBE_CHUNK = 64, GRU_TBE_VMAX = 64;
+constexpr int GRU_TBE_CHUNK = 64, GRU_TBE_VG = 12;
 __global__ void __launch_bounds__(256)
 gru_table_bwd_e_kernel(const float* __restrict__ dt, int ldt, const float* __restrict__ w_ih, int V, int H, float* d_emb) {
-  __shared__ float dts[GRU_TBE_VMAX][GRU_TBE_CHUNK];                      // this chunk's [V][64] slice of dTable
-  const int k = blockIdx.x * 256 + threadIdx.x;                           // grid (H / 256, 3H / 64)
+  __shared__ float dts[GRU_TBE_VG][GRU_TBE_CHUNK];                        // this block's [12 symbols][64 units] slice of dTable
+  const int k = blockIdx.x * 256 + threadIdx.x;                           // grid (H / 256, 3H / 64, V / 12)
   const int j0 = blockIdx.y * GRU_TBE_CHUNK, nj = min(GRU_TBE_CHUNK, 3 * H - j0);
-  for (int e = threadIdx.x; e < V * GRU_TBE_CHUNK; e += 256) {
+  const int v0 = blockIdx.z * GRU_TBE_VG;
+  for (int e = threadIdx.x; e < GRU_TBE_VG * GRU_TBE_CHUNK; e += 256) {
     const int v = e / GRU_TBE_CHUNK, jj = e - v * GRU_TBE_CHUNK;
-    dts[v][jj] = jj < nj ? dt[(int64_t)v * ldt + j0 + jj] : 0.f;
+    dts[v][jj] = (jj < nj && v0 + v < V) ? dt[(int64_t)(v0 + v) * ldt + j0 + jj] : 0.f;
   }
   __syncthreads();
   if (k >= H) return;
-  float acc[GRU_TBE_VMAX];
+  float acc[GRU_TBE_VG];
 #pragma unroll
-  for (int v = 0; v < GRU_TBE_VMAX; ++v) acc[v] = 0.f;
+  for (int v = 0; v < GRU_TBE_VG; ++v) acc[v] = 0.f;
   for (int jj = 0; jj < nj; ++jj) {
     const float w = w_ih[(int64_t)(j0 + jj) * H + k];
 #pragma unroll
-    for (int v = 0; v < GRU_TBE_VMAX; ++v) if (v < V) acc[v] = fmaf(dts[v][jj], w, acc[v]);
+    for (int v = 0; v < GRU_TBE_VG; ++v) acc[v] = fmaf(dts[v][jj], w, acc[v]);
   }
 #pragma unroll
-  for (int v = 1; v < GRU_TBE_VMAX; ++v)                                   // padding_idx = 0 row gets no gradient
-    if (v < V) atomicAdd(d_emb + (int64_t)v * H + k, acc[v]);
+  for (int v = 0; v < GRU_TBE_VG; ++v)                                    // padding_idx = 0 row gets no gradient
+    if (v0 + v >= 1 && v0 + v < V) atomicAdd(d_emb + (int64_t)(v0 + v) * H + k, acc[v]);
 }
 int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const float* emb, const float* w_ih, int V, int H,
                   float* d_emb, float* d_w_ih, float* d_b_ih) {
-  if (V > GRU_TBE_VMAX) return RL_ERR_ARG;
+  if (V > 64) return RL_ERR_ARG;               // (gru_table_bwd_w_kernel keeps a symbol column of dTable in 64 LDS floats)
   hipLaunchKernelGGL(gru_table_bwd_w_kernel, dim3(3 * H), dim3(256), 0, st, dtable, ld_dtable, emb, V, H, d_w_ih, d_b_ih);
-  hipLaunchKernelGGL(gru_table_bwd_e_kernel, dim3((H + 255) / 256, (3 * H + GRU_TBE_CHUNK - 1) / GRU_TBE_CHUNK), dim3(256), 0, st, dtable, ld_dtable, w_ih, V, H, d_emb);
+  hipLaunchKernelGGL(gru_table_bwd_e_kernel, dim3((H + 255) / 256, (3 * H + GRU_TBE_CHUNK - 1) / GRU_TBE_CHUNK, (V + GRU_TBE_VG - 1) / GRU_TBE_VG), dim3(256), 0, st,
+                     dtable, ld_dtable, w_ih, V, H, d_emb);
   return RL_LAUNCH_CHECK();
 }
 
@@ -709,20 +722,14 @@ template int conv_weight_shadow<float>(hipStream_t, const float*, int, int, int,
 // dgrad[ci][slot][co0 ..].  (The element-per-thread form gathered every source float with a 36-byte stride: 167 us for 14 M weights.)
 // Padding entries (ci >= Ci of a Cpad-wide row, rows >= Ci of the dgrad copy) are never written: the shadow arena is zero-filled.
 constexpr int CSH_T = 32;
-template <typename T>
-__global__ void __launch_bounds__(256) conv_weight_shadow_multi_kernel(ConvShadowDescs ds) {
-  __shared__ float tile[CSH_T][CSH_T * 9 + 1];
-  int k = 0;
-#pragma unroll 1
-  for (int i = 1; i < ds.n; ++i) if ((int)blockIdx.x >= ds.d[i].block_begin) k = i;
-  const ConvShadowDesc& d = ds.d[k];
+// (KHW and, on full tiles, the tile edges are compile-time constants: the index arithmetic is shifts and multiply-shifts - with
+// run-time divisors the kernel was bound by its integer divisions, 123 us)
+template <typename T, int KHW, bool FULL>
+__device__ __forceinline__ void conv_shadow_tile(const ConvShadowDesc& d, float (*tile)[CSH_T * 9 + 1], int co0, int ci0, int nco_, int nci_) {
+  const int nco = FULL ? CSH_T : nco_, nci = FULL ? CSH_T : nci_, run = nci * KHW;
+  const int Co = d.Co, Ci = d.Ci, Cpad = d.Cpad;
   T* fwd = (T*)d.fwd;
   T* dgrad = (T*)d.dgrad;
-  const int Co = d.Co, Ci = d.Ci, KHW = d.KHW, Cpad = d.Cpad;
-  const int tiles_ci = (Ci + CSH_T - 1) / CSH_T;
-  const int b = (int)blockIdx.x - d.block_begin;
-  const int co0 = (b / tiles_ci) * CSH_T, ci0 = (b % tiles_ci) * CSH_T;
-  const int nco = min(CSH_T, Co - co0), nci = min(CSH_T, Ci - ci0), run = nci * KHW;
   for (int e = threadIdx.x; e < nco * run; e += 256) {                    // [co][ci][tap] block -> LDS, the same order
     const int c = e / run, r = e - c * run;
     tile[c][r] = d.w[((int64_t)(co0 + c) * Ci + ci0) * KHW + r];
@@ -740,12 +747,27 @@ __global__ void __launch_bounds__(256) conv_weight_shadow_multi_kernel(ConvShado
       dgrad[((int64_t)(ci0 + ci) * KHW + slot) * Co + co0 + c] = from_f<T>(tile[c][ci * KHW + src_tap]);
     }
 }
+template <typename T>
+__global__ void __launch_bounds__(256) conv_weight_shadow_multi_kernel(ConvShadowDescs ds) {
+  __shared__ float tile[CSH_T][CSH_T * 9 + 1];
+  int k = 0;
+#pragma unroll 1
+  for (int i = 1; i < ds.n; ++i) if ((int)blockIdx.x >= ds.d[i].block_begin) k = i;
+  const ConvShadowDesc& d = ds.d[k];
+  const int tiles_ci = (d.Ci + CSH_T - 1) / CSH_T;
+  const int b = (int)blockIdx.x - d.block_begin;
+  const int co0 = (b / tiles_ci) * CSH_T, ci0 = (b % tiles_ci) * CSH_T;
+  const int nco = min(CSH_T, d.Co - co0), nci = min(CSH_T, d.Ci - ci0);
+  const bool full = nco == CSH_T && nci == CSH_T;
+  if (d.KHW == 9) { if (full) conv_shadow_tile<T, 9, true>(d, tile, co0, ci0, nco, nci); else conv_shadow_tile<T, 9, false>(d, tile, co0, ci0, nco, nci); }
+  else if (d.KHW == 1) { if (full) conv_shadow_tile<T, 1, true>(d, tile, co0, ci0, nco, nci); else conv_shadow_tile<T, 1, false>(d, tile, co0, ci0, nco, nci); }
+}
 template <typename T> int conv_weight_shadow_multi(hipStream_t st, ConvShadowDescs& ds) {
   if (ds.n < 1 || ds.n > CONV_SHADOW_MAX) return RL_ERR_ARG;
   int blocks = 0;
   for (int k = 0; k < ds.n; ++k) {
     const ConvShadowDesc& d = ds.d[k];
-    if ((d.order.n != 0 && d.order.n != d.KHW) || d.KHW < 1 || d.KHW > 9 || d.Ci > d.Cpad || d.Ci > d.CiRows) return RL_ERR_ARG;
+    if ((d.order.n != 0 && d.order.n != d.KHW) || (d.KHW != 1 && d.KHW != 9) || d.Ci > d.Cpad || d.Ci > d.CiRows) return RL_ERR_ARG;
     ds.d[k].block_begin = blocks;
     blocks += ((d.Co + CSH_T - 1) / CSH_T) * ((d.Ci + CSH_T - 1) / CSH_T);
   }
