@@ -1036,6 +1036,7 @@ template <typename T> struct Engine : EngineBase {
         EpiParams<T> e2 = ep;
         e2.ln_gamma = gamma; e2.ln_beta = beta; e2.ln_eps = cfg.ln_eps; e2.ln_y = y; e2.ln_rstd = rstd;
         e2.ln_part = wp<float>(pl.ln_part[sid]);
+        if (g_ln_fuse == 2) e2.ln_flag = (int*)e2.ln_part;       // diagnostics: no cross-tile hand-off (see nt8_ln_epilogue)
         e2.ln_target = (ln_epoch[sid] % 0x7FFFFFF0) + 1;          // launch tag: never 0 (the zero-filled buffer), != the previous launch's
         e2.ln_timeout = id_flag != nullptr ? id_flag + 1 : nullptr;
         const int rc = gemm_nt8_ln(st, a, K, w, K, Tk, H, K, e2);

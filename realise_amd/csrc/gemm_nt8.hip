@@ -128,8 +128,13 @@ __device__ __forceinline__ void nt8_ln_epilogue(char* smem, const EpiParams<bf16
     }
     s_out = __uint_as_float((uint32_t)w0); m_out = __uint_as_float((uint32_t)w1);
   };
-  if (has_a) fetch(sq, s_a, pm2);
-  if (has_b) { float m_b; fetch(sq + 4, s_b, m_b); pm2 += m_b; }
+  if (ep.ln_flag != nullptr) {          // diagnostics (tools/repro_probe.py, LNDEBUG=1): no hand-off - every tile uses its own partial for all tiles
+    if (has_a) { s_a = sum; pm2 = m2; }   // (wrong statistics, but what is left is deterministic unless phases A / B / E race)
+    if (has_b) { s_b = sum; pm2 += m2; }
+  } else {
+    if (has_a) fetch(sq, s_a, pm2);
+    if (has_b) { float m_b; fetch(sq + 4, s_b, m_b); pm2 += m_b; }
+  }
   float tsum = s_a + s_b;
   tsum += __shfl_xor(tsum, 1, 64); tsum += __shfl_xor(tsum, 2, 64);
   const float mean = tsum / (float)N;
@@ -137,37 +142,26 @@ __device__ __forceinline__ void nt8_ln_epilogue(char* smem, const EpiParams<bf16
   float tot = pm2 + (has_a ? (float)BN * da * da : 0.f) + (has_b ? (float)BN * db * db : 0.f);      // sum_t [M2_t + n_t (mean_t - mean)^2]
   tot += __shfl_xor(tot, 1, 64); tot += __shfl_xor(tot, 2, 64);
   const float rstd = 1.0f / sqrtf(tot / (float)N + ep.ln_eps);
-  if (sq == 0) {
-    rowstat[srow * 2] = mean; rowstat[srow * 2 + 1] = rstd;
-    if (tn == 0 && ep.ln_rstd != nullptr) ep.ln_rstd[m0 + srow] = rstd;
-  }
-  __syncthreads();
-  // E. normalise this tile's columns: 8 per item, BN / 8 items per row, 16-byte stores of xhat (over the pre-LN buffer) and y
-  constexpr int IPR = BN / 8, ITEMS = BM * IPR, NIT = (ITEMS + 511) / 512;
+  if (sq == 0 && tn == 0 && ep.ln_rstd != nullptr) ep.ln_rstd[m0 + srow] = rstd;
+  // E. normalise this tile's columns from the registers of phase B: the four threads of a row own 48 consecutive columns each = 96
+  // contiguous bytes of xhat (written over the pre-LN buffer) and of y (16-byte stores; a row's four threads cover 384 contiguous bytes).
+  // (Round 4's first form re-read the tile from LDS by 8-column items after a third barrier; tools/repro_probe.py showed one
+  // aligned 16-lane group per ~2000 launches leaving that re-read with one wrong element - this form has no re-read to go wrong.)
+  (void)rowstat;
+  const int col0 = n0 + sq * QC;
+  const int64_t o = (int64_t)(m0 + srow) * ep.ldo + col0;
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int e = tid + 512 * it;
-    if (e < ITEMS) {
-      const int r = e / IPR, c8 = e - r * IPR;
-      const uint4 u = *(const uint4*)(smem + r * PITCH + c8 * 16);
-      floatx4 lo, hi;
-      unpack8(u, lo, hi);
-      const float mu = rowstat[r * 2], rs = rowstat[r * 2 + 1];
-      const int col = n0 + c8 * 8;
-      const floatx4 g0 = *(const floatx4*)(ep.ln_gamma + col), g1 = *(const floatx4*)(ep.ln_gamma + col + 4);
-      const floatx4 b0 = *(const floatx4*)(ep.ln_beta + col), b1 = *(const floatx4*)(ep.ln_beta + col + 4);
-      const floatx4 h0 = (lo - mu) * rs, h1 = (hi - mu) * rs;
-      const int64_t o = (int64_t)(m0 + r) * ep.ldo + col;
-      store8<T>(ep.out + o, h0, h1);
-      store8<T>(ep.ln_y + o, h0 * g0 + b0, h1 * g1 + b1);
-    }
+  for (int k = 0; k < QCH; ++k) {
+    const floatx4 g0 = *(const floatx4*)(ep.ln_gamma + col0 + 8 * k), g1 = *(const floatx4*)(ep.ln_gamma + col0 + 8 * k + 4);
+    const floatx4 b0 = *(const floatx4*)(ep.ln_beta + col0 + 8 * k), b1 = *(const floatx4*)(ep.ln_beta + col0 + 8 * k + 4);
+    floatx4 h0, h1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h0[e] = (xs[8 * k + e] - mean) * rstd; h1[e] = (xs[8 * k + 4 + e] - mean) * rstd; }
+    store8<T>(ep.out + o + 8 * k, h0, h1);
+    store8<T>(ep.ln_y + o + 8 * k, h0 * g0 + b0, h1 * g1 + b1);
   }
 }
 
-// ---- K6 epilogue: the gate math of one GRU time step on the recurrent projection this launch just computed (EpiParams::gru_*).
-// The wave's 32 x 96 tile holds [gh_r | gh_z | gh_n] of 32 hidden units (gate-interleaved B rows); it is staged 16 rows at a time
-// through the wave's LDS transpose tile, a lane then owns one row and 8 units.  gh goes through bf16 like the two-launch form
-// (GEMM stores bf16(acc + b_hh), gru_step_fwd reads it back), so both forms give the same bits.
 // Row state of the GRU epilogue, fetched at kernel start so that the dependent chain perm -> pho_idx -> table row (three global
 // latencies) and the h_prev rows run under the main loop instead of in front of every 16-row chunk of the epilogue.
 struct GruRows { int tok[2]; int gi_off[2]; bool ends[2]; uint4 hp[2]; };
