@@ -28,8 +28,8 @@ void realise_set_nt_variant(int v);
  * reduction tile in bf16, 2: whole 64-row tiles only - bit-identical to 0 -, 0 off); key 6 = K-ranges of the split-K classifier data
  * gradient (bf16; default 3, 0 / 1 = one launch over the whole K = 21184); key 7 = grouped weight gradients of the transformer layers on
  * the 4-wave 128 x 128 kernel, two workgroups per CU (0, default) or on the 8-wave 256 x 128 kernel, one tile per CU (1: measured, slower); key 8 = BertSelfOutput /
- * BertOutput as GEMM + LayerNorm launches (0, default) or as one launch (dense + bias + dropout + residual + LayerNorm: 1 - experimental:
- * a rare element-level mismatch under stream overlap is not root-caused, tools/repro_probe.py); key 9 = a GRU
+ * BertOutput as GEMM + LayerNorm launches (0, default) or as one launch (dense + bias + dropout + residual + LayerNorm: 1 - correct, measured
+ * 0.3 ms/step slower; 2 = the same without the cross-tile hand-off, diagnostics only: wrong statistics); key 9 = a GRU
  * time step as one launch (recurrent GEMM with the gate math in its epilogue: 1, default) or as GEMM + gate kernel (0) */
 void realise_set_engine(int key, int value);
 /* realise_gemm_tn_grouped over a list of live reduction blocks, as the engine's backward calls it: live[k] (device, ascending) = index

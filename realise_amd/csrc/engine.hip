@@ -57,11 +57,11 @@ void set_cls_compact(int on) { g_cls_compact = on; }
 // folded in plane order by the scatter that follows anyway.  0 = off (one launch over the whole K).
 // K4 (realise_set_engine key 8): BertSelfOutput / BertOutput as ONE launch - dense + bias + dropout + residual + LayerNorm (bf16,
 // the 128 x 192 two-per-CU kernel: the four column tiles of a row band exchange their LayerNorm partial sums through self-validating
-// device-scope slots).  0 (DEFAULT) = the GEMM and the LayerNorm as two launches.  The fused form is OFF: it passes every parity test
-// (full-size goldens included) and is perf-neutral in the step (17.50 vs 17.55 ms; alone 53 us against 41 + 9), but
-// tools/repro_probe.py - 500 identical forwards compared bit for bit - shows that about one launch in 2000 writes a handful of wrong
-// elements (one element of every 8-column item of ONE row, statistics correct) when it runs next to the other streams' kernels; not
-// root-caused in round 4, so it is not the product path.
+// device-scope slots).  0 (DEFAULT) = the GEMM and the LayerNorm as two launches; 1 = fused; 2 = fused without the hand-off (diagnostics).
+// Measured and left OFF (profiles/round4_ab.log, round4_repro_probe.log): the first form (normalise by re-reading the tile from LDS) was
+// perf-neutral (17.50 vs 17.55 ms; alone 53 us against 41 + 9) but one launch in ~2000 left that re-read with a wrong element in one
+// aligned 16-lane group; the shipped form normalises from registers - 1400 forwards bit-identical - but its 96-byte-per-thread store
+// pattern makes the step 0.3 ms SLOWER than the two launches (17.69 vs 17.40 ms).  Passes every parity test either way.
 static int g_ln_fuse = 0;
 void set_ln_fuse(int on) { g_ln_fuse = on; }
 // K6 (realise_set_engine key 9): a GRU time step t > 0 as ONE launch - the recurrent projection with the gate math in its epilogue

@@ -168,7 +168,7 @@ def test_nt_gemm_bounded_by_a_device_side_row_count(M, N, K, live, accumulate):
 
 @pytest.mark.parametrize("drop", [0.0, 0.1])
 def test_fused_dense_residual_layernorm_matches_the_two_launch_form(drop):
-    """(The fused form is an experimental knob, OFF by default - realise_amd/csrc/engine.hip g_ln_fuse.)
+    """(The fused form is a knob, OFF by default: correct, measured slower in the step - realise_amd/csrc/engine.hip g_ln_fuse.)
     K4 (BertSelfOutput / BertOutput, modeling_bert.py:273-277, 339-343) through the engine: with realise_set_engine(8, 1) every
     dense + dropout + residual + LayerNorm site is ONE launch (the column tiles of a row band exchange LayerNorm partials); the taps
     after one layer - attention output LayerNorm, layer output - and the logits must equal the two-launch form to bf16 rounding (the
