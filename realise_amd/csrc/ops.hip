@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
 // 8-column chunks (columns 8l.. and H/2 + 8l..: H / 16 active lanes - 48 of 64 at H = 768; the idle quarter costs nothing on a
 // memory-bound kernel): 16-byte accesses, 32 accumulator registers, and the next row's loads are issued before the current row is
 // processed (two register sets, statically named), so every wave always has a row in flight.
-struct LnRow16 { uint4 dy[2], xh[2]; };
+struct LnRow16 { uint4 dy[2], xh[2]; float rstd; };      // (rstd rides with the row's data loads: loaded after the reductions it was an exposed latency per row)
 template <bool DROP>
 __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
   // LDS: gamma [H] + one [4 waves][H] reduction buffer used twice (dgamma, then dbeta): 15 KB at H = 768.  The footprint matters
@@ -319,15 +319,32 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+  // Row liveness of every row this wave will visit, fetched ONCE up front (lane k holds the flag of the wave's k-th row): read inside
+  // the row loop, the flag byte was a dependent global load in front of every row's data loads - a memory latency per row on a
+  // wave that only visits four.
+  const int stride = gridDim.x * 4;
+  const int row_first = blockIdx.x * 4 + wave;
+  int live_reg = 1;
+  if (a.row_live != nullptr) {
+    const int64_t rk = (int64_t)row_first + (int64_t)lane * stride;
+    live_reg = rk < a.rows ? (int)a.row_live[rk] : 0;
+  }
+  auto is_live = [&](int row) -> bool {          // wave-uniform
+    if (a.row_live == nullptr) return true;
+    const int k = (row - row_first) / stride;
+    if (k < 64) return __builtin_amdgcn_readlane(live_reg, k) != 0;
+    return row < a.rows && a.row_live[row] != 0;
+  };
   auto load = [&](int row, LnRow16& r) {
-    const bool ok = active && row < a.rows && (a.row_live == nullptr || a.row_live[row] != 0);
+    const bool ok = active && row < a.rows && is_live(row);
     const uint32_t o0 = ((uint32_t)row * (uint32_t)H + (uint32_t)c0) * 2u, o1 = o0 + (uint32_t)H;      // rows * H * 2 < 4 GiB (launcher)
     const uint4 z = uint4{0u, 0u, 0u, 0u};
     r.dy[0] = ok ? *(const uint4*)((const char*)a.dy + o0) : z; r.dy[1] = ok ? *(const uint4*)((const char*)a.dy + o1) : z;
     r.xh[0] = ok ? *(const uint4*)((const char*)a.xhat + o0) : z; r.xh[1] = ok ? *(const uint4*)((const char*)a.xhat + o1) : z;
+    r.rstd = ok ? a.rstd[row] : 0.f;
   };
   auto process = [&](int row, LnRow16& r) {
-    if (a.row_live != nullptr && a.row_live[row] == 0) {      // a padding row (wave-uniform): dy = 0 -> dx = 0, no dgamma / dbeta term
+    if (!is_live(row)) {      // a padding row (wave-uniform): dy = 0 -> dx = 0, no dgamma / dbeta term
       if (active) {
         const uint4 z = uint4{0u, 0u, 0u, 0u};
 #pragma unroll
@@ -359,7 +376,7 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
     s1 = wave_sum(s1) / (float)H;
     s2 = wave_sum(s2) / (float)H;
     if (!active || row >= a.rows) return;
-    const float rstd = a.rstd[row];
+    const float rstd = r.rstd;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = i ? c1 : c0;
@@ -384,8 +401,7 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
       }
     }
   };
-  const int stride = gridDim.x * 4;
-  int row = blockIdx.x * 4 + wave;
+  int row = row_first;
   LnRow16 ra, rb;
   load(row, ra);
   while (row < a.rows) {
