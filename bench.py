@@ -287,6 +287,8 @@ def main():
                     help="hand the model the reference's host-built batch (pho_idx + the host list pho_lens: an argsort and an H2D copy per "
                          "forward) instead of the device-side build_batch (model.set_pinyin_table)")
     ap.add_argument("--bucket-cap-mb", type=float, default=None, help="N > 1: split every gradient bucket into collectives of at most this many MB")
+    ap.add_argument("--ddp-algo", default="allreduce", choices=["allreduce", "mesh"],
+                    help="N > 1 gradient exchange: the library's all-reduce per bucket, or the direct (mesh) all-to-all reduce-scatter + all-gather")
     ap.add_argument("--no-overlap", action="store_true", help="run the bert / pho / glyph branches serially on one stream")
     ap.add_argument("--knob", action="append", default=[], help="diagnostic knob as name:key=value, e.g. engine:0=1 (realise_set_engine(0, 1)); names: engine, ln, nt8p; "
                                                                     "opt:fused=0 steps with the arena-level AdamW kernels + full operand refresh")
@@ -360,7 +362,7 @@ def main():
     model.to(dev)
     model.train()
     model.assume_unit_loss_grad = True                      # plain loss.backward(), as in run.py:200
-    wrapped = DistributedDataParallel(model, grad_dtype=args.grad_dtype, bucket_cap_mb=args.bucket_cap_mb, collect_stats=True) if ddp else model
+    wrapped = DistributedDataParallel(model, grad_dtype=args.grad_dtype, bucket_cap_mb=args.bucket_cap_mb, collect_stats=True, algo=args.ddp_algo) if ddp else model
     no_decay = ["bias", "LayerNorm.weight"]                 # run.py:146-151
     groups = [{"params": [p for n, p in model.named_parameters() if p.requires_grad and not any(nd in n for nd in no_decay)],
                "weight_decay": 0.0},

@@ -17,9 +17,19 @@ class _GradSync:
     """grad_dtype "bf16": the buckets cross the wire as bf16 copies (half the bytes of the 679 MB fp32 exchange, SURVEY.md
     section 5); the fp32 arena receives the reduced values back.  Pre-division by the world size happens in fp32 first."""
 
-    def __init__(self, buckets, world, group, use_side_stream, grad_dtype="fp32", bucket_cap_mb=None, collect_stats=False):
+    def __init__(self, buckets, world, group, use_side_stream, grad_dtype="fp32", bucket_cap_mb=None, collect_stats=False, algo="allreduce"):
         if grad_dtype not in ("fp32", "bf16"):
             raise ValueError("grad_dtype must be 'fp32' or 'bf16'")
+        if algo not in ("allreduce", "mesh"):
+            raise ValueError("algo must be 'allreduce' or 'mesh'")
+        # algo "mesh" (SURVEY.md section 5): the exchange written for a fully connected xGMI node instead of left to the library's
+        # choice of ring - every rank sends shard j of the bucket straight to rank j (one all-to-all: W - 1 concurrent point-to-point
+        # transfers per rank, one per link), adds the W copies of ITS shard in rank order in fp32 (also when the wire is bf16: one
+        # rounding per element instead of W - 1), and an all-gather hands the reduced shards round.  2 (W - 1)/W of the bucket crosses
+        # each rank's links in total, 1/W of it per link.  Every rank ends with bit-identical gradients by construction (each element
+        # is reduced on exactly one rank).
+        self.algo = algo
+        self._mesh = {}
         self.buckets, self.world, self.group = buckets, world, group
         self.stream = torch.cuda.Stream() if use_side_stream else None
         self.wire = [torch.empty_like(b, dtype=torch.bfloat16) for b in buckets] if grad_dtype == "bf16" else None
@@ -43,11 +53,43 @@ class _GradSync:
         """bytes every rank hands to the collectives per step, bucket by bucket (communication order is the caller's)"""
         return [(self.wire[i] if self.wire is not None else b).numel() * (2 if self.wire is not None else 4) for i, b in enumerate(self.buckets)]
 
+    def _mesh_bufs(self, key, n, dtype, device):
+        b = self._mesh.get(key)
+        if b is None:
+            w = self.world
+            b = (torch.empty(n, dtype=dtype, device=device), torch.empty(n // w, dtype=torch.float32, device=device),
+                 torch.empty(n // w, dtype=dtype, device=device) if dtype != torch.float32 else None)
+            self._mesh[key] = b
+        return b
+
+    def _launch_mesh(self, i):
+        """direct reduce-scatter + all-gather of bucket i (pre-divided like the all-reduce forms: the shard sum IS the mean)"""
+        buf, w = self.buckets[i], self.world
+        if self.wire is not None:
+            torch.mul(buf, 1.0 / w, out=self.wire[i])
+            src = self.wire[i]
+        else:
+            buf.div_(w)
+            src = buf
+        for k, c in enumerate(self._chunks(src)):
+            n = c.numel() - c.numel() % w
+            if n:
+                recv, acc, narrow = self._mesh_bufs((i, k), n, c.dtype, c.device)
+                dist.all_to_all_single(recv, c[:n], group=self.group)              # row r of recv = rank r's copy of my shard
+                torch.sum(recv.view(w, n // w), dim=0, dtype=torch.float32, out=acc)
+                if narrow is not None:
+                    narrow.copy_(acc)
+                self.works.append((i, dist.all_gather_into_tensor(c[:n], acc if narrow is None else narrow, group=self.group, async_op=True)))
+            if n != c.numel():                                                      # fewer than W trailing elements
+                self.works.append((i, dist.all_reduce(c[n:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+
     def _launch(self, i):
         buf = self.buckets[i]
         if self.collect_stats:
             self._mark(i, 0)
-        if self.wire is not None:
+        if self.algo == "mesh":
+            self._launch_mesh(i)
+        elif self.wire is not None:
             # pre-divide and narrow in ONE pass over the bucket: SUM of bf16(g / W) == mean, overflow-safe
             torch.mul(buf, 1.0 / self.world, out=self.wire[i])
             for c in self._chunks(self.wire[i]):
@@ -90,7 +132,7 @@ class _GradSync:
         self.last_stats = {"comm_order": order, "bucket_wire_bytes": [wb[i] for i in order], "bucket_ready_ms": [round(x, 3) for x in ready],
                            "bucket_done_ms": [round(x, 3) for x in done], "backward_done_ms": round(bwd, 3),
                            "exposed_tail_ms": round(max(0.0, done[-1] - bwd), 3), "tail_bucket_wire_bytes": wb[order[-1]],
-                           "bucket_cap_mb": self.bucket_cap_mb, "collectives_per_step": sum(len(self._chunks(self.wire[i] if self.wire is not None else self.buckets[i])) for i in order)}
+                           "bucket_cap_mb": self.bucket_cap_mb, "algo": self.algo, "collectives_per_step": (2 if self.algo == "mesh" else 1) * sum(len(self._chunks(self.wire[i] if self.wire is not None else self.buckets[i])) for i in order)}
         return self.last_stats
 
     # ---- event-driven form: the engine runs the whole (branch-overlapped) backward in one call and records events[i] when
@@ -147,7 +189,7 @@ class DistributedDataParallel(nn.Module):
     """``DistributedDataParallel(model)`` for a RealiseModule (or any module exposing
     ``bucket_views()``, ``flat_parameters()``, ``flat_bn_buffers()`` and a ``grad_sync`` slot)."""
 
-    def __init__(self, module, process_group=None, broadcast_buffers=True, grad_dtype="fp32", bucket_cap_mb=None, collect_stats=False):
+    def __init__(self, module, process_group=None, broadcast_buffers=True, grad_dtype="fp32", bucket_cap_mb=None, collect_stats=False, algo="allreduce"):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -160,7 +202,7 @@ class DistributedDataParallel(nn.Module):
                 if a.numel() > 1:
                     dist.broadcast(a, src=0, group=process_group)
             module.mark_parameters_updated()
-        module.grad_sync = _GradSync(module.bucket_views(), self.world, process_group, flat.is_cuda, grad_dtype, bucket_cap_mb, collect_stats)
+        module.grad_sync = _GradSync(module.bucket_views(), self.world, process_group, flat.is_cuda, grad_dtype, bucket_cap_mb, collect_stats, algo)
 
     def forward(self, *args, **kw):
         if self.broadcast_buffers and self.module.training:

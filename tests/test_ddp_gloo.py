@@ -19,6 +19,62 @@ def _free_port():
     return p
 
 
+def _mesh_worker(rank, world, port, grad_dtype, cap_mb, q):
+    """the direct reduce-scatter + all-gather exchange against the analytic mean, on buckets whose lengths are NOT multiples of the
+    world size and whose contents differ per element and per rank (a shard routed to the wrong rank or row would show)"""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from realise_amd.ddp import _GradSync
+        sizes = [1000003, 7, 4099, world - 1 if world > 1 else 1, 65536]
+        base = [torch.arange(n, dtype=torch.float32).remainder_(251.0) - 100.0 for n in sizes]
+        buckets = [b * float(rank + 1) + float(i) for i, b in enumerate(base)]
+        sync = _GradSync(buckets, world, None, False, grad_dtype, cap_mb, False, "mesh")
+        ref = _GradSync([b.clone() for b in buckets], world, None, False, grad_dtype, cap_mb, False, "allreduce")
+        for s in (sync, ref):
+            for i in range(len(sizes)):
+                s.bucket_ready(i)
+            s.finish()
+        mean_scale = sum(r + 1 for r in range(world)) / world
+        for i, b in enumerate(base):
+            want = b * mean_scale + float(i)
+            got = sync.buckets[i]
+            if grad_dtype == "fp32":
+                assert torch.allclose(got, want, rtol=1e-6, atol=1e-5), (i, (got - want).abs().max())
+            else:
+                # bf16 wire: inputs and the gathered result are rounded to bf16; the shard sum itself runs in fp32, so the mesh form is
+                # at least as close to the exact mean as the bf16 all-reduce
+                assert torch.allclose(got, want, rtol=2e-2, atol=2e-2), (i, (got - want).abs().max())
+                assert (got - want).abs().max() <= (ref.buckets[i] - want).abs().max() + 1e-6
+        # every rank ends with the SAME bits
+        flat = torch.cat([b.reshape(-1) for b in sync.buckets])
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        assert all(torch.equal(g, gathered[0]) for g in gathered)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: %s\n%s" % (e, traceback.format_exc())))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,grad_dtype,cap_mb", [(2, "fp32", None), (3, "fp32", 0.5), (2, "bf16", None), (3, "bf16", 1.0)])
+def test_mesh_reduce_scatter_all_gather_gloo(world, grad_dtype, cap_mb):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mesh_worker, args=(r, world, port, grad_dtype, cap_mb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res
+
+
 def _worker(rank, world, port, model_type, q):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"

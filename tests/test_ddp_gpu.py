@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, signalled):
+def _worker(rank, world, port, q, signalled, algo="allreduce"):
     try:
         os.environ["REALISE_SIGNALLED_BACKWARD"] = signalled
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -45,7 +45,7 @@ def _worker(rank, world, port, q, signalled):
             ref += m.flat_gradients() / world
         m.zero_grad()
         m.flat_bn_buffers().copy_(bn0)
-        ddp = DistributedDataParallel(m)
+        ddp = DistributedDataParallel(m, algo=algo)
         loss = ddp(batches[rank])[0]
         loss.backward()
         torch.cuda.synchronize()
@@ -65,14 +65,14 @@ def _worker(rank, world, port, q, signalled):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("signalled", ["1", "0"])
-def test_two_ranks_one_gpu_bucketed_allreduce_matches_reference(signalled):
+@pytest.mark.parametrize("signalled,algo", [("1", "allreduce"), ("0", "allreduce"), ("1", "mesh")])
+def test_two_ranks_one_gpu_bucketed_allreduce_matches_reference(signalled, algo):
     """signalled = 1: one-call branch-overlapped backward + per-bucket 'final' events (the default under DDP);
-    0: one engine call per bucket"""
+    0: one engine call per bucket.  algo "mesh": the direct all-to-all reduce-scatter + all-gather exchange"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, signalled)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, signalled, algo)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=900) for _ in procs]
