@@ -312,16 +312,11 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
   const int H = a.H, HH = H >> 1;
   const bool active = lane * 16 < H;
   const int c0 = lane * 8, c1 = HH + lane * 8;
-  for (int c = threadIdx.x; c < H; c += 256) gsm[c] = a.gamma[c];
-  __syncthreads();
-  float dg[2][8], db[2][8];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
   // Row liveness of every row this wave will visit, fetched ONCE up front (lane k holds the flag of the wave's k-th row): read inside
   // the row loop, the flag byte was a dependent global load in front of every row's data loads - a memory latency per row on a
-  // wave that only visits four.
+  // wave that only visits four.  It is also the FIRST load of the kernel, ahead of gamma: the first rows' data loads wait on it, and
+  // they are issued before gamma goes to the LDS (gamma -> barrier -> flags -> rows was three memory latencies in a row on a
+  // workgroup that lives for about ten).
   const int stride = gridDim.x * 4;
   const int row_first = blockIdx.x * 4 + wave;
   int live_reg = 1;
@@ -329,6 +324,14 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
     const int64_t rk = (int64_t)row_first + (int64_t)lane * stride;
     live_reg = rk < a.rows ? (int)a.row_live[rk] : 0;
   }
+  float gpre[4];                       // H <= 1024: at most four gamma elements per thread
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = threadIdx.x + 256 * i; gpre[i] = c < H ? a.gamma[c] : 0.f; }
+  float dg[2][8], db[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
   auto is_live = [&](int row) -> bool {          // wave-uniform
     if (a.row_live == nullptr) return true;
     const int k = (row - row_first) / stride;
@@ -404,6 +407,9 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
   int row = row_first;
   LnRow16 ra, rb;
   load(row, ra);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = threadIdx.x + 256 * i; if (c < H) gsm[c] = gpre[i]; }
+  __syncthreads();
   while (row < a.rows) {
     load(row + stride, rb);
     process(row, ra);
