@@ -41,6 +41,12 @@ void realise_set_engine(int key, int value);
  * tile and nothing beyond it). */
 int realise_gemm_nt_rows(void* stream, int dtype, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
                          const realise_epilogue* ep, const int* rows_dev);
+/* realise_gemm_nt (bf16, K % 64 == 0, M % 16 == 0) over a device-side LIST of 16-row blocks, as a training step launches the layer GEMMs of
+ * a padded batch: live_list[k] = index of the k-th listed block (ascending), *live_count = how many.  Rows of listed blocks are computed
+ * exactly as the dense launch computes them (bit-identical) and read / written at their original positions; rows of the other blocks
+ * are neither read nor written. */
+int realise_gemm_nt_live(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                         const realise_epilogue* ep, const int* live_list, const int* live_count);
 /* Split-K form of the 8-wave NT GEMM as the classifier's data gradient uses it (bf16, K % 64 == 0): slab[s][m][n] (fp32, row pitch N,
  * plane pitch slab_stride floats) = A[m, K-range s] . B[n, K-range s]^T; rows at or beyond *m_dev (device, nullable) are not computed. */
 int realise_gemm_nt_splitk(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int nsplit,

@@ -140,7 +140,8 @@ template <typename T>
 __global__ void __launch_bounds__(256, 3)
 attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
                 const float* __restrict__ mask_add, T* __restrict__ ctx, int64_t ldc,
-                float* __restrict__ lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, int probe) {
+                float* __restrict__ lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, int probe,
+                const int* __restrict__ rlen) {
   typedef typename MmaOf<T>::type Mma;
   typedef AttnGeo<T> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,19 +154,23 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
   const T* K = k_ + (int64_t)b * S * ldq + h * HD;
   const T* V = v_ + (int64_t)b * S * ldq + h * HD;
 
+  // Sl (live-row steps): rows >= Sl of this sentence are padding.  As keys they are masked - exact-zero probabilities whatever their
+  // K rows hold, so the K / V rows beyond Sl are staged as zeros instead of being read -, as queries nobody reads their output: the
+  // 32-query blocks beyond Sl are skipped.
+  const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;
   const int q0 = wave * 32;
   typename Mma::Frag qf[2][G::KSTEPS];          // this wave's query fragments: fetched first, they land during the staging pass
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
-    for (int ks = 0; ks < G::KSTEPS; ++ks) qf[m][ks] = gfrag<T>(Q, ldq, q0 + 16 * m + l15, S, ks, g);
-  stage_tile<T>(K, ldq, S, Ks, tid, probe & 16);
-  stage_tile<T>(V, ldq, S, Vs, tid, probe & 16);
+    for (int ks = 0; ks < G::KSTEPS; ++ks) qf[m][ks] = gfrag<T>(Q, ldq, q0 + 16 * m + l15, Sl, ks, g);
+  stage_tile<T>(K, ldq, Sl, Ks, tid, probe & 16);
+  stage_tile<T>(V, ldq, Sl, Vs, tid, probe & 16);
   probe &= 15;
   if (tid < SMAX) madd[tid] = tid < S ? mask_add[b * S + tid] : 0.0f;
   stage_wait<T>();
   __syncthreads();
-  if (q0 >= S || probe == 1) return;
+  if (q0 >= Sl || probe == 1) return;
 
   floatx4 sc[8][2];
 #pragma unroll
@@ -174,7 +179,7 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
     for (int m = 0; m < 2; ++m) sc[n][m] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
-    if (16 * n < S) {
+    if (16 * n < Sl) {                   // (key tiles beyond Sl: scores stay 0 + mask -> probabilities exact zeros, as computed)
 #pragma unroll
       for (int ks = 0; ks < G::KSTEPS; ++ks) {
         const typename Mma::Frag kf = ktile_frag<T, HD>(Ks, 16 * n + l15, ks, g);
@@ -236,7 +241,7 @@ attn_fwd_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __r
     for (int dn = 0; dn < 4; ++dn) o[dn] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-      if (32 * kk < S) contract_seq32<T>(o, Vs, 32 * kk, sc[2 * kk][m], sc[2 * kk + 1][m], l15, g);
+      if (32 * kk < Sl) contract_seq32<T>(o, Vs, 32 * kk, sc[2 * kk][m], sc[2 * kk + 1][m], l15, g);
     const int q = q0 + 16 * m + l15;
     if (q < S) {
       T* dst = ctx + ((int64_t)b * S + q) * ldc + h * HD + 4 * g;
@@ -278,7 +283,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
   {  // rowdot[q] = sum_d dO[q,d] * O[q,d]  (two threads per row)
     const int row = tid >> 1, half = tid & 1;
     float acc = 0.f;
-    if (row < S) {
+    if (row < Sl) {                      // (a padding row's dO counts as zero whatever the buffer holds: its dot is 0)
       const T* po = O + (int64_t)row * H + half * 32;
       const T* pd = dO + (int64_t)row * H + half * 32;
 #pragma unroll
@@ -290,7 +295,7 @@ attn_bwd_dkv_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T*
     acc += __shfl_xor(acc, 1, 64);
     if (half == 0) {
       dot_s[row] = acc;
-      lse_s[row] = row < S ? lse[(int64_t)bh * S + row] : 0.0f;
+      lse_s[row] = row < Sl ? lse[(int64_t)bh * S + row] : 0.0f;       // (rows in [Sl, S): Q and dO are staged as zeros -> ds = p * 0; p only has to be finite)
       if (row < S) rowdot[(int64_t)bh * S + row] = acc;
     }
   }
@@ -426,12 +431,12 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int q = q0 + 16 * m + l15;
-    lq[m] = q < S ? lse[(int64_t)bh * S + q] : 0.0f;
-    dq_[m] = q < S ? rowdot[(int64_t)bh * S + q] : 0.0f;
+    lq[m] = q < Sl ? lse[(int64_t)bh * S + q] : 0.0f;          // (queries in [Sl, S) of a live block: zero operands -> ds = 0 -> dq = 0)
+    dq_[m] = q < Sl ? rowdot[(int64_t)bh * S + q] : 0.0f;
 #pragma unroll
     for (int ks = 0; ks < G::KSTEPS; ++ks) {
-      qf[m][ks] = gfrag<T>(Q, ldq, q, S, ks, g);
-      dof[m][ks] = gfrag<T>(dO, H, q, S, ks, g);
+      qf[m][ks] = gfrag<T>(Q, ldq, q, Sl, ks, g);
+      dof[m][ks] = gfrag<T>(dO, H, q, Sl, ks, g);
     }
   }
   floatx4 dq[2][4];
@@ -505,7 +510,7 @@ template <typename K> static void set_lds(K kernel, size_t bytes) {
 
 template <typename T>
 int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, const float* mask_add, T* ctx, int64_t ldc,
-             float* lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale) {
+             float* lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* rlen) {
   if (S < 1 || S > SMAX || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC)) return RL_ERR_ARG;
   typedef AttnGeo<T> G;
   const size_t lds = 2 * G::KT_BYTES + SMAX * sizeof(float);
@@ -513,7 +518,7 @@ int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
   if (!once) { set_lds(attn_fwd_kernel<T>, lds); once = true; }
   ProfScope ps(st, PK_ATTN_FWD, 4.0 * B * nh * (double)S * S * 64);
   RL_LAUNCH((attn_fwd_kernel<T>), dim3(B * nh), dim3(256), lds, st, q, k, v, ldq, mask_add, ctx, ldc, lse, B, nh, S,
-                     drop_seed, drop_thresh, drop_scale, g_attn_probe);
+                     drop_seed, drop_thresh, drop_scale, g_attn_probe, rlen);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -542,8 +547,8 @@ int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, co
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
-template int attn_fwd<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, int64_t, const float*, bf16_t*, int64_t, float*, int, int, int, uint32_t, uint32_t, float);
-template int attn_fwd<float>(hipStream_t, const float*, const float*, const float*, int64_t, const float*, float*, int64_t, float*, int, int, int, uint32_t, uint32_t, float);
+template int attn_fwd<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, int64_t, const float*, bf16_t*, int64_t, float*, int, int, int, uint32_t, uint32_t, float, const int*);
+template int attn_fwd<float>(hipStream_t, const float*, const float*, const float*, int64_t, const float*, float*, int64_t, float*, int, int, int, uint32_t, uint32_t, float, const int*);
 template int attn_bwd<bf16_t>(hipStream_t, const bf16_t*, const bf16_t*, const bf16_t*, int64_t, const float*, const bf16_t*, const bf16_t*, int64_t, const float*, float*, bf16_t*, bf16_t*, bf16_t*, int64_t, int, int, int, uint32_t, uint32_t, float, const int*);
 template int attn_bwd<float>(hipStream_t, const float*, const float*, const float*, int64_t, const float*, const float*, const float*, int64_t, const float*, float*, float*, float*, float*, int64_t, int, int, int, uint32_t, uint32_t, float, const int*);
 

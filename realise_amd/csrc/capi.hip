@@ -120,6 +120,13 @@ int realise_gemm_nt_rows(void* stream, int dtype, const void* A, int64_t lda, co
   if (dtype == REALISE_F32) return gemm_nt<float>(st, (const float*)A, lda, (const float*)B, ldb, M, N, K, to_epi<float>(ep), rows_dev);
   return RL_ERR_ARG;
 }
+int realise_gemm_nt_live(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                         const realise_epilogue* ep, const int* live_list, const int* live_count) {
+  if (!ep || !ep->out || !live_list || !live_count) return RL_ERR_ARG;
+  EpiParams<bf16_t> e = to_epi<bf16_t>(ep);
+  e.live_list = live_list; e.live_count = live_count;
+  return gemm_nt8_live((hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, e);
+}
 int realise_gemm_nt_splitk(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int nsplit,
                            float* slab, int64_t slab_stride, const int* m_dev) {
   return gemm_nt8_splitk((hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K, nsplit, slab, slab_stride, m_dev);
@@ -151,7 +158,7 @@ void realise_set_nt_group_m(int g) { set_nt8_group_m(g); }
 void realise_set_ln(int key, int value) {
   if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); else if (key == 2) set_bn_fast(value); else if (key == 3) set_bn_chunks(value); else if (key == 4) set_ce_fast(value);
 }
-void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); else if (key >= 1 && key <= 3) set_stream_priority(key - 1, value); else if (key == 4) set_cls_compact(value); else if (key == 5) set_skip_dead(value); else if (key == 6) set_cls_splitk(value); else if (key == 7) set_tn_group8(value); else if (key == 8) set_ln_fuse(value); else if (key == 9) set_gru_fuse(value); }
+void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); else if (key >= 1 && key <= 3) set_stream_priority(key - 1, value); else if (key == 4) set_cls_compact(value); else if (key == 5) set_skip_dead(value); else if (key == 6) set_cls_splitk(value); else if (key == 7) set_tn_group8(value); else if (key == 8) set_ln_fuse(value); else if (key == 9) set_gru_fuse(value); else if (key == 10) set_live_rows(value); }
 void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); else if (key == 2) set_nt8_single_round(value); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }

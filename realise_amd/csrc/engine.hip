@@ -70,6 +70,17 @@ static int g_gru_fuse = 1;
 void set_gru_fuse(int on) { g_gru_fuse = on; }
 static int g_cls_splitk = 3;
 void set_cls_splitk(int n) { g_cls_splitk = n < 0 ? 0 : (n > 4 ? 4 : n); }
+// Live rows (realise_set_engine key 10; bf16 training steps, needs the 16-row block lists of g_skip_dead = 1): the layer GEMMs of the
+// three transformer stacks - forward AND data gradients - run over the live 16-row blocks of the batch only (gemm_nt8_live), the
+// attention forward skips the query blocks and key rows beyond a sentence's last live row.  Rows after a sentence's last attended /
+// loss position never reach the loss: no query attends to them (additive -10000 mask: their probabilities are exact fp32 zeros), the
+// masked mean and the loss skip them, their gradient rows are exact zeros.  The reference computes them anyway; here their
+// activations are simply not produced (the workspace rows keep old, finite values - the workspace is zero-filled when a plan is
+// installed), the returned training logits of such rows are computed from those stale states and mean nothing, as the reference's
+// mean nothing.  The loss, every live row's activations and every gradient are bit-identical to the dense pass (same kernels, same
+// accumulation order per row; tests/test_round4_gpu.py).  Evaluation / inference forwards are always dense.
+static int g_live_rows = 1;
+void set_live_rows(int on) { g_live_rows = on; }
 static int g_stream_pri[3] = {0, 0, 0};
 void set_stream_priority(int which, int pri) { if (which >= 0 && which < 3) g_stream_pri[which] = pri < 0 ? -1 : (pri > 0 ? 1 : 0); }
 static hipError_t create_stream(hipStream_t* s, int which) {
@@ -220,6 +231,19 @@ template <typename T> struct Engine : EngineBase {
   const int* live_tiles() const { return dead_ok ? wp<int>(sizeof(T) == 2 ? (live16() ? pl.live_t16 : pl.live_t64) : pl.live_t32) : nullptr; }
   const int* live_tile_count() const { return dead_ok ? wp<int>(pl.live_n) + (sizeof(T) == 2 ? (live16() ? 2 : 0) : 1) : nullptr; }
   int live_list_rows() const { return sizeof(T) == 2 ? (live16() ? 16 : 64) : 32; }
+  bool rows_live = false;                  // the last forward ran its layer GEMMs over the live 16-row blocks (g_live_rows); the backward follows
+  // a layer GEMM over the token rows: the live blocks of a live-row step (no dense fall-back: the dead rows of its operands are stale)
+  int nt_rows(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep) {
+    if constexpr (sizeof(T) == 2) {
+      if (rows_live) {
+        EpiParams<T> e2 = ep;
+        e2.live_list = wp<int>(pl.live_t16); e2.live_count = wp<int>(pl.live_n) + 2;
+        return gemm_nt8_live(st, A, lda, B, ldb, M, N, K, e2);
+      }
+    }
+    return gemm_nt<T>(st, A, lda, B, ldb, M, N, K, ep);
+  }
+  const int* live_rlen() const { return dead_ok ? wp<int>(pl.live_rlen) : nullptr; }
   bool cls_compact = false;                // the last forward wrote compacted classifier-gradient rows (stage_head must match)
 
   template <typename U> U* wp(int64_t off) const { return (U*)(ws + off); }
@@ -614,20 +638,20 @@ template <typename T> struct Engine : EngineBase {
       LayerAct& t = a.layers[l];
       {  // fused QKV projection (modeling_bert.py:221,231-232)
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = wp<T>(t.qkv); ep.ldo = 3 * H; ep.bias = pp(o.qkv_b);
-        RL_TRY(gemm_nt<T>(st, x, H, sp<T>(w.qkv_w), H, Tk, 3 * H, H, ep));
+        RL_TRY(nt_rows(st, x, H, sp<T>(w.qkv_w), H, Tk, 3 * H, H, ep));
       }
       {
         const DropParams d = site(sid * 1000 + (int)l * 10 + 1, cfg.attn_dropout);
         const T* q = wp<T>(t.qkv);
         RL_TRY(attn_fwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), H, wp<float>(t.lse), B, nh, S,
-                           d.seed, d.thresh, d.scale));
+                           d.seed, d.thresh, d.scale, rows_live ? live_rlen() : nullptr));
       }
       // BertSelfOutput: dense -> dropout -> + input -> LayerNorm (modeling_bert.py:273-277)
       RL_TRY(dense_resid_ln(st, sid, wp<T>(t.ctx), H, sp<T>(w.ao_w), pp(o.ao_b), x, site(sid * 1000 + (int)l * 10 + 2, cfg.hidden_dropout),
                             pp(o.ao_ln_g), pp(o.ao_ln_b), wp<T>(t.s1), wp<float>(t.rstd1), wp<T>(t.y1)));
       {  // BertIntermediate (modeling_bert.py:326-329)
         EpiParams<T> ep; ep.mode = EPI_GELU; ep.out = wp<T>(t.post); ep.out2 = wp<T>(t.pre); ep.ldo = I; ep.bias = pp(o.in_b);
-        RL_TRY(gemm_nt<T>(st, wp<T>(t.y1), H, sp<T>(w.in_w), H, Tk, I, H, ep));
+        RL_TRY(nt_rows(st, wp<T>(t.y1), H, sp<T>(w.in_w), H, Tk, I, H, ep));
       }
       // BertOutput (modeling_bert.py:339-343)
       RL_TRY(dense_resid_ln(st, sid, wp<T>(t.post), I, sp<T>(w.out_w), pp(o.out_b), wp<T>(t.y1), site(sid * 1000 + (int)l * 10 + 3, cfg.hidden_dropout),
@@ -715,12 +739,12 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(wgrad(0, dso, H, wp<T>(t.post), I, H, I, gp(o.out_b), gp(o.out_w)));
       {  // d pre = (d s2' . W_out) * gelu'(pre)
         EpiParams<T> ep; ep.mode = EPI_GELU_BWD; ep.out = gD; ep.ldo = I; ep.aux = wp<T>(t.pre); ep.ldaux = I;
-        RL_TRY(gemm_nt<T>(st, dso, H, sp<T>(w.out_wT), H, Tk, I, H, ep));
+        RL_TRY(nt_rows(st, dso, H, sp<T>(w.out_wT), H, Tk, I, H, ep));
       }
       RL_TRY(wgrad(1, gD, I, wp<T>(t.y1), H, I, H, gp(o.in_b), gp(o.in_w)));
       {  // d y1 = d s2 + d pre . W_in
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gB; ep.ldo = H; ep.accumulate = 1;
-        RL_TRY(gemm_nt<T>(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
+        RL_TRY(nt_rows(st, gD, I, sp<T>(w.in_wT), I, Tk, H, I, ep));
       }
       {  // attention-output LayerNorm: gB = d y1 -> gA = d s1, gC2 = d(dense out)
         LnBwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.dy = gB; ln.xhat = wp<T>(t.s1); ln.rstd = wp<float>(t.rstd1); ln.row_live = live_rows();
@@ -732,7 +756,7 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(wgrad(2, dsa, H, wp<T>(t.ctx), H, H, H, gp(o.ao_b), gp(o.ao_w)));
       {  // d ctx = d s1' . W_ao
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gE; ep.ldo = H;
-        RL_TRY(gemm_nt<T>(st, dsa, H, sp<T>(w.ao_wT), H, Tk, H, H, ep));
+        RL_TRY(nt_rows(st, dsa, H, sp<T>(w.ao_wT), H, Tk, H, H, ep));
       }
       {
         const T* q = wp<T>(t.qkv);
@@ -750,7 +774,7 @@ template <typename T> struct Engine : EngineBase {
       }
       {  // d x_in = d s1 + d qkv . W_qkv
         EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H; ep.accumulate = 1;
-        RL_TRY(gemm_nt<T>(st, gF, 3 * H, sp<T>(w.qkv_wT), 3 * H, Tk, H, 3 * H, ep));
+        RL_TRY(nt_rows(st, gF, 3 * H, sp<T>(w.qkv_wT), 3 * H, Tk, H, 3 * H, ep));
       }
       if (ov) {
         if (hipEventRecord(ev_done[p], side) != hipSuccess) return RL_ERR_LAUNCH;
@@ -1032,7 +1056,7 @@ template <typename T> struct Engine : EngineBase {
     const int Tk = pl.B * pl.S;
     EpiParams<T> ep; ep.mode = EPI_DROP_RESID; ep.out = s_xhat; ep.ldo = H; ep.bias = bias; ep.aux = resid; ep.ldaux = H; set_drop(ep, drop);
     if constexpr (sizeof(T) == 2) {
-      if (g_ln_fuse && sid >= 0 && sid < 3 && pl.ln_part[sid] != 0 && (Tk % 128) == 0 && (H % 192) == 0) {
+      if (g_ln_fuse && !rows_live && sid >= 0 && sid < 3 && pl.ln_part[sid] != 0 && (Tk % 128) == 0 && (H % 192) == 0) {
         EpiParams<T> e2 = ep;
         e2.ln_gamma = gamma; e2.ln_beta = beta; e2.ln_eps = cfg.ln_eps; e2.ln_y = y; e2.ln_rstd = rstd;
         e2.ln_part = wp<float>(pl.ln_part[sid]);
@@ -1044,7 +1068,7 @@ template <typename T> struct Engine : EngineBase {
         if (rc != RL_ERR_ARG) return rc;
       }
     }
-    RL_TRY(gemm_nt<T>(st, a, K, w, K, Tk, H, K, ep));
+    RL_TRY(nt_rows(st, a, K, w, K, Tk, H, K, ep));
     LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = s_xhat; ln.gamma = gamma; ln.beta = beta;
     ln.eps = cfg.ln_eps; ln.y = y; ln.xhat = s_xhat; ln.rstd = rstd;
     return ln_fwd<T>(st, ln);
@@ -1053,8 +1077,10 @@ template <typename T> struct Engine : EngineBase {
     if (p.total > ws_bytes) { fprintf(stderr, "[realise_hip] workspace too small: need %lld have %lld\n", (long long)p.total, (long long)ws_bytes); return RL_ERR_ARG; }
     pl = p;
     ln_epoch[0] = ln_epoch[1] = ln_epoch[2] = 0;           // (the arrival counters are zero-filled below)
-    for (const auto& z : pl.zero_once)
-      if (hipMemsetAsync(ws + z.first, 0, (size_t)z.second, st) != hipSuccess) return RL_ERR_LAUNCH;
+    // The whole workspace starts at zero (once per plan): the self-cleaning accumulators need it (zero_once), and a live-row step
+    // leaves the activation rows of padding tokens as they are - what they hold must be finite wherever a later pass multiplies it by
+    // an exact zero (masked mean, gate gradients).
+    if (hipMemsetAsync(ws, 0, (size_t)pl.total, st) != hipSuccess) return RL_ERR_LAUNCH;
     return RL_OK;
   }
   int forward(hipStream_t st, const realise_batch& b) override {
@@ -1068,7 +1094,7 @@ template <typename T> struct Engine : EngineBase {
     last = b;
     last.Tp = Tp;
     have_glyph_fwd = false;            // the activations a glyph_backward would read are about to be overwritten
-    dead_ok = false; cls_compact = false;
+    dead_ok = false; rows_live = false; cls_compact = false;
     last_alive.assign(Tp, 0);
     // host counts (the reference's contract: pho_lens is a host list) or, after realise_build_pho, device counts: every
     // step is then launched over all B*S rows and bounded on the device
@@ -1085,6 +1111,13 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(sanitize_ids(st, b.pho_idx, (int64_t)Tk * Tp, cfg.pho_vocab, wp<int64_t>(pl.pho_clean), id_flag));
       last.pho_idx = wp<int64_t>(pl.pho_clean);
     }
+    // Rows after a sentence's last real / loss position are padding no query attends to and no loss term reads: every backward
+    // activation row there is an exact zero (the embedding scatter has relied on it since round 1).  The backward skips them
+    // (LayerNorm backward rows, blocks of the weight-gradient reductions), and a live-row step (g_live_rows) does not compute
+    // their forward activations in the transformer stacks either.
+    dead_ok = b.tgt_idx != nullptr && b.loss_masks != nullptr && g_skip_dead && b.want_dlogits && b.masks != nullptr && (Tk % 64) == 0;
+    if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_t16), wp<int>(pl.live_n), wp<int>(pl.live_rlen)));
+    rows_live = dead_ok && b.training && g_live_rows && live16() && (H % 64) == 0 && (I % 64) == 0 && (int64_t)Tk * I * 2 < 0xFFFFFF00ll;
     const T* bert_h = nullptr;
     const bool ovl = cfg.model_type == 1 && g_branch_overlap && branches_ok();
     hipStream_t s_pho = ovl ? bst[0] : st, s_glyph = ovl ? bst[1] : st;
@@ -1125,11 +1158,7 @@ template <typename T> struct Engine : EngineBase {
       // Backward of the classifier over the rows that enter the loss only (loss_masks: no [CLS] / [SEP] / padding - 60 % of the
       // rows of a SIGHAN-shaped batch): the gradient rows are written compacted, the classifier input is gathered to match; the
       // other rows' gradients are exact zeros in the dense form, so the weight / bias / data gradients are the same sums.
-      // Rows after a sentence's last real / loss position are padding no query attends to and no loss term reads: every backward
-      // activation row there is an exact zero (the embedding scatter has relied on it since round 1).  The backward skips them:
-      // LayerNorm backward rows, whole 64-row tiles of the weight-gradient reductions.
-      dead_ok = g_skip_dead && b.want_dlogits && b.masks != nullptr && (Tk % 64) == 0;
-      if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_t16), wp<int>(pl.live_n), wp<int>(pl.live_rlen)));
+      // (the padding rows the backward skips: row_liveness at the top of this call)
       cls_compact = g_cls_compact && b.want_dlogits && Tk <= 65536;
       CeCompact cc;
       if (cls_compact) { cc.act_idx = wp<int>(pl.cls_act); cc.inv = wp<int>(pl.cls_inv); cc.n_act = wp<int>(pl.cls_nact); }

@@ -43,6 +43,13 @@ template <typename T> struct EpiParams {
   float* slab = nullptr;
   int64_t slab_stride = 0;
   int ksplit = 1;
+  // Live-row form of the 8-wave 128 x 192 kernel (gemm_nt8_live): the M dimension is a device-side LIST of 16-row blocks (block ids
+  // ascending, *live_count of them: row_liveness's 16-row list of a padded batch).  Tile t works on the rows of blocks
+  // live_list[8t .. 8t + 7]: A rows are fetched from, and output rows (aux / out / out2, the dropout hash index) addressed at, their
+  // ORIGINAL positions; rows of unlisted blocks are neither read nor written, tiles at or beyond the count leave at once.  A listed
+  // row's result is bit-identical to the dense launch's (same kernel, same K order).
+  const int* live_list = nullptr;
+  const int* live_count = nullptr;
   // K4 (BertSelfOutput / BertOutput, modeling_bert.py:273-277, 339-343): EPI_DROP_RESID followed by the LayerNorm of the row in the SAME
   // launch (8-wave 128 x 192 kernel, M % 128 == 0, N % 192 == 0, N / 192 <= 8).  A row spans N / 192 column tiles = workgroups: each
   // leaves (sum, M2) of its 192 columns in ln_part[row][tile] as two self-validating 64-bit words {value, tag = ln_target} and polls
@@ -351,6 +358,7 @@ int gemm_nt8_gru(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, 
 // Split-K NT GEMM (bf16, K % 64 == 0, nsplit <= K / 64): slab[s][m][n] (fp32, row pitch N, plane pitch slab_stride) = A[m, Ks] . B[n, Ks]^T
 // over the s-th K-range; rows at or beyond *m_dev (nullable) are not computed.  For reductions long enough that the output tiles
 // alone do not fill the chip: the classifier's data gradient (K = 21184, N = 768, ~4.9 k live rows = 156 tiles of 128 x 192).
+int gemm_nt8_live(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
 int gemm_nt8_splitk(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, int nsplit,
                     float* slab, int64_t slab_stride, const int* m_dev);
 

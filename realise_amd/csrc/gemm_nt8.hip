@@ -236,7 +236,8 @@ __device__ __forceinline__ void nt8_gru_epilogue(char* smem, const EpiParams<bf1
 }
 
 // XEPI: 0 = the standard epilogues (EpiParams::mode), 1 = K4 (+ LayerNorm across the row band's tiles), 2 = K6 (GRU gate math on
-// gate-interleaved B rows) - separate instantiations, so that the special epilogues' registers are not the layer GEMMs' problem
+// gate-interleaved B rows), 3 = the standard epilogues over a LIST of live 16-row blocks (EpiParams::live_list) - separate
+// instantiations, so that the special forms' registers are not the layer GEMMs' problem
 template <typename C, int PROBE, bool KTAIL = false, int XEPI = 0>
 __global__ void __launch_bounds__(512, 2 * C::WGS)
 gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __restrict__ B_, int64_t ldb, int M, int N, int K, int tiles_n,
@@ -260,14 +261,27 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
     const int per = (((K + 63) >> 6) + ep.ksplit - 1) / ep.ksplit;
     const int k0 = split * per * 64;
     A += k0; B += k0; K = min(K - k0, per * 64);
+  } else if constexpr (XEPI == 3) {
+    tile = 0;
   } else {
     tile = xcd_remap(blockIdx.x, ntiles);
   }
   int tm, tn;
-  tile_coords(tile, tiles_n, ntiles, group_m, tm, tn);
+  int nlive = 0;                                            // XEPI 3: live 16-row blocks; tile row tm owns list entries tm * BM / 16 ..
+  if constexpr (XEPI == 3) {
+    // the launch is sized for every block being live; the XCD split is made over the tiles that exist (made over the nominal count,
+    // the surplus tiles - the tail of the logical order - would all sit on the last XCDs and leave them idle)
+    nlive = *ep.live_count;
+    const int ntl = ((nlive + C::BM / 16 - 1) / (C::BM / 16)) * tiles_n;
+    if ((int)blockIdx.x >= ntl) return;                     // (the whole workgroup leaves before any barrier)
+    tile = xcd_remap(blockIdx.x, ntl);
+    tile_coords(tile, tiles_n, ntl, group_m, tm, tn);
+  } else {
+    tile_coords(tile, tiles_n, ntiles, group_m, tm, tn);
+  }
   const int m0 = tm * C::BM, n0 = tn * C::BN;
   const int mlive = ep.m_dev != nullptr ? *ep.m_dev : M;
-  if (m0 >= mlive) return;                                  // device-side live-row count: the whole workgroup leaves before any barrier
+  if (XEPI != 3 && m0 >= mlive) return;                     // device-side live-row count: the whole workgroup leaves before any barrier
   const int mzero = ep.m_exact ? mlive : M;                 // A rows at or beyond it read as zeros
   GruRows gru_rows;
   if constexpr (XEPI == 2) nt8_gru_prefetch<C>(ep, gru_rows, mlive, N / 3, m0, tn, wave / C::WN, wave % C::WN, lane);
@@ -297,8 +311,17 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
         grow = gate * (N / 3) + tn * 64 + half * 32 + (cc & 31);
       }
     }
+    bool park = XEPI != 3 && !is_b && m0 + row + lrow >= mzero;
+    if constexpr (XEPI == 3) {
+      if (!is_b) {                                  // a piece is 8 rows of ONE 16-row block (row % 8 == 0): wave-uniform list entry
+        const int j = tm * (C::BM / 16) + (row >> 4);
+        const int blk = j < nlive ? ep.live_list[j] : -1;
+        grow = (blk < 0 ? 0 : blk) * 16 + ((row + lrow) & 15);
+        park = blk < 0;                             // list exhausted inside the last tile: zeros
+      }
+    }
     go[s] = (uint32_t)((int64_t)grow * (is_b ? ldb : lda) * 2 + kchunk_b);
-    if (!is_b && m0 + row + lrow >= mzero) go[s] = 0xFFFFFF00u;     // beyond num_records: the buffer range check returns zeros
+    if (park) go[s] = 0xFFFFFF00u;                  // beyond num_records: the buffer range check returns zeros
   }
   // Fetches are raw-buffer LDS-DMA loads: resource descriptor + K-tile byte offset in SGPRs, the per-lane row/chunk offset in
   // ONE 32-bit VGPR per piece - no vector ALU work per fetch (a 64-bit flat address costs two v_lshl_add_u64 each, which showed
@@ -431,6 +454,13 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   const int row_w = m0 + wm * C::RM, col_w = n0 + wn * C::RN;
 #pragma unroll
   for (int c = 0; c < C::RM / ER; ++c) {
+    int row_c = row_w + c * ER;
+    if constexpr (XEPI == 3) {                      // the chunk's 16 rows are one listed block (or lie beyond the list: nothing to store)
+      static_assert(XEPI != 3 || ER == 16, "live-row form: one 16-row block per epilogue chunk");
+      const int j = tm * (C::BM / 16) + ((wm * C::RM + c * ER) >> 4);
+      if (j >= nlive) continue;
+      row_c = ep.live_list[j] * 16;
+    }
 #pragma unroll
     for (int i = 0; i < ER / 16; ++i)
 #pragma unroll
@@ -440,13 +470,13 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
       const int e = lane + 64 * it, r = e / ITEMS, c8 = e - r * ITEMS;
       const floatx4 v0 = *(const floatx4*)(et + r * RS + c8 * 8), v1 = *(const floatx4*)(et + r * RS + c8 * 8 + 4);
       if (!KTAIL && ep.slab != nullptr) {
-        const int row = row_w + c * ER + r, col = col_w + c8 * 8;
+        const int row = row_c + r, col = col_w + c8 * 8;
         if (row < M && col < N) {
           float* o = ep.slab + (int64_t)split * ep.slab_stride + (int64_t)row * N + col;
           *(floatx4*)o = v0; *(floatx4*)(o + 4) = v1;
         }
       } else {
-        epilogue8<T>(ep, M, N, row_w + c * ER + r, col_w + c8 * 8, v0, v1);
+        epilogue8<T>(ep, M, N, row_c + r, col_w + c8 * 8, v0, v1);
       }
     }
   }
@@ -470,6 +500,7 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
   }
   ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
   if (ep.m_dev != nullptr) prof_set_exec(ep.m_dev, 2.0 * N * K, C::BM, M);      // tiles that start at or beyond the count leave at once
+  if constexpr (XEPI == 3) prof_set_exec(ep.live_count, 2.0 * N * K * 16.0, C::BM / 16, M / 16);      // (counted in 16-row blocks)
 #if RL_PROBES
   if constexpr (!KTAIL) {
     if (g_nt8_probe == 2) { RL_LAUNCH((gemm_nt8_kernel<C, 2>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
@@ -758,6 +789,14 @@ int gemm_nt8_gru(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, 
       ep.ln_y != nullptr || N != 3 * H || (H % 64) != 0 || (K % 64) != 0 || M < 1 || !nt8_supported(M, N, K, ep, lda, ldb))
     return RL_ERR_ARG;
   return launch_nt8_cfg<Cfg128x192q, false, 2>(st, A, lda, B, ldb, M, N, K, ep);
+}
+
+// the M dimension as a list of live 16-row blocks (EpiParams::live_list / live_count): see gemm.h
+int gemm_nt8_live(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep) {
+  if (ep.live_list == nullptr || ep.live_count == nullptr || ep.m_dev != nullptr || ep.slab != nullptr || ep.rm_hw_shift >= 0 ||
+      ep.ln_y != nullptr || ep.gru_table != nullptr || (K % 64) != 0 || (M % 16) != 0 || M < 16 || !nt8_supported(M, N, K, ep, lda, ldb))
+    return RL_ERR_ARG;
+  return launch_nt8_cfg<Cfg128x192q, false, 3>(st, A, lda, B, ldb, M, N, K, ep);
 }
 
 int gemm_nt8_splitk(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, int nsplit,

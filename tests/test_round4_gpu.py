@@ -248,3 +248,134 @@ def test_fused_gru_step_matches_the_two_launch_form(device_batch):
     for n in ("pho_gru.weight_hh_l0", "pho_gru.bias_hh_l0", "pho_gru.weight_ih_l0", "pho_embeddings.weight"):
         a, b = gradf[n].float(), gradu[n].float()
         assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-12, n      # (fp32 atomics in the table / bias sums)
+
+
+def _epilogue(mode, out, N, accumulate=0, out2=None, bias=None, aux=None, drop=0.0, seed=1234):
+    ep = _capi.Epilogue()
+    ep.mode, ep.accumulate, ep.out, ep.ldo, ep.alpha, ep.drop_scale = mode, accumulate, out.data_ptr(), N, 1.0, 1.0
+    if out2 is not None:
+        ep.out2 = out2.data_ptr()
+    if bias is not None:
+        ep.bias = bias.data_ptr()
+    if aux is not None:
+        ep.aux, ep.ldaux = aux.data_ptr(), N
+    if drop > 0.0:
+        ep.drop_seed, ep.drop_thresh, ep.drop_scale = seed, int(drop * 4294967296.0), 1.0 / (1.0 - drop)
+    return ep
+
+
+@pytest.mark.parametrize("M,N,K,mode,accumulate,blocks", [
+    (8192, 2304, 768, 0, 0, "ragged"),          # qkv
+    (8192, 3072, 768, 1, 0, "ragged"),          # FFN-up + GELU (+ the pre-activation copy)
+    (8192, 768, 3072, 2, 0, "ragged"),          # FFN-down + dropout + residual
+    (8192, 3072, 768, 4, 0, "ragged"),          # GELU' data gradient
+    (8192, 768, 2304, 0, 1, "ragged"),          # accumulating data gradient
+    (1024, 768, 768, 2, 0, "one"),              # a single listed block: one tile, seven of its eight block slots empty
+    (1024, 768, 768, 0, 1, "none"),             # an empty list: nothing is touched
+    (2048, 768, 768, 0, 0, "all"),              # every block listed: the dense product
+    (256, 192, 128, 0, 0, "odd")])              # small: 16 blocks, the odd ones
+def test_nt_gemm_over_a_list_of_live_row_blocks(M, N, K, mode, accumulate, blocks):
+    """gemm_nt8_live (EpiParams::live_list): the layer GEMMs of a live-row training step.  The rows of the listed 16-row blocks carry
+    EXACTLY the dense launch's values (same kernel, same accumulation order per row, the same dropout mask: the hash index is the
+    original row), read and written at their original positions; the other rows - whose A rows here are NaN, as stale as can be -
+    are neither read nor written."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(M + N + K + mode)
+    nb = M // 16
+    if blocks == "ragged":          # sentences of 128 rows = 8 blocks with a live prefix of 1 .. 8 blocks, as row_liveness lists them
+        rng = np.random.default_rng(M + mode)
+        live = np.concatenate([np.arange(s * 8, s * 8 + int(rng.integers(1, 9))) for s in range(nb // 8)])
+    elif blocks == "one":
+        live = np.array([37])
+    elif blocks == "none":
+        live = np.zeros(0, np.int64)
+    elif blocks == "all":
+        live = np.arange(nb)
+    else:
+        live = np.arange(1, nb, 2)
+    rows = torch.from_numpy((live[:, None] * 16 + np.arange(16)[None, :]).reshape(-1)).long().cuda()
+    dead = torch.ones(M, dtype=torch.bool, device="cuda")
+    dead[rows] = False
+    a = (torch.randn(M, K, generator=g) * 0.1).bfloat16().cuda()
+    b = (torch.randn(N, K, generator=g) * 0.1).bfloat16().cuda()
+    bias = (torch.randn(N, generator=g) * 0.1).float().cuda()
+    aux = torch.randn(M, N, generator=g).bfloat16().cuda() if mode in (2, 4) else None
+    old = torch.randn(M, N, generator=g).bfloat16().cuda()
+    drop = 0.1 if mode == 2 else 0.0
+
+    def run(live_form):
+        out = old.clone()
+        out2 = old.clone() if mode == 1 else None
+        x = a.clone()
+        if live_form:
+            x[dead] = float("nan")
+        ep = _epilogue(mode, out, N, accumulate, out2, bias if mode != 4 else None, aux, drop)
+        if live_form:
+            lst = torch.full((nb + 8,), -7, dtype=torch.int32, device="cuda")
+            lst[:len(live)] = torch.from_numpy(live.astype(np.int32)).cuda()
+            cnt = torch.tensor([len(live)], dtype=torch.int32, device="cuda")
+            _capi.check(lib.realise_gemm_nt_live(stream(), P(x), K, P(b), K, M, N, K, C.byref(ep), P(lst), P(cnt)), "gemm_nt_live")
+        else:
+            _capi.check(lib.realise_gemm_nt(stream(), _capi.BF16, P(x), K, P(b), K, M, N, K, C.byref(ep)), "gemm_nt")
+        torch.cuda.synchronize()
+        return out, out2
+
+    out_l, out2_l = run(True)
+    out_d, out2_d = run(False)
+    assert torch.isfinite(out_l.float()).all()
+    assert torch.equal(out_l[rows], out_d[rows])
+    assert torch.equal(out_l[dead], old[dead])
+    if mode == 1:
+        assert torch.equal(out2_l[rows], out2_d[rows]) and torch.equal(out2_l[dead], old[dead])
+    if len(live):             # and the dense launch is the product (loose: bf16 operands, fp32 accumulation)
+        ref = a[rows].float() @ b.float().t()
+        if mode == 0:
+            ref = ref + bias + (old[rows].float() if accumulate else 0.0)
+            assert (out_l[rows].float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("B,S,layers", [(8, 64, 2), (64, 128, 1)])
+def test_live_row_training_step_equals_the_dense_step(B, S, layers):
+    """realise_set_engine(10, 1) (default): a bf16 training step runs the layer GEMMs of the three transformer stacks - forward and data
+    gradients - and the attention forward over the live 16-row blocks only.  Against the dense step (10, 0) on the same module state, the
+    same batch and the same dropout masks: the loss is the same number, the logits of every row that precedes its sentence's last
+    attended / loss position are bit-identical, every gradient of an order-fixed kernel is bit-identical (the tables behind float
+    atomics agree to fp32 rounding, as between any two runs).  The dense rows a live-row step does not produce hold finite values."""
+    lib = _capi.load()
+    cfg = RealiseConfig(num_hidden_layers=layers, pho_layers=1, out_layers=1)
+    sd = init_state_dict_numpy(cfg, seed=11)
+    batch = synthetic_batch(B, S, seed=17)
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    masks = batch["masks"].bool() | batch["loss_masks"].bool()
+    last = torch.where(masks.any(1), S - masks.flip(1).float().argmax(1), torch.zeros(B, dtype=torch.long, device="cuda"))
+    live = (torch.arange(S, device="cuda")[None, :] < last[:, None])                     # [B, S]
+    assert 0.3 < live.float().mean().item() < 0.95
+
+    def step(on):
+        lib.realise_set_engine(10, on)
+        try:
+            m = build(cfg, sd, "bf16", train=True)
+            out = []
+            for _ in range(2):                       # two steps on one module: the second one runs on a workspace that holds stale rows
+                m.zero_grad()
+                loss, logits = m(batch)
+                loss.backward()
+                torch.cuda.synchronize()
+                out.append((float(loss.item()), logits.detach().clone(),
+                            {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+            return out
+        finally:
+            lib.realise_set_engine(10, 1)
+
+    dense, lived = step(0), step(1)
+    for (l0, z0, g0), (l1, z1, g1) in zip(dense, lived):
+        assert l0 == l1
+        assert torch.isfinite(z1.float()).all()
+        assert torch.equal(z0[live], z1[live])
+        moved = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+        print("tensors not bit-identical between the dense and the live-row step (%d of %d):" % (len(moved), len(g0)), moved)
+        for n in g0:
+            scale = g0[n].abs().max().item()
+            assert (g0[n] - g1[n]).abs().max().item() <= 5e-5 * scale + 1e-12, n
+        layer_weights = [n for n in g0 if ".layer." in n and n.endswith("weight") and "LayerNorm" not in n]
+        assert layer_weights and not [n for n in layer_weights if n in moved], [n for n in layer_weights if n in moved][:8]
