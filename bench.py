@@ -56,9 +56,10 @@ ROCPROF_STATS = os.path.join(ROOT, "profiles", "round4_final_kernel_stats.md")
 NT_KERNEL_PREFIXES = ["gemm_nt8_kernel", "gemm_nt8p_kernel", "gemm_nt_kernel<bf16_t, DenseLoader<bf16_t>", "gemm_nt_ln_kernel"]
 
 
-def fwd_flops_per_sentence(S, mean_len, resnet_frac=1.0):
-    """BASELINE.md section 4 accounting (dense forward FLOPs); resnet_frac scales the glyph-ResNet term (dedup)."""
-    per_tok = 19 * (14155776 + 2 * 2 * S * 768) + 32452608 + RESNET_FLOPS_PER_STACK * resnet_frac + 18432 + 7077888 * mean_len
+def fwd_flops_per_sentence(S, mean_len, resnet_frac=1.0, stack_frac=1.0):
+    """BASELINE.md section 4 accounting (dense forward FLOPs); resnet_frac scales the glyph-ResNet term (dedup), stack_frac the 19
+    transformer layers (live-row training steps: the rows of the live 16-row blocks over all rows)."""
+    per_tok = 19 * (14155776 + 2 * 2 * S * 768) * stack_frac + 32452608 + RESNET_FLOPS_PER_STACK * resnet_frac + 18432 + 7077888 * mean_len
     return per_tok * S
 
 
@@ -289,6 +290,10 @@ def main():
     ap.add_argument("--bucket-cap-mb", type=float, default=None, help="N > 1: split every gradient bucket into collectives of at most this many MB")
     ap.add_argument("--ddp-algo", default="allreduce", choices=["allreduce", "mesh"],
                     help="N > 1 gradient exchange: the library's all-reduce per bucket, or the direct (mesh) all-to-all reduce-scatter + all-gather")
+    ap.add_argument("--dense-rows", action="store_true",
+                    help="compute the transformer stacks over ALL rows of the padded batch, as the reference does (realise_set_engine(10, 0)); "
+                         "default: the live 16-row blocks only - loss, live-row logits and gradients bit-identical (tests/test_round4_gpu.py)")
+    ap.add_argument("--no-dense-rows-ab", action="store_true", help="skip the dense-rows sub-measurement of the default run")
     ap.add_argument("--no-overlap", action="store_true", help="run the bert / pho / glyph branches serially on one stream")
     ap.add_argument("--knob", action="append", default=[], help="diagnostic knob as name:key=value, e.g. engine:0=1 (realise_set_engine(0, 1)); names: engine, ln, nt8p; "
                                                                     "opt:fused=0 steps with the arena-level AdamW kernels + full operand refresh")
@@ -346,6 +351,8 @@ def main():
         else:
             getattr(lib, "realise_set_" + name)(int(k), int(v))
 
+    if args.dense_rows:
+        lib.realise_set_engine(10, 0)
     cfg = RealiseConfig()                                   # full model: 12 + 4 + 3 layers, 3 fonts, dropout 0.1
     model = SpellBertPho2ResArch3(cfg, compute_dtype=args.dtype, seed=0)
     if args.workload == "glyph256":
@@ -431,6 +438,30 @@ def main():
     T_ = B * args.seq
     uniq = int(model.tap("glyph.bounds").view(torch.int32)[0].item())
     live = uniq / float(T_)
+    # live rows of the padded batch: rows before a sentence's last attended / loss position, and the 16-row blocks that hold any
+    # (what row_liveness lists on the device; computed here from the same masks)
+    mk = ((batch["masks"] == 1) | (batch["loss_masks"] == 1)).cpu()
+    pos = torch.arange(1, args.seq + 1)[None, :]
+    last = (mk * pos).max(dim=1).values                                  # [B]: 1 + last flagged position
+    row_live = (torch.arange(args.seq)[None, :] < last[:, None]).reshape(-1)
+    rows_frac = float(row_live.float().mean())
+    blk16 = row_live[:T_ - T_ % 16].reshape(-1, 16).any(dim=1)
+    blocks16_frac = float(blk16.float().mean())
+    live_rows_on = (args.dtype == "bf16") and not args.dense_rows and (T_ % 64) == 0
+    stack_frac = blocks16_frac if live_rows_on else 1.0
+    dense_ab = None
+    if live_rows_on and world == 1 and not ddp and not args.no_dense_rows_ab:
+        # the same step with the transformer stacks over all rows (what the reference computes): realise_set_engine(10, 0)
+        lib.realise_set_engine(10, 0)
+        for _ in range(3):
+            step()
+        nd = max(5, min(args.steps, 20))
+        td = timed_loop(lambda i: step(), nd, world, dev)
+        lib.realise_set_engine(10, 1)
+        step()
+        dense_ab = {"value": round(B * nd / td, 2), "unit": "sentences/s", "ms_per_step": round(1e3 * td / nd, 3), "steps": nd,
+                    "note": "same model, batch and step with every row of the padded batch computed in the transformer stacks "
+                            "(bench.py --dense-rows / realise_set_engine(10, 0)): the reference's row count"}
 
     fwd = None
     if not args.no_forward:
@@ -495,7 +526,7 @@ def main():
     if rank == 0:
         sent = world * B * args.steps
         step_nom = 3.0 * fwd_flops_per_sentence(args.seq, mean_len) * B
-        step_exe = 3.0 * fwd_flops_per_sentence(args.seq, mean_len, live) * B
+        step_exe = 3.0 * fwd_flops_per_sentence(args.seq, mean_len, live, stack_frac) * B
         sec = elapsed / args.steps
         out = {
             "metric": "train sentences/sec (seq_len=128)",
@@ -515,10 +546,14 @@ def main():
                        "mean_pinyin_len": round(mean_len, 3), "mean_loss": round(final_loss, 4),
                        "branch_overlap": bool(overlap), "build_batch": "host" if args.host_batch else "device",
                        "optimizer": "FusedAdamW (%s)" % ("engine sweep: Linear weights + their bf16 operand copies in one pass" if opt.fused_operand_copies else "arena kernels + full operand refresh"),
-                       "distinct_glyphs": uniq, "tokens": T_},
+                       "distinct_glyphs": uniq, "tokens": T_,
+                       "padding_rows": ("transformer stacks over the live 16-row blocks only (%.3f of the rows; %.3f of the rows precede their "
+                                        "sentence's last attended / loss position): loss, live-row logits and gradients bit-identical to the "
+                                        "dense pass" % (blocks16_frac, rows_frac)) if live_rows_on else "all rows computed (dense, as the reference)"},
             "model_flops_per_step_per_gpu": {"nominal": step_nom, "executed": step_exe,
                                              "note": "nominal = dense reference graph (3 x forward); executed: the glyph ResNet runs on the "
-                                                     "%d distinct token ids of the %d tokens" % (uniq, T_)},
+                                                     "%d distinct token ids of the %d tokens%s" % (uniq, T_, ", the 19 transformer layers on the live "
+                                                     "16-row blocks (%.3f of the rows)" % blocks16_frac if live_rows_on else "")},
             "model_mfma_util": round(step_nom / sec / (PEAK_BF16_TFLOPS * 1e12), 4),
             "model_mfma_util_executed": round(step_exe / sec / (PEAK_BF16_TFLOPS * 1e12), 4),
         }
@@ -526,6 +561,8 @@ def main():
             out["forward"] = fwd
         if parity is not None:
             out["fp32_parity"] = parity
+        if dense_ab is not None:
+            out["dense_rows"] = dense_ab
         if ddp_stats is not None:
             out["ddp"] = ddp_stats
         for name in ("conv_nt", "conv_tn"):                  # launch records charge the dense row count: scale to the live rows
@@ -538,9 +575,13 @@ def main():
             f = fams["gemm_nt"]
             traffic, tnote = pmc_traffic_per_launch(NT_KERNEL_PREFIXES)
             out["roofline"] = {"bound": "mfma",
-                               "kernel": "dense NT GEMM family: gemm_nt8p_kernel<256x192> (persistent 8-wave ping-pong: qkv, FFN-up, FFN-down "
-                                         "dgrad, classifier) + gemm_nt8_kernel<128x192, two per CU> (N = 768 outputs) + "
-                                         "gemm_nt_kernel<bf16, DenseLoader> (GRU steps), v_mfma_f32_16x16x32_bf16",
+                               "kernel": ("dense NT GEMM family: gemm_nt8_kernel<128x192, two per CU, live-row form> (the layer GEMMs of the three "
+                                          "transformer stacks, forward and data gradients, over the live 16-row blocks) + gemm_nt8p_kernel<256x192> "
+                                          "(persistent 8-wave ping-pong: classifier) + gemm_nt8_kernel<128x192> (classifier data gradient, GRU steps), "
+                                          "v_mfma_f32_16x16x32_bf16") if live_rows_on else
+                                         ("dense NT GEMM family: gemm_nt8p_kernel<256x192> (persistent 8-wave ping-pong: qkv, FFN-up, FFN-down "
+                                          "dgrad, classifier) + gemm_nt8_kernel<128x192, two per CU> (N = 768 outputs) + "
+                                          "gemm_nt_kernel<bf16, DenseLoader> (GRU steps), v_mfma_f32_16x16x32_bf16"),
                                "achieved": round(f["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(f["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tnote,
                                "achieved_nominal": round(f["tflops_nominal"], 2), "frac_nominal": round(f["tflops_nominal"] / PEAK_BF16_TFLOPS, 4),

@@ -480,7 +480,13 @@ def test_full_size_config2_properties_bf16():
         lib.realise_set_glyph_dedup(1)
     (l1, lg1, g1), (l0, lg0, g0) = res[1], res[0]
     assert np.isfinite(l1) and abs(l1 - l0) < 2e-3 * abs(l0)
-    assert (lg1 - lg0).abs().max().item() < 6e-2
+    # the logits that mean something: rows before their sentence's last attended / loss position (a bf16 training step does not compute
+    # the transformer stacks on the padding rows behind it - realise_set_engine(10, .) - as nothing reads them; they stay finite)
+    flagged = (batch["masks"] == 1) | (batch["loss_masks"] == 1)
+    last = (flagged * torch.arange(1, 129)[None, :]).max(dim=1).values
+    live = (torch.arange(128)[None, :] < last[:, None]).to(lg1.device)
+    assert torch.isfinite(lg1).all() and torch.isfinite(lg0).all()
+    assert (lg1 - lg0)[live].abs().max().item() < 6e-2
     assert torch.isfinite(g1).all() and abs(g1.norm().item() - g0.norm().item()) < 2e-2 * g0.norm().item()
     rel = ((g1 - g0).norm() / g0.norm()).item()
     assert rel < 5e-2, rel
@@ -495,7 +501,7 @@ def test_full_size_config2_properties_bf16():
     m.zero_grad()
     lp, lgp = m(pb)
     assert abs(lp.item() - l1) < 2e-3 * abs(l1)
-    assert (lgp.detach().float() - lg1[perm]).abs().max().item() < 6e-2
+    assert (lgp.detach().float() - lg1[perm])[live[perm]].abs().max().item() < 6e-2
     # (5)
     lp.backward()
     before = m.flat_parameters().clone()

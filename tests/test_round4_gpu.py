@@ -181,6 +181,7 @@ def test_fused_dense_residual_layernorm_matches_the_two_launch_form(drop):
 
     def run(fuse):
         lib.realise_set_engine(8, fuse)
+        lib.realise_set_engine(10, 0)             # (the fused form is a dense-row launch: a live-row step keeps the two launches)
         try:
             m = build(cfg, sd, "bf16", train=True)
             loss, logits = m(batch)
@@ -192,6 +193,7 @@ def test_fused_dense_residual_layernorm_matches_the_two_launch_form(drop):
             return float(loss.item()), logits.float().clone(), taps, grads
         finally:
             lib.realise_set_engine(8, 0)
+            lib.realise_set_engine(10, 1)
 
     lf, logf, tf, gf = run(1)
     lu, logu, tu, gu = run(0)

@@ -5,7 +5,7 @@ R=$(pwd); TAG=${1:-r2}; shift
 mkdir -p $R/gpurun_out/prof_$TAG
 export PYTHONDONTWRITEBYTECODE=1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o bench -- python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-fp32-parity "$@" > $R/gpurun_out/prof_$TAG/bench.json 2> $R/gpurun_out/prof_$TAG/bench.err
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG -o bench -- python $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-profile --no-fp32-parity --no-dense-rows-ab "$@" > $R/gpurun_out/prof_$TAG/bench.json 2> $R/gpurun_out/prof_$TAG/bench.err
 echo "rocprof exit $?"; cat $R/gpurun_out/prof_$TAG/bench.json | cut -c1-300
 cd $R
 db=$(find gpurun_out/prof_$TAG -name "*.db" | head -1)
