@@ -30,7 +30,10 @@ void realise_set_nt_variant(int v);
  * the 4-wave 128 x 128 kernel, two workgroups per CU (0, default) or on the 8-wave 256 x 128 kernel, one tile per CU (1: measured, slower); key 8 = BertSelfOutput /
  * BertOutput as GEMM + LayerNorm launches (0, default) or as one launch (dense + bias + dropout + residual + LayerNorm: 1 - correct, measured
  * 0.3 ms/step slower; 2 = the same without the cross-tile hand-off, diagnostics only: wrong statistics); key 9 = a GRU
- * time step as one launch (recurrent GEMM with the gate math in its epilogue: 1, default) or as GEMM + gate kernel (0) */
+ * time step as one launch (recurrent GEMM with the gate math in its epilogue: 1, default) or as GEMM + gate kernel (0); key 10 = bf16
+ * training steps run the layer GEMMs of the transformer stacks (forward and data gradients) and the attention forward over the live
+ * 16-row blocks of the padded batch only (1, default: loss, live-row logits and gradients bit-identical to the dense step; the rows
+ * behind a sentence's last attended / loss position keep stale activations) or over all rows (0) */
 void realise_set_engine(int key, int value);
 /* realise_gemm_tn_grouped over a list of live reduction blocks, as the engine's backward calls it: live[k] (device, ascending) = index
  * of the k-th block of `list_rows` rows that holds anything but exact zeros in the A operands, *n_live (device) = how many; the other
