@@ -232,7 +232,11 @@ typedef struct {
   const int32_t* pho_lens_sorted; /* [B*S] (device) */
   const int32_t* n_alive;     /* HOST array [Tp]: #sequences with length > t; NULL when n_alive_dev is given */
   float* loss_out;            /* 1 float (device), nullable when tgt_idx is null */
-  void* logits_out;           /* [B*S, vocab] in `dtype` (device) */
+  void* logits_out;           /* [B*S, vocab] in `dtype` (device).  A bf16 TRAINING call with tgt_idx, loss_masks, masks and want_dlogits set
+                               * (B*S % 64 == 0) computes the transformer stacks only on the rows that precede a sentence's last position with
+                               * masks == 1 or loss_masks == 1: the loss, those rows' logits and every gradient equal the dense computation bit
+                               * for bit; the logits rows behind that position are finite and meaningless (the reference never reads them:
+                               * src/run.py:200, :262-270).  realise_set_engine(10, 0) (include/realise_hip_debug.h) computes every row. */
   const int32_t* n_alive_dev; /* DEVICE array [Tp] written by realise_build_pho (used when n_alive == NULL) */
 } realise_batch;
 
