@@ -1,5 +1,6 @@
 """forward reproducibility at full size: N training-mode forwards of one batch (no dropout), each compared bit for bit with the first.
-Every forward kernel is order-fixed, so ANY difference is a race / uninitialised read.  KNOBS as in tools/perm_probe.py."""
+Every forward kernel is order-fixed, so ANY difference is a race / uninitialised read.  KNOBS as in tools/perm_probe.py.
+GRAD=1: the forwards run with gradients enabled - the form a training step calls, i.e. the live-row path (realise_set_engine(10, .))."""
 import os
 import sys
 
@@ -22,11 +23,11 @@ m = SpellBertPho2ResArch3(cfg, compute_dtype="bf16", seed=3).to("cuda").train()
 batch = synthetic_batch(64, 128, seed=77)
 taps = ["bert.emb", "bert.layer.0.qkv", "bert.layer.0.ctx", "bert.layer.0.attn_out", "bert.layer.0.inter", "bert.layer.0.out", "bert.layer.11.out", "pho_gru", "pho_model.layer.3.out", "res_h", "fused", "output_block.layer.2.out"]
 ref, bad = None, {}
-with torch.no_grad():
+with torch.set_grad_enabled(os.environ.get("GRAD", "0") == "1"):
     for it in range(N):
         loss, logits = m(batch)
         torch.cuda.synchronize()
-        cur = {"logits": logits.clone()}
+        cur = {"logits": logits.detach().clone()}
         for t in taps:
             cur[t] = m.tap(t).clone()
         if ref is None:
@@ -46,5 +47,5 @@ try:
     flag = "flags clear"
 except Exception as e:      # noqa: BLE001
     flag = "FLAG: %s" % type(e).__name__
-print("KNOBS [%s] %s, %d forwards: %s" % (os.environ.get("KNOBS", ""), flag, N,
+print("KNOBS [%s] GRAD=%s %s, %d forwards: %s" % (os.environ.get("KNOBS", ""), os.environ.get("GRAD", "0"), flag, N,
                                       "all identical" if not bad else "; ".join("%s: %d x (max %.4f)" % (k, len(v), max(x[1] for x in v)) for k, v in bad.items())))
