@@ -422,9 +422,12 @@ def test_live_row_training_trajectory_follows_the_dense_one():
     ll, el, zl = run(1)
     ld, ed, zd = run(0)
     assert all(np.isfinite(x) for x in ll + ld)
+    print("live vs dense trajectory: max |d loss| %.2e (rel %.2e), eval loss %.5f vs %.5f" %
+          (max(abs(a - b) for a, b in zip(ll, ld)), max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(ll, ld)), el, ed))
     assert ll[0] == ld[0]                                     # the first step is the same computation
     for a, b in zip(ll, ld):
         assert abs(a - b) <= 5e-3 * max(1.0, abs(b)), (ll, ld)
     assert abs(el - ed) <= 5e-3 * max(1.0, abs(ed))
     mk = (batches[0]["masks"] == 1)
+    print("eval logits on attended rows: max |d| %.3f mean %.2e" % ((zl - zd)[mk].abs().max().item(), (zl - zd)[mk].abs().mean().item()))
     assert (zl - zd)[mk].abs().max().item() < 0.5 and (zl - zd)[mk].abs().mean().item() < 5e-2      # (bf16 logits after ten optimizer steps that differ in last bits)
