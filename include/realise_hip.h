@@ -236,7 +236,7 @@ typedef struct {
                                * (B*S % 64 == 0) computes the transformer stacks only on the rows that precede a sentence's last position with
                                * masks == 1 or loss_masks == 1: the loss, those rows' logits and every gradient equal the dense computation bit
                                * for bit; the logits rows behind that position are finite and meaningless (the reference never reads them:
-                               * src/run.py:200, :262-270).  realise_set_engine(10, 0) (include/realise_hip_debug.h) computes every row. */
+                               * src/run.py:200, :262-270).  Engine knob 10 = 0 (the setter is declared in include/realise_hip_debug.h) computes every row. */
   const int32_t* n_alive_dev; /* DEVICE array [Tp] written by realise_build_pho (used when n_alive == NULL) */
 } realise_batch;
 
