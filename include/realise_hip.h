@@ -217,6 +217,11 @@ void realise_engine_set_grads_fresh(realise_engine* e, int fresh);
  * launch gave up waiting for the other column tiles of its rows (never observed; the wait is bounded so that a scheduling surprise
  * cannot hang the device - the step's results are meaningless then). */
 void realise_engine_set_id_flag(realise_engine* e, int32_t* flag);
+/* The gradient arriving at the loss (`grad_output` of loss.backward(): 1, or 1 / gradient_accumulation_steps, src/run.py:197-200) as
+ * a DEVICE fp32 scalar that realise_engine_backward reads when it runs (NULL = 1, the default).  It scales the three gradients that
+ * leave the classifier head inside the kernels that store them; the host never reads it and the cross-entropy gradient rows are
+ * not touched.  The pointer must stay valid until the backward's kernels have run; it stays installed until changed. */
+void realise_engine_set_loss_grad(realise_engine* e, const float* grad_dev);
 
 typedef struct {
   int32_t B, S, Tp;

@@ -60,11 +60,17 @@ int realise_gemm_tn_grouped_live(void* stream, int dtype, int n, const realise_t
  * [dgamma | dbeta] records in `slots` (8 MiB scratch) folded in a fixed order.  tools/ln_probe.py times it. */
 int realise_layernorm_bwd_ex(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,
                              uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* dgamma, float* dbeta, float* slots, int rows, int H);
+/* the same with the row-liveness bytes of a padded batch (row_live[r] == 0: dy[r] is an exact zero - the row is not read, its outputs are zeros) */
+int realise_layernorm_bwd_live(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,
+                               uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* dgamma, float* dbeta, float* slots,
+                               const uint8_t* row_live, int rows, int H);
 /* LayerNorm kernels: key 0 = bf16 fast path (half a wave per row, 16-byte accesses; default 1), key 1 = workgroups of its backward (default 512);
  * BatchNorm kernels: key 2 = bf16 fast paths (1, default: 16-byte accesses, paired bn2 + shortcut backward, one-pass training
  * statistics; 3: the same with two-pass statistics; 0: generic kernels), key 3 = row chunks of their
  * column reductions (default 1024) ; key 4 = bf16 masked cross-entropy with the logits row read once into registers
- * (1, default) or the generic three-walk kernel (0) */
+ * (1, default) or the generic three-walk kernel (0); key 5 = round-5 LayerNorm kernels (1, default: row reductions through DPP,
+ * backward with four rows of a wave in flight, no barrier before the first row, one-barrier epilogue, 256 workgroups; 0: the round-4
+ * kernels) - key 1 sets the workgroups of whichever backward is active */
 void realise_set_ln(int key, int value);
 /* BatchNorm training statistics and backward exactly as the engine's glyph branch runs them (bf16, NHWC viewed as [P, C];
  * char_cnn.py:15-32): per-row-chunk partial records in `slots` (1 MiB scratch) folded in a fixed order; `counts` (nullable) =

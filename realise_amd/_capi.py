@@ -90,6 +90,7 @@ SYMBOLS = {
     "realise_set_ln": (None, [_I, _I]),
     "realise_set_engine": (None, [_I, _I]),
     "realise_layernorm_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_float, _P, _P, _P, _I, _I]),
+    "realise_layernorm_bwd_live": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_float, _P, _P, _P, _P, _I, _I]),
     "realise_batchnorm_stats_ex": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, C.c_float, C.c_float] + [_P] * 9),
     "realise_batchnorm_bwd_ex": (_I, [_P, _P, _P, _I, _I, _I, _P, _I] + [_P] * 7 + [_P] * 7 + [_P, _P]),
     "realise_set_tn_probe": (None, [_I]),
@@ -138,6 +139,7 @@ SYMBOLS = {
     "realise_engine_invalidate_frozen": (None, [_P]),
     "realise_engine_set_id_flag": (None, [_P, _P]),
     "realise_engine_set_grads_fresh": (None, [_P, _I]),
+    "realise_engine_set_loss_grad": (None, [_P, _P]),
     "realise_engine_forward": (_I, [_P, _P, C.POINTER(Batch)]),
     "realise_engine_backward": (_I, [_P, _P, _I, _I]),
     "realise_engine_backward_signalled": (_I, [_P, _P, C.POINTER(C.c_void_p), _I]),

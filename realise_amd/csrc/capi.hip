@@ -156,7 +156,7 @@ void realise_set_nt_probe(int mode) { set_nt_probe(mode); }
 void realise_set_nt_variant(int v) { set_nt_variant(v); }
 void realise_set_nt_group_m(int g) { set_nt8_group_m(g); }
 void realise_set_ln(int key, int value) {
-  if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); else if (key == 2) set_bn_fast(value); else if (key == 3) set_bn_chunks(value); else if (key == 4) set_ce_fast(value);
+  if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); else if (key == 2) set_bn_fast(value); else if (key == 3) set_bn_chunks(value); else if (key == 4) set_ce_fast(value); else if (key == 5) set_ln_v2(value);
 }
 void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); else if (key >= 1 && key <= 3) set_stream_priority(key - 1, value); else if (key == 4) set_cls_compact(value); else if (key == 5) set_skip_dead(value); else if (key == 6) set_cls_splitk(value); else if (key == 7) set_tn_group8(value); else if (key == 8) set_ln_fuse(value); else if (key == 9) set_gru_fuse(value); else if (key == 10) set_live_rows(value); }
 void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); else if (key == 2) set_nt8_single_round(value); }
@@ -238,6 +238,14 @@ int realise_layernorm_bwd_ex(void* stream, const void* dy, const void* xhat, con
   LnBwdArgs<bf16_t> a; a.rows = rows; a.H = H; a.dy = (const bf16_t*)dy; a.xhat = (const bf16_t*)xhat; a.rstd = rstd;
   a.gamma = gamma; a.dx = (bf16_t*)dx; a.dx_drop = (bf16_t*)dx_drop; a.out_drop.seed = drop_seed; a.out_drop.thresh = drop_thresh;
   a.out_drop.scale = drop_scale; a.dgamma = dgamma; a.dbeta = dbeta; a.slots = slots;
+  return ln_bwd<bf16_t>((hipStream_t)stream, a);
+}
+int realise_layernorm_bwd_live(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,
+                               uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* dgamma, float* dbeta, float* slots,
+                               const uint8_t* row_live, int rows, int H) {
+  LnBwdArgs<bf16_t> a; a.rows = rows; a.H = H; a.dy = (const bf16_t*)dy; a.xhat = (const bf16_t*)xhat; a.rstd = rstd;
+  a.gamma = gamma; a.dx = (bf16_t*)dx; a.dx_drop = (bf16_t*)dx_drop; a.out_drop.seed = drop_seed; a.out_drop.thresh = drop_thresh;
+  a.out_drop.scale = drop_scale; a.dgamma = dgamma; a.dbeta = dbeta; a.slots = slots; a.row_live = row_live;
   return ln_bwd<bf16_t>((hipStream_t)stream, a);
 }
 int realise_build_pho(void* stream, const int64_t* src_idx, int T, const int64_t* table, const int32_t* vlens, int V, int Tw,
@@ -438,6 +446,7 @@ int realise_engine_refresh_shadows_ex(realise_engine* e, void* stream, int linea
 void realise_engine_invalidate_frozen(realise_engine* e) { if (e) e->impl->invalidate_frozen(); }
 void realise_engine_set_grads_fresh(realise_engine* e, int fresh) { if (e) e->impl->set_grads_fresh(fresh); }
 void realise_engine_set_id_flag(realise_engine* e, int32_t* flag) { if (e) e->impl->set_id_flag((int*)flag); }
+void realise_engine_set_loss_grad(realise_engine* e, const float* grad_dev) { if (e) e->impl->set_loss_grad(grad_dev); }
 int realise_engine_forward(realise_engine* e, void* stream, const realise_batch* batch) {
   return (e && batch) ? e->impl->forward((hipStream_t)stream, *batch) : RL_ERR_ARG;
 }

@@ -157,10 +157,46 @@ __device__ __forceinline__ floatx4 drop_mult4(uint32_t seed, uint32_t thresh, fl
   return floatx4{(h.x & 0xffffu) >= t ? scale : 0.0f, (h.x >> 16) >= t ? scale : 0.0f, (h.y & 0xffffu) >= t ? scale : 0.0f, (h.y >> 16) >= t ? scale : 0.0f};
 }
 
+// the same without the thresh == 0 test (callers that are only instantiated for a live dropout site: the test is a uniform BRANCH
+// per call that splits a straight-line row loop into blocks the scheduler cannot move loads across)
+__device__ __forceinline__ floatx4 drop_mult4_nz(uint32_t seed, uint32_t thresh, float scale, uint32_t idx) {
+  const uint2 h = rng_hash4(seed, idx >> 2);
+  const uint32_t t = thresh >> 16;
+  return floatx4{(h.x & 0xffffu) >= t ? scale : 0.0f, (h.x >> 16) >= t ? scale : 0.0f, (h.y & 0xffffu) >= t ? scale : 0.0f, (h.y >> 16) >= t ? scale : 0.0f};
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+// The same sum through the DPP cross-lane paths of the VALU instead of six ds_bpermute round trips through the LDS crossbar (a
+// dependent chain of ~6 x 60-100 clk per reduction: the LayerNorm kernels, one or two reductions per row, spent a third of a row's
+// time in it).  quad_perm -> row_half_mirror -> row_mirror leave every lane with its 16-lane row's sum; row_bcast:15 / :31 carry the
+// row sums into rows 1, 3 and then 2, 3, so lane 63 (and every lane of row 3) holds the total.  Another summation ORDER than
+// wave_sum: results agree to fp32 rounding, not bit for bit.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum_dpp(float v) {      // every lane: the sum over its aligned 16-lane row
+  v = dpp_add<0xB1, 0xF>(v);       // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);       // quad_perm:[2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);      // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);      // row_mirror
+  return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {        // wave-uniform result
+  v = row16_sum_dpp(v);
+  v = dpp_add<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float half_sum_dpp(float v, int half) {      // sum over the lane's 32-lane half (half = lane >> 5)
+  v = row16_sum_dpp(v);
+  v = dpp_add<0x142, 0xA>(v);      // lanes 16-31 / 48-63 now hold the sums of half 0 / half 1
+  const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+  const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return half ? s1 : s0;
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

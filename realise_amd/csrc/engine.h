@@ -31,6 +31,7 @@ struct EngineBase {
   virtual void invalidate_frozen() = 0;
   virtual void set_id_flag(int* flag) = 0;
   virtual void set_grads_fresh(int fresh) = 0;
+  virtual void set_loss_grad(const float* grad_dev) = 0;
   virtual int forward(hipStream_t st, const realise_batch& b) = 0;
   virtual int backward(hipStream_t st, int first, int last) = 0;
   virtual int backward_signalled(hipStream_t st, void* const* bucket_events, int n_events) = 0;

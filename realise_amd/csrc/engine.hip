@@ -466,6 +466,7 @@ template <typename T> struct Engine : EngineBase {
         const std::string ln = name + ".layer." + std::to_string(l);
         tap(ln + ".qkv", x.qkv, Tk * 3 * H); tap(ln + ".ctx", x.ctx, Tk * H); tap(ln + ".attn_out", x.y1, Tk * H);
         tap(ln + ".inter", x.post, Tk * I); tap(ln + ".out", x.y2, Tk * H);
+        tap(ln + ".sum1", x.s1, Tk * H); tap(ln + ".sum2", x.s2, Tk * H);      // (pre-LayerNorm sums; after a training forward: their xhat)
       }
     };
     p.mask_add = b.take(Tk * 4);
@@ -790,6 +791,7 @@ template <typename T> struct Engine : EngineBase {
     LnBwdArgs<T> ln; ln.slots = ln_region(LN_FOLD_MAX); ln.rows = Tk; ln.H = H; ln.dy = gA; ln.in_drop = site(sid * 1000 + 900, cfg.hidden_dropout);
     ln.xhat = wp<T>(a.emb_xhat); ln.rstd = wp<float>(a.emb_rstd); ln.gamma = pp(so.ln_g); ln.dx = dx;
     ln.dgamma = gp(so.ln_g); ln.dbeta = gp(so.ln_b);
+    ln.row_live = live_rows();      // (padding rows: dy is an exact zero - dx written as zeros without reading the row's saved xhat)
     RL_TRY(ln_bwd<T>(st, ln));
     RL_TRY(embed_bwd<T>(st, dx, ids, B, S, H, (ids && so.word >= 0) ? gp(so.word) : nullptr, gp(so.pos), pos_zero, gp(so.type)));
     return RL_OK;
@@ -1117,7 +1119,8 @@ template <typename T> struct Engine : EngineBase {
     // their forward activations in the transformer stacks either.
     dead_ok = b.tgt_idx != nullptr && b.loss_masks != nullptr && g_skip_dead && b.want_dlogits && b.masks != nullptr && (Tk % 64) == 0;
     if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_t16), wp<int>(pl.live_n), wp<int>(pl.live_rlen)));
-    rows_live = dead_ok && b.training && g_live_rows && live16() && (H % 64) == 0 && (I % 64) == 0 && (int64_t)Tk * I * 2 < 0xFFFFFF00ll;
+    // (the weight gradients of a live-row step must walk the same block list - only the grouped launch takes one: ADVICE round 4)
+    rows_live = dead_ok && b.training && g_live_rows && g_wgrad_group && live16() && (H % 64) == 0 && (I % 64) == 0 && (int64_t)Tk * I * 2 < 0xFFFFFF00ll;
     const T* bert_h = nullptr;
     const bool ovl = cfg.model_type == 1 && g_branch_overlap && branches_ok();
     hipStream_t s_pho = ovl ? bst[0] : st, s_glyph = ovl ? bst[1] : st;
@@ -1246,6 +1249,11 @@ template <typename T> struct Engine : EngineBase {
   // ---------------------------------------------------------------- backward, in bucket-sized stages
   int n_stages() const { return (int)L.buckets.size(); }
 
+  // d loss arriving at backward() as a DEVICE scalar (nullptr: 1): the head's three gradients are linear in it, so it is applied where
+  // they leave the head - the classifier's weight / bias gradient epilogues (TnEpi::alpha_dev) and the scatter that writes d(top
+  // hidden) - instead of a read-modify-write pass over the ~200 MB of cross-entropy gradient rows
+  const float* loss_grad = nullptr;
+  void set_loss_grad(const float* g) override { loss_grad = g; }
   int stage_head(hipStream_t st) {      // classifier + final dropout ; leaves d(top hidden) in gA
     const int Tk = pl.B * pl.S;
     const T* dl = wp<T>(pl.dlogits);
@@ -1256,20 +1264,23 @@ template <typename T> struct Engine : EngineBase {
     if (cls_compact) {
       const int* n_act = wp<int>(pl.cls_nact);
       { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(L.cls_b); te.out = gp(L.cls_w); te.ldo = H;
+        te.alpha_dev = loss_grad;
         RL_TRY(gemm_tn<T>(st, dl, Vp, wp<T>(pl.cls_xc), H, Tk, V, H, te, n_act)); }
       if constexpr (sizeof(T) == 2) {
         const int ns = g_cls_splitk;
         if (ns >= 2 && pl.cls_slab != 0 && Tk >= 1024 &&
             gemm_nt8_splitk(st, dl, Vp, sp<T>(sh_cls_wT), Vp, Tk, H, Vp, ns, wp<float>(pl.cls_slab), (int64_t)Tk * H, n_act) == RL_OK)
-          return scatter_rows_drop_slab<T>(st, wp<float>(pl.cls_slab), ns, (int64_t)Tk * H, wp<int>(pl.cls_inv), Tk, H, gA, dfin);
+          return scatter_rows_drop_slab<T>(st, wp<float>(pl.cls_slab), ns, (int64_t)Tk * H, wp<int>(pl.cls_inv), Tk, H, gA, dfin, loss_grad);
       }
       { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = wp<T>(pl.cls_gc); ep.ldo = H; ep.m_dev = n_act;
         RL_TRY(gemm_nt<T>(st, dl, Vp, sp<T>(sh_cls_wT), Vp, Tk, H, Vp, ep)); }
-      return scatter_rows_drop<T>(st, wp<T>(pl.cls_gc), wp<int>(pl.cls_inv), Tk, H, gA, dfin);      // rows outside the loss: zero; + the final dropout's map
+      return scatter_rows_drop<T>(st, wp<T>(pl.cls_gc), wp<int>(pl.cls_inv), Tk, H, gA, dfin, loss_grad);      // rows outside the loss: zero; + the final dropout's map
     }
-    { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(L.cls_b); te.out = gp(L.cls_w); te.ldo = H; RL_TRY(gemm_tn<T>(st, dl, Vp, cls_in, H, Tk, V, H, te)); }
+    { TnEpi te; te.slab = wp<float>(pl.tn_slab); te.slab_elems = TN_SLAB_ELEMS; te.colsum = gp(L.cls_b); te.out = gp(L.cls_w); te.ldo = H; te.alpha_dev = loss_grad;
+      RL_TRY(gemm_tn<T>(st, dl, Vp, cls_in, H, Tk, V, H, te)); }
     { EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = gA; ep.ldo = H;
       RL_TRY(gemm_nt<T>(st, dl, Vp, sp<T>(sh_cls_wT), Vp, Tk, H, Vp, ep)); }      // K = Vp: the padding columns are exact zeros on both sides
+    if (loss_grad != nullptr) RL_TRY(scale_by_dev<T>(st, gA, (int64_t)Tk * H, loss_grad));      // (dense fallback: a pass over [T, H], not over the logits)
     if (dfin.thresh) RL_TRY(dropout_apply<T>(st, gA, gA, Tk, H, dfin));
     return RL_OK;
   }
@@ -1308,7 +1319,7 @@ template <typename T> struct Engine : EngineBase {
   int stage_gate(hipStream_t st) {           // d fused -> X1 (d bert), X2 (d pho), X3 (d res) + gate_net gradients
     GateArgs<T> g = gate_args();
     g.dfused = wp<T>(pl.sc[0].gB); g.dbert = wp<T>(pl.X1); g.dpho = wp<T>(pl.X2); g.dres = wp<T>(pl.X3); g.dz = wp<float>(pl.dz);
-    g.dW = gp(L.gate_w); g.dbias = gp(L.gate_b);
+    g.dW = gp(L.gate_w); g.dbias = gp(L.gate_b); g.row_live = live_rows();
     return gate_bwd<T>(st, g);
   }
   int stage_glyph(hipStream_t st) {          // resnet LayerNorm, segment sum over the tokens of a glyph, glyph ResNet

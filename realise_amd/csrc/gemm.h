@@ -307,6 +307,7 @@ struct TnEpi {
   float* out = nullptr;     // fp32, accumulated (out += result)
   int64_t ldo = 0;
   float alpha = 1.0f;
+  const float* alpha_dev = nullptr; // optional device scalar multiplied on top of alpha (the incoming d loss of the classifier's gradients: never read on the host)
   int Cin = 0, Cpad = 0, KHW = 0;   // TN_CONVW: j = tap*Cpad + ci -> out[(i*Cin + ci)*KHW + tap + tap0]
   int tap0 = 0;                     // first tap the J columns cover (a 3x3 convolution on a 1x1 map only has its centre tap: J = Cpad, tap0 = 4)
   // split-reduction scratch: when the reduction is split over several workgroups each writes a dense fp32

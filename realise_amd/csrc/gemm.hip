@@ -774,7 +774,7 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int i = i0 + wi * 64 + f * 16 + l15;
-      if (i < I) atomicAdd(ep.colsum + i, csum[f][0] * ep.alpha);
+      if (i < I) atomicAdd(ep.colsum + i, csum[f][0] * tn_alpha(ep));
     }
   }
 }
@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(256) tn_fold_plain_kernel(TnEpi ep, int nsplit
       }
     }
     if (ls == 0 && e < n4) {
-      s *= ep.alpha;
+      s *= tn_alpha(ep);
       const int i = (int)((e * 4) / J), j = (int)((e * 4) - (int64_t)i * J);
       if (ep.mode == TN_PLAIN && (ep.ldo & 3) == 0) {
         floatx4* o = (floatx4*)(ep.out + (int64_t)i * ep.ldo + j);
@@ -877,7 +877,7 @@ __global__ void __launch_bounds__(256) tn_fold_convw_kernel(TnEpi ep, int nsplit
         }
         __syncthreads();
       }
-      if (ls == 0 && e < items) ep.out[e * ep.KHW + tap + ep.tap0] += s * ep.alpha;
+      if (ls == 0 && e < items) ep.out[e * ep.KHW + tap + ep.tap0] += s * tn_alpha(ep);
     }
   }
 }
@@ -987,7 +987,13 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
   TnGroup<T> grp;
   grp.n = n; grp.alpha = alpha; grp.probe = g_tn_probe; grp.overwrite = overwrite;
   if (list_rows != 0 && list_rows != G::BP && !(list_rows == 16 && sizeof(T) == 2)) return RL_ERR_ARG;
-  if (tile_list != nullptr && n_tiles != nullptr && (P % G::BP) == 0 && !g_tn_group_ring) { grp.tile_list = tile_list; grp.n_tiles = n_tiles; grp.list_rows = list_rows ? list_rows : G::BP; }
+  // A caller that hands over a live-block list may rely on it (a live-row step leaves stale values in the rows of unlisted blocks):
+  // the list is honoured or the call fails - it is never silently dropped.  The four-stage ring has no list form, so a listed call
+  // runs on the default two-stage ring whatever the knob says.
+  const bool listed_call = tile_list != nullptr;
+  if (listed_call && (n_tiles == nullptr || (P % G::BP) != 0)) return RL_ERR_ARG;
+  const bool ring4 = g_tn_group_ring && !listed_call;
+  if (listed_call) { grp.tile_list = tile_list; grp.n_tiles = n_tiles; grp.list_rows = list_rows ? list_rows : G::BP; }
   int total = 0;
   double flops = 0.0;
   for (int k = 0; k < n; ++k) {
@@ -1012,7 +1018,7 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<T, TRV, NSTV, BPDV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
     RL_LAUNCH((gemm_tn_group_kernel<T, TRV, NSTV, BPDV>), dim3(total), dim3(256), lds, st, grp, P, pchunk); } while (0)
   const bool tr = sizeof(T) == 2 && g_tn_tr;
-  if (g_tn_group_ring) { if (tr) RL_TN_GROUP(true, 4, 2); else RL_TN_GROUP(false, 4, 2); }
+  if (ring4) { if (tr) RL_TN_GROUP(true, 4, 2); else RL_TN_GROUP(false, 4, 2); }
   else { if (tr) RL_TN_GROUP(true, 2, 1); else RL_TN_GROUP(false, 2, 1); }
 #undef RL_TN_GROUP
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
@@ -1044,7 +1050,7 @@ int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& l
     // 64 -> 64 channels, 3x3 / stride 1 / pad 1 on 16x16 maps (glyph ResNet block 1): the LDS-resident-input kernel
     if (g_conv_c64 && g_tn_probe == 0 && lb.C == 64 && lb.KH == 3 && lb.KW == 3 && lb.stride == 1 && lb.pad == 1 && lb.mode == 0 && lb.Hr == 16 &&
         lb.Wr == 16 && lb.Hs == 16 && lb.Ws == 16 && lb.img_index == nullptr && I == 64 && lda == 64 && P == lb.rows && (P % 256) == 0 &&
-        ep.mode == TN_CONVW && ep.Cin == 64 && ep.Cpad == 64 && ep.KHW == 9 && ep.tap0 == 0 && ep.alpha == 1.0f && ep.slab != nullptr &&
+        ep.mode == TN_CONVW && ep.Cin == 64 && ep.Cpad == 64 && ep.KHW == 9 && ep.tap0 == 0 && ep.alpha == 1.0f && ep.alpha_dev == nullptr && ep.slab != nullptr &&
         ep.slab_elems >= 64 * 576 && (int64_t)P * 128 < 0xFFFFFE00ll)
       return conv_wgrad_c64(st, A, lb.src, P, lb.rows_dev, ep);
   }

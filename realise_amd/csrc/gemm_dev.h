@@ -156,13 +156,15 @@ __device__ __forceinline__ int64_t tn_out_index(const TnEpi& ep, int i, int j) {
   return ci < ep.Cin ? ((int64_t)i * ep.Cin + ci) * ep.KHW + tap + ep.tap0 : -1;
 }
 
+__device__ __forceinline__ float tn_alpha(const TnEpi& ep) { return ep.alpha_dev != nullptr ? ep.alpha * *ep.alpha_dev : ep.alpha; }
+
 __device__ __forceinline__ void tn_epilogue4(const TnEpi& ep, int how, int split, int I, int J, int i, int j, floatx4 v) {
   if (i >= I || j >= J) return;
   if (how == TN_OUT_SLAB) {                       // dense [split][I][J]; J % 4 == 0
     *(floatx4*)(ep.slab + ((int64_t)split * I + i) * J + j) = v;
     return;
   }
-  v *= ep.alpha;
+  v *= tn_alpha(ep);
   if (how == TN_OUT_DIRECT && ep.mode == TN_PLAIN && (ep.ldo & 3) == 0) {
     floatx4* o = (floatx4*)(ep.out + (int64_t)i * ep.ldo + j);
     if (ep.overwrite) *o = v; else *o = *o + v;

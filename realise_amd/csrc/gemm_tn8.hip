@@ -220,7 +220,7 @@ __device__ __forceinline__ void tn8_body(const bf16_t* __restrict__ A, int64_t l
 #pragma unroll
     for (int f = 0; f < MT; ++f) {
       const int i = i0 + wi * 64 + f * 16 + l15;
-      if (i < I) atomicAdd(ep.colsum + i, csum[f][0] * ep.alpha);
+      if (i < I) atomicAdd(ep.colsum + i, csum[f][0] * tn_alpha(ep));
     }
   }
 }

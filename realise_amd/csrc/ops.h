@@ -85,6 +85,7 @@ struct LnFoldSite { const float* recs; int nrec; float* dgamma; float* dbeta; };
 struct LnFoldSites { int n = 0; int H = 0; LnFoldSite s[LN_FOLD_MAX]; };
 int ln_fold_multi(hipStream_t st, const LnFoldSites& sites);
 void set_ln_fast(int on);            // 1 (default): bf16 rows of 256 / 512 / 768 / 1024 columns take the half-wave-per-row kernels (16-byte accesses)
+void set_ln_v2(int on);              // 1 (default, round 5): DPP row reductions + ln_bwd16v2_kernel; 0: the round-4 kernels
 void set_ln_bwd_blocks(int n);       // workgroups of the fast LayerNorm backward (default 512)
 
 // scatter d(embedding sum) to the word / position / type tables
@@ -109,9 +110,11 @@ int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, 
             float* loss_out, float* count_buf, T* dlogits, float* row_loss = nullptr, int64_t ld_dl = 0, const CeCompact& cc = CeCompact());
 // out[j] = in[idx[j]], j < *n_dev (rows of H elements); out[row] = inv[row] >= 0 ? in[inv[row]] * dropout mask : 0
 template <typename T> int gather_rows(hipStream_t st, const T* in, const int* idx, const int* n_dev, int max_rows, int H, T* out);
-template <typename T> int scatter_rows_drop(hipStream_t st, const T* in, const int* inv, int rows, int H, T* out, DropParams d);
+// scale_dev (nullable): a device scalar multiplied into every stored value - the incoming loss gradient, never read on the host
+template <typename T> int scatter_rows_drop(hipStream_t st, const T* in, const int* inv, int rows, int H, T* out, DropParams d, const float* scale_dev = nullptr);
+template <typename T> int scale_by_dev(hipStream_t st, T* x, int64_t n, const float* scale_dev);
 template <typename T> int scatter_rows_drop_slab(hipStream_t st, const float* slab, int nsplit, int64_t stride, const int* inv, int rows, int H, T* out,
-                                                 DropParams d);      // rows of a split-K GEMM's fp32 planes, folded in plane order   // ld_dl: row pitch of dlogits (0: ld)
+                                                 DropParams d, const float* scale_dev = nullptr);      // rows of a split-K GEMM's fp32 planes, folded in plane order   // ld_dl: row pitch of dlogits (0: ld)
 
 // ---- eval decode (run.py:262-263): ids[row] = argmax_v logits[row][v], first maximum wins (numpy / torch semantics), a NaN
 // counts as the maximum.  Only the ids leave the device (32 KB instead of the 692 MB fp32 logits of run.py:262).
@@ -133,6 +136,9 @@ template <typename T> struct GateArgs {
   T* dbert = nullptr; T* dpho = nullptr; T* dres = nullptr;
   float* dz = nullptr;             // [B*S][4] scratch
   float* dW = nullptr; float* dbias = nullptr;
+  // optional byte per token row (row_liveness): 0 = a padding row behind the sentence's last attended / loss position.  Its d fused row is an
+  // exact zero, so the backward writes its zeros without reading the row's (possibly stale - live-row steps) forward activations.
+  const uint8_t* row_live = nullptr;
 };
 template <typename T> int gate_fwd(hipStream_t st, const GateArgs<T>& a);
 template <typename T> int gate_bwd(hipStream_t st, const GateArgs<T>& a);

@@ -100,7 +100,7 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return u;
 }
 
-template <int NV8, int RP>
+template <int NV8, int RP, bool DPP>
 __global__ void __launch_bounds__(256) ln_fwd16_kernel(LnFwdArgs<bf16_t> a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
   const int H = a.H;
@@ -131,13 +131,13 @@ __global__ void __launch_bounds__(256) ln_fwd16_kernel(LnFwdArgs<bf16_t> a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) sum += v[i][j];
     }
-    const float mean = half_sum(sum) / (float)H;
+    const float mean = (DPP ? half_sum_dpp(sum, half) : half_sum(sum)) / (float)H;
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < NV8; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
-    const float rstd = 1.0f / sqrtf(half_sum(sq) / (float)H + a.eps);
+    const float rstd = 1.0f / sqrtf((DPP ? half_sum_dpp(sq, half) : half_sum(sq)) / (float)H + a.eps);
     if (row >= a.rows) continue;
     if (hl == 0 && a.rstd != nullptr) a.rstd[row] = rstd;
 #pragma unroll
@@ -164,25 +164,32 @@ __global__ void __launch_bounds__(256) ln_fwd16_kernel(LnFwdArgs<bf16_t> a) {
 static int g_ce_fast = 1;                            // bf16 cross-entropy with the row in registers (realise_set_ln key 4)
 void set_ce_fast(int on) { g_ce_fast = on; }
 static int g_ln_fast = 1, g_ln_bwd_blocks = 512;
+// round 5 (realise_set_ln key 5): 1 = the row reductions of the bf16 LayerNorm kernels through DPP (wave_sum_dpp) and the backward on
+// ln_bwd16v2_kernel (no barrier before the first row, four rows of a wave in flight, one-barrier epilogue); 0 = the round-4 kernels
+static int g_ln_v2 = 1, g_ln_bwd_blocks_v2 = 256;
+void set_ln_v2(int on) { g_ln_v2 = on; }
 static int g_bn_fast = 1, g_bn_chunks = 1024;       // bf16 16-byte BatchNorm / column-reduction kernels; row chunks (= workgroups) of the reductions
 static int g_bn_onepass = 1;                        // bf16 training statistics in one pass about the running mean (bn_stats_train16)
 void set_bn_fast(int on) { g_bn_fast = on & 1; g_bn_onepass = (on & 1) && !(on & 2); }
 void set_bn_chunks(int n) { if (n >= 1 && n <= 4096) g_bn_chunks = n; }
 int bn_fast() { return g_bn_fast; }
 void set_ln_fast(int on) { g_ln_fast = on; }
-void set_ln_bwd_blocks(int n) { g_ln_bwd_blocks = n > 0 ? n : 512; }
+void set_ln_bwd_blocks(int n) { if (g_ln_v2) g_ln_bwd_blocks_v2 = n > 0 ? n : 256; else g_ln_bwd_blocks = n > 0 ? n : 512; }      // (of the active variant)
 
 template <typename T> int ln_fwd_fast(hipStream_t st, const LnFwdArgs<T>& a) { return -1; }
 template <> int ln_fwd_fast<bf16_t>(hipStream_t st, const LnFwdArgs<bf16_t>& a) {
   if (!g_ln_fast || a.in_mode != 0 || a.row_index != nullptr || (a.H % 256) != 0 || a.H > 1024) return -1;
   constexpr int RP = 2;
   const int blocks = (a.rows + 4 * 2 * RP - 1) / (4 * 2 * RP);
+#define RL_LNF(NV) do { if (g_ln_v2) hipLaunchKernelGGL((ln_fwd16_kernel<NV, RP, true>), dim3(blocks), dim3(256), 0, st, a); \
+                       else hipLaunchKernelGGL((ln_fwd16_kernel<NV, RP, false>), dim3(blocks), dim3(256), 0, st, a); } while (0)
   switch (a.H / 256) {
-    case 1: hipLaunchKernelGGL((ln_fwd16_kernel<1, RP>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((ln_fwd16_kernel<2, RP>), dim3(blocks), dim3(256), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((ln_fwd16_kernel<3, RP>), dim3(blocks), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((ln_fwd16_kernel<4, RP>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 1: RL_LNF(1); break;
+    case 2: RL_LNF(2); break;
+    case 3: RL_LNF(3); break;
+    default: RL_LNF(4); break;
   }
+#undef RL_LNF
   return RL_LAUNCH_CHECK();
 }
 
@@ -214,19 +221,31 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(LnBwdArgs<T> a) {
     const int c = (i * 64 + lane) * 4;
     gm[i] = c < H ? *(const floatx4*)(a.gamma + c) : floatx4{0.f, 0.f, 0.f, 0.f};
   }
+  // padding rows (row_live[row] == 0, a wave owns a row: wave-uniform): dy is an exact zero, so dx is - written without reading the row
+  auto dead = [&](int row) -> bool { return a.row_live != nullptr && row < a.rows && a.row_live[row] == 0; };
   auto load_row = [&](int row, floatx4 (&dy)[NV], floatx4 (&xh)[NV]) {
+    const bool skip = dead(row);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       dy[i] = floatx4{0.f, 0.f, 0.f, 0.f};
       xh[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-      if (c < H && row < a.rows) {
+      if (c < H && row < a.rows && !skip) {
         dy[i] = load4<T>(a.dy + (int64_t)row * H + c);
         xh[i] = load4<T>(a.xhat + (int64_t)row * H + c);
       }
     }
   };
   auto do_row = [&](int row, floatx4 (&dy)[NV], floatx4 (&xh)[NV]) {
+    if (dead(row)) {
+      const floatx4 z4 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < H) { store4<T>(a.dx + (int64_t)row * H + c, z4); if (a.dx_drop != nullptr) store4<T>(a.dx_drop + (int64_t)row * H + c, z4); }
+      }
+      return;
+    }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -440,6 +459,221 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
     }
   }
 }
+// Round 5: the same row arithmetic on a leaner skeleton.  tools/ln_probe.py's block sweep put the FIXED cost of a workgroup of the
+// kernel above at ~8 us against ~1.5 us per row: a prologue of three dependent memory latencies (liveness flags -> first rows -> gamma
+// through the LDS and a barrier), an epilogue of two LDS passes with four barriers, and per row two wave reductions of six
+// ds_bpermute round trips each.  Here
+//   * nothing waits before the first row: the flags, gamma (straight into 16 registers per lane - no LDS, no barrier) and the first
+//     row's data are requested together (that row is fetched whether or not it is live; the later ones only when live);
+//   * a wave keeps FOUR rows in flight (statically named register sets) and walks twice as many rows, so half as many workgroups
+//     pay the fixed cost and write records;
+//   * the row sums go through DPP (wave_sum_dpp);
+//   * the epilogue is ONE barrier: every wave stores its 2 x 16 partial columns as 16-byte LDS writes, 256 threads add the four
+//     waves in order and write the record as 16-byte stores.  LDS 32 H bytes (24 KB at H = 768), touched by the epilogue only.
+// Same record layout ([dgamma | dbeta] per workgroup), same fold kernels; a wave's rows are summed in row order, the four waves in
+// wave order: deterministic, but another order than the kernel above.
+typedef __attribute__((ext_vector_type(4))) uint32_t ln_u32x4;
+typedef __attribute__((ext_vector_type(4))) int ln_i32x4;
+// Row loads the COMPILER DOES NOT TRACK.  hipcc's waitcnt insertion treats vmcnt as out of order as soon as loads and stores are
+// pending together (one counter for both on gfx9) and then waits with vmcnt(0): in a row loop that stores row k while rows k+1.. are
+// in flight, EVERY use of a loaded row drained the whole queue - the prefetched rows included - which is why the round-3/4 kernel
+// gained nothing from more rows in flight.  The hardware retires a wave's loads and stores in issue order through that counter
+// (gemm_nt8p.hip relies on the same), so a counted wait is exact: these loads are inline asm, the waits are explicit, and
+// ln_pin() keeps the uses of a loaded value behind its wait.  (Device pass only: the host pass cannot place the constraints.)
+__device__ __forceinline__ ln_u32x4 ln_load16(uint32_t voff, uint32_t soff, ln_i32x4 rsrc) {
+  ln_u32x4 v = {0u, 0u, 0u, 0u};
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#endif
+  return v;
+}
+__device__ __forceinline__ uint32_t ln_load4(uint32_t voff, uint32_t soff, ln_i32x4 rsrc) {
+  uint32_t v = 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+#endif
+  return v;
+}
+template <int N> __device__ __forceinline__ void ln_wait_vm() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+struct LnRowA { ln_u32x4 dy[2], xh[2]; uint32_t rstd; };
+__device__ __forceinline__ void ln_pin(LnRowA& r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(r.dy[0]), "+v"(r.dy[1]), "+v"(r.xh[0]), "+v"(r.xh[1]), "+v"(r.rstd));
+#endif
+}
+
+template <bool DROP>
+__global__ void __launch_bounds__(256, 2) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a) {
+  // Branch-free row path: every global access of the row loop is a raw buffer access - the row's byte offset in the SCALAR offset
+  // operand, the lane's column offset in the vector operand, which is parked beyond the buffer for whatever must not happen (a lane
+  // beyond H / 16, a row beyond this wave's last, the loads of a padding row): out-of-range loads return zeros and move no bytes,
+  // out-of-range stores are dropped (the range check looks at the vector offset only).  A padding row runs the same arithmetic on
+  // zeros (dx = 0 * (0 - 0 - 0) = 0, nothing added to dgamma / dbeta) and stores its zero row.  Every row therefore issues exactly
+  // 5 loads and 4 stores, which is what makes the counted waits below compile-time constants.
+  extern __shared__ float ln_lds[];          // [4 waves][2 H]: epilogue only
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int H = a.H, HH = H >> 1;
+  const bool active = lane * 16 < H;
+  constexpr uint32_t OOB = 0xFFFFFF00u;
+  const uint32_t nbytes = (uint32_t)a.rows * (uint32_t)H * 2u;              // < 4 GiB - 256 (launcher)
+  auto rsrc_words = [](const void* p, uint32_t bytes) {      // raw buffer descriptor: base, stride 0, num_records = bytes, DST_SEL / format word of a 32-bit raw buffer
+    const uint64_t ad = (uint64_t)(uintptr_t)p;
+    return ln_i32x4{(int)(uint32_t)ad, (int)(uint32_t)((ad >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  };
+  const ln_i32x4 rs_dy = rsrc_words(a.dy, nbytes), rs_xh = rsrc_words(a.xhat, nbytes), rs_rs = rsrc_words(a.rstd, (uint32_t)a.rows * 4u);
+  const __amdgpu_buffer_rsrc_t rs_dx = __builtin_amdgcn_make_buffer_rsrc((void*)a.dx, 0, (int)nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dx_drop != nullptr ? a.dx_drop : a.dx), 0, a.dx_drop != nullptr ? (int)nbytes : 0, 0x00020000);
+  const int c0 = active ? lane * 8 : 0, c1 = active ? HH + lane * 8 : 0;
+  const uint32_t lo0 = active ? (uint32_t)c0 * 2u : OOB, lo1 = active ? (uint32_t)c1 * 2u : OOB;      // byte offsets inside a row; idle lanes parked
+  const int stride = gridDim.x * 4;
+  const int row_first = blockIdx.x * 4 + wave;
+  const int nrow = row_first < a.rows ? (a.rows - row_first + stride - 1) / stride : 0;      // this wave's rows: row_first + k * stride, k < nrow <= 64
+  const uint32_t row_bytes = (uint32_t)H * 2u;
+  // (bit-ands, not &&: no short-circuit branches around the loads)
+  auto load = [&](int k, LnRowA& r, int fetch) {
+    const uint32_t row = (uint32_t)(row_first + k * stride);
+    const uint32_t sbase = fetch ? row * row_bytes : 0u;
+    const uint32_t v0 = fetch ? lo0 : OOB, v1 = fetch ? lo1 : OOB;
+    r.dy[0] = ln_load16(v0, sbase, rs_dy);
+    r.dy[1] = ln_load16(v1, sbase, rs_dy);
+    r.xh[0] = ln_load16(v0, sbase, rs_xh);
+    r.xh[1] = ln_load16(v1, sbase, rs_xh);
+    r.rstd = ln_load4(fetch ? 0u : OOB, fetch ? row * 4u : 0u, rs_rs);
+  };
+  LnRowA r0, r1, r2, r3;
+  // ---- prologue: the liveness flags (lane k: is the wave's k-th row live; no table: every row), gamma and the FIRST row's data are
+  // requested together - one memory latency, not three in a row; that row is fetched whether or not it is live
+  int live_reg = 1;
+  if (a.row_live != nullptr) live_reg = lane < nrow ? (int)a.row_live[(int64_t)row_first + (int64_t)lane * stride] : 0;
+  float gm[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i ? c1 : c0;
+    *(floatx4*)&gm[i][0] = *(const floatx4*)(a.gamma + c); *(floatx4*)&gm[i][4] = *(const floatx4*)(a.gamma + c + 4);
+  }
+  load(0, r0, (int)(nrow > 0));
+  ln_wait_vm<0>();                           // flags, gamma, row 0
+  ln_pin(r0);
+  // the compiler's OWN wait for gamma / the flags (it does not see the asm wait above) must land here, before rows 1-3 are requested:
+  // at gamma's first use inside the row loop its vmcnt(0) would drain those rows too
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(gm[0][0]), "+v"(gm[0][1]), "+v"(gm[0][2]), "+v"(gm[0][3]), "+v"(gm[0][4]), "+v"(gm[0][5]), "+v"(gm[0][6]), "+v"(gm[0][7]),
+                    "+v"(gm[1][0]), "+v"(gm[1][1]), "+v"(gm[1][2]), "+v"(gm[1][3]), "+v"(gm[1][4]), "+v"(gm[1][5]), "+v"(gm[1][6]), "+v"(gm[1][7]),
+                    "+v"(live_reg));
+#endif
+  auto live_k = [&](int k) -> int { return (int)(k < nrow) & (int)(__builtin_amdgcn_readlane(live_reg, k & 63) != 0); };      // k wave-uniform
+  load(1, r1, live_k(1)); load(2, r2, live_k(2)); load(3, r3, live_k(3));
+  float dg[2][8], db[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+  // keep = 0: the row's data was fetched although it is a padding row (the wave's first row) - its dy counts as zeros
+  auto process = [&](int k, const LnRowA& r, int keep) {
+    const int store = (int)(k < nrow);
+    const uint32_t row = (uint32_t)(row_first + k * stride);
+    const uint32_t msk = keep ? 0xFFFFFFFFu : 0u;
+    // (opaque to the loop optimiser: as row * H + c it became eight per-lane induction variables carried - and spilled - across the loop)
+    const uint32_t row_h = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row * (uint32_t)H));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float dy[8], xh[8];
+      unpack8(uint4{r.dy[i][0] & msk, r.dy[i][1] & msk, r.dy[i][2] & msk, r.dy[i][3] & msk}, dy);
+      unpack8(uint4{r.xh[i][0] & msk, r.xh[i][1] & msk, r.xh[i][2] & msk, r.xh[i][3] & msk}, xh);      // (a stale xhat row may hold anything: 0 * NaN)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = dy[j] * gm[i][j];
+        s1 += t;
+        s2 += t * xh[j];
+        dg[i][j] += dy[j] * xh[j];
+        db[i][j] += dy[j];
+      }
+    }
+    s1 = wave_sum_dpp(s1) / (float)H;
+    s2 = wave_sum_dpp(s2) / (float)H;
+    const float rstd = __uint_as_float(r.rstd & msk);
+    const uint32_t sbase = store ? row * row_bytes : 0u;
+    // (fences: the dropout hashes and the second unpack are not to be hoisted above the reductions - they would all be live across them)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i) __builtin_amdgcn_sched_barrier(0);
+      const int c = i ? c1 : c0;
+      float dy[8], xh[8], dx[8];
+      unpack8(uint4{r.dy[i][0] & msk, r.dy[i][1] & msk, r.dy[i][2] & msk, r.dy[i][3] & msk}, dy);
+      unpack8(uint4{r.xh[i][0] & msk, r.xh[i][1] & msk, r.xh[i][2] & msk, r.xh[i][3] & msk}, xh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dx[j] = rstd * (dy[j] * gm[i][j] - s1 - xh[j] * s2);
+      const uint32_t voff = store ? (i ? lo1 : lo0) : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, pack8(dx)), rs_dx, voff, sbase, 0);
+      if constexpr (DROP) {
+#pragma unroll
+        for (int hq = 0; hq < 2; ++hq) {
+          const floatx4 dm = drop_mult4_nz(a.out_drop.seed, a.out_drop.thresh, a.out_drop.scale, row_h + (uint32_t)(c + 4 * hq));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dx[4 * hq + j] *= dm[j];
+        }
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, pack8(dx)), rs_dd, voff, sbase, 0);      // (no dx_drop: a zero-size buffer drops it)
+    }
+  };
+  // Counted waits.  Issue order of a wave's vector-memory operations from here on (L = the 5 loads of a row, S = its 4 stores):
+  //   L1 L2 L3 | S0 L4 | S1 L5 | S2 L6 | S3 L7 | S4 L8 | ...      (row k is processed, then row k + 4 requested into its registers)
+  // so when row k is about to be processed the operations younger than L(k) are: k = 1: L2 L3 S0 L4 = 19, k = 2: L3 S0 L4 S1 L5 = 23,
+  // k >= 3: S(k-3) L(k+1) S(k-2) L(k+2) S(k-1) L(k+3) = 27.  (Loads / stores of parked rows are still issued: the counts do not
+  // depend on the data.)  sched_barrier: the compiler must not move a row's arithmetic across its wait, nor interleave four rows'
+  // arithmetic (> 256 registers).
+#define RL_LN_STEP(K, R, NYOUNGER, KEEP) do { ln_wait_vm<NYOUNGER>(); ln_pin(R); __builtin_amdgcn_sched_barrier(0); \
+    process(K, R, KEEP); __builtin_amdgcn_sched_barrier(0); load((K) + 4, R, live_k((K) + 4)); __builtin_amdgcn_sched_barrier(0); } while (0)
+  if (nrow > 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    process(0, r0, live_k(0));               // (row 0 landed in the prologue)
+    __builtin_amdgcn_sched_barrier(0);
+    load(4, r0, live_k(4));
+    __builtin_amdgcn_sched_barrier(0);
+    RL_LN_STEP(1, r1, 19, 1);
+    RL_LN_STEP(2, r2, 23, 1);
+    RL_LN_STEP(3, r3, 27, 1);
+    for (int k = 4; k < nrow; k += 4) {
+      RL_LN_STEP(k, r0, 27, 1);
+      RL_LN_STEP(k + 1, r1, 27, 1);
+      RL_LN_STEP(k + 2, r2, 27, 1);
+      RL_LN_STEP(k + 3, r3, 27, 1);
+    }
+  }
+#undef RL_LN_STEP
+  ln_wait_vm<0>();                           // the parked loads of the rows beyond the last must not land in registers the epilogue re-uses
+  // ---- epilogue: [dgamma | dbeta] of the workgroup = the four waves' partials added in wave order
+  float* mine = ln_lds + (size_t)wave * 2 * H;
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = i ? c1 : c0;
+      *(floatx4*)(mine + c) = *(const floatx4*)&dg[i][0]; *(floatx4*)(mine + c + 4) = *(const floatx4*)&dg[i][4];
+      *(floatx4*)(mine + H + c) = *(const floatx4*)&db[i][0]; *(floatx4*)(mine + H + c + 4) = *(const floatx4*)&db[i][4];
+    }
+  }
+  __syncthreads();
+  float* rec = a.slots != nullptr ? a.slots + (int64_t)blockIdx.x * 2 * H : nullptr;
+  for (int q = threadIdx.x; q < 2 * H / 4; q += 256) {
+    const floatx4 v = ((*(const floatx4*)(ln_lds + 4 * q) + *(const floatx4*)(ln_lds + 2 * H + 4 * q)) + *(const floatx4*)(ln_lds + 4 * H + 4 * q)) +
+                      *(const floatx4*)(ln_lds + 6 * H + 4 * q);
+    if (rec != nullptr) *(floatx4*)(rec + 4 * q) = v;
+    else {
+      float* out = 4 * q < H ? a.dgamma : a.dbeta;
+      const int c = 4 * q < H ? 4 * q : 4 * q - H;
+      if (out != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(out + c + j, v[j]);
+      }
+    }
+  }
+}
 // dgamma / dbeta += sum of the per-workgroup records: one float4 column group per 64 threads (record lanes k, k + 64, ...),
 // four groups per block, fixed-order LDS tree.
 __global__ void __launch_bounds__(256) ln_fold_kernel(const float* __restrict__ recs, int nrec, int H, float* dgamma, float* dbeta) {
@@ -499,8 +733,20 @@ template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a) {
   if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr;
   const int nv = (a.H + 255) / 256;
   if constexpr (sizeof(T) == 2) {
-    if (g_ln_fast && a.in_drop.thresh == 0u && (a.H % 16) == 0 && a.H <= 1024 && (int64_t)a.rows * a.H * 2 < (1ll << 32)) {     // (the embedding LayerNorm, whose input gradient is dropout-masked first, keeps the general kernel)
+    if (g_ln_fast && a.in_drop.thresh == 0u && (a.H % 16) == 0 && a.H <= 1024 && ((int64_t)a.rows + 8192) * a.H * 2 < (1ll << 32) - 4096) {     // (the embedding LayerNorm, whose input gradient is dropout-masked first, keeps the general kernel)
       const int groups = (a.rows + 3) / 4;
+      if (g_ln_v2) {
+        blocks = groups < g_ln_bwd_blocks_v2 ? groups : g_ln_bwd_blocks_v2;
+        if (blocks * 256 < a.rows) blocks = (a.rows + 255) / 256;       // a wave's rows must fit its 64 liveness lanes
+        if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr; else b.slots = a.slots;
+        if (b.slots != nullptr && blocks > 1024) return RL_ERR_ARG;     // (LN_SLOT_FLOATS holds 1024 records)
+        const size_t lds2 = (size_t)8 * a.H * sizeof(float);
+        if (a.out_drop.thresh != 0u) hipLaunchKernelGGL((ln_bwd16v2_kernel<true>), dim3(blocks), dim3(256), lds2, st, b);
+        else hipLaunchKernelGGL((ln_bwd16v2_kernel<false>), dim3(blocks), dim3(256), lds2, st, b);
+        if (a.deferred_records != nullptr) *a.deferred_records = b.slots != nullptr ? blocks : 0;
+        else if (b.slots != nullptr) hipLaunchKernelGGL(ln_fold_kernel, dim3((2 * a.H / 4 + 3) / 4), dim3(256), 0, st, b.slots, blocks, a.H, a.dgamma, a.dbeta);
+        return RL_LAUNCH_CHECK();
+      }
       blocks = groups < g_ln_bwd_blocks ? groups : g_ln_bwd_blocks;
       if (blocks <= 96 || a.dgamma == nullptr || a.dbeta == nullptr) b.slots = nullptr; else b.slots = a.slots;
       const size_t lds = (size_t)5 * a.H * sizeof(float);
@@ -1310,46 +1556,64 @@ template int gather_rows<bf16_t>(hipStream_t, const bf16_t*, const int*, const i
 template int gather_rows<float>(hipStream_t, const float*, const int*, const int*, int, int, float*);
 // out[row] = inv[row] >= 0 ? in[inv[row]] * dropout(row, c) : 0   (the inverse of the gather, fused with the dropout map of the site)
 template <typename T>
-__global__ void scatter_rows_drop_kernel(const T* __restrict__ in, const int* __restrict__ inv, int H, T* __restrict__ out, DropParams d) {
+__global__ void scatter_rows_drop_kernel(const T* __restrict__ in, const int* __restrict__ inv, int H, T* __restrict__ out, DropParams d,
+                                         const float* __restrict__ scale_dev) {
   const int row = blockIdx.x, j = inv[row];
+  const float sc = scale_dev != nullptr ? *scale_dev : 1.0f;
   for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
     floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
-    if (j >= 0) v = load4<T>(in + (int64_t)j * H + c) * drop_mult4(d.seed, d.thresh, d.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c);
+    if (j >= 0) v = load4<T>(in + (int64_t)j * H + c) * drop_mult4(d.seed, d.thresh, d.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c) * sc;
     store4<T>(out + (int64_t)row * H + c, v);
   }
 }
-template <typename T> int scatter_rows_drop(hipStream_t st, const T* in, const int* inv, int rows, int H, T* out, DropParams d) {
+template <typename T> int scatter_rows_drop(hipStream_t st, const T* in, const int* inv, int rows, int H, T* out, DropParams d, const float* scale_dev) {
   if (H & 3) return RL_ERR_ARG;
-  hipLaunchKernelGGL((scatter_rows_drop_kernel<T>), dim3(rows), dim3(192), 0, st, in, inv, H, out, d);
+  hipLaunchKernelGGL((scatter_rows_drop_kernel<T>), dim3(rows), dim3(192), 0, st, in, inv, H, out, d, scale_dev);
   return RL_LAUNCH_CHECK();
 }
 // the same scatter fed by the fp32 partial planes of a split-K GEMM: out[row] = inv[row] >= 0 ? (sum_s slab[s][inv[row]]) * dropout : 0,
 // planes added in index order (bit-reproducible)
 template <typename T>
 __global__ void scatter_rows_drop_slab_kernel(const float* __restrict__ slab, int nsplit, int64_t stride, const int* __restrict__ inv, int H,
-                                              T* __restrict__ out, DropParams d) {
+                                              T* __restrict__ out, DropParams d, const float* __restrict__ scale_dev) {
   const int row = blockIdx.x, j = inv[row];
+  const float sc = scale_dev != nullptr ? *scale_dev : 1.0f;
   for (int c = threadIdx.x * 4; c < H; c += blockDim.x * 4) {
     floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
     if (j >= 0) {
       const float* p = slab + (int64_t)j * H + c;
       v = *(const floatx4*)p;
       for (int s = 1; s < nsplit; ++s) v += *(const floatx4*)(p + s * stride);
-      v *= drop_mult4(d.seed, d.thresh, d.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c);
+      v *= drop_mult4(d.seed, d.thresh, d.scale, (uint32_t)row * (uint32_t)H + (uint32_t)c) * sc;
     }
     store4<T>(out + (int64_t)row * H + c, v);
   }
 }
 template <typename T> int scatter_rows_drop_slab(hipStream_t st, const float* slab, int nsplit, int64_t stride, const int* inv, int rows, int H, T* out,
-                                                 DropParams d) {
+                                                 DropParams d, const float* scale_dev) {
   if ((H & 3) || nsplit < 1) return RL_ERR_ARG;
-  hipLaunchKernelGGL((scatter_rows_drop_slab_kernel<T>), dim3(rows), dim3(192), 0, st, slab, nsplit, stride, inv, H, out, d);
+  hipLaunchKernelGGL((scatter_rows_drop_slab_kernel<T>), dim3(rows), dim3(192), 0, st, slab, nsplit, stride, inv, H, out, d, scale_dev);
   return RL_LAUNCH_CHECK();
 }
-template int scatter_rows_drop_slab<bf16_t>(hipStream_t, const float*, int, int64_t, const int*, int, int, bf16_t*, DropParams);
-template int scatter_rows_drop_slab<float>(hipStream_t, const float*, int, int64_t, const int*, int, int, float*, DropParams);
-template int scatter_rows_drop<bf16_t>(hipStream_t, const bf16_t*, const int*, int, int, bf16_t*, DropParams);
-template int scatter_rows_drop<float>(hipStream_t, const float*, const int*, int, int, float*, DropParams);
+template int scatter_rows_drop_slab<bf16_t>(hipStream_t, const float*, int, int64_t, const int*, int, int, bf16_t*, DropParams, const float*);
+template int scatter_rows_drop_slab<float>(hipStream_t, const float*, int, int64_t, const int*, int, int, float*, DropParams, const float*);
+template int scatter_rows_drop<bf16_t>(hipStream_t, const bf16_t*, const int*, int, int, bf16_t*, DropParams, const float*);
+template int scatter_rows_drop<float>(hipStream_t, const float*, const int*, int, int, float*, DropParams, const float*);
+
+// x *= *scale_dev (n % 4 == 0): the dense-classifier fallback of the incoming loss gradient (engine.hip stage_head)
+template <typename T>
+__global__ void __launch_bounds__(256) scale_dev_kernel(T* __restrict__ x, int64_t n4, const float* __restrict__ scale_dev) {
+  const float sc = *scale_dev;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) store4<T>(x + 4 * i, load4<T>(x + 4 * i) * sc);
+}
+template <typename T> int scale_by_dev(hipStream_t st, T* x, int64_t n, const float* scale_dev) {
+  if ((n & 3) || scale_dev == nullptr) return RL_ERR_ARG;
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL((scale_dev_kernel<T>), dim3((int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)), dim3(256), 0, st, x, n4, scale_dev);
+  return RL_LAUNCH_CHECK();
+}
+template int scale_by_dev<bf16_t>(hipStream_t, bf16_t*, int64_t, const float*);
+template int scale_by_dev<float>(hipStream_t, float*, int64_t, const float*);
 
 // ---------------------------------------------------------------------------------------------
 // Gate fusion (models.py:840-850).  The [T, 4H] concat is never materialised.
@@ -1369,7 +1633,8 @@ __global__ void __launch_bounds__(256) gate_mean_kernel(GateArgs<T> a) {
   for (int s = rl; s < a.S; s += 4) {
     const float m = (float)a.masks[b * a.S + s];
     ms += m;
-    if (c < a.H) acc += load4<T>(a.bert + ((int64_t)b * a.S + s) * a.H + c) * m;
+    // (select, not multiply: a masked row of a live-row step holds whatever an earlier step left there - 0 * NaN must not get in)
+    if (c < a.H && m != 0.f) acc += load4<T>(a.bert + ((int64_t)b * a.S + s) * a.H + c) * m;
   }
   part[rl][q] = acc;
   if (q == 0) mpart[rl] = ms;
@@ -1433,6 +1698,16 @@ __global__ void __launch_bounds__(256) gate_bwd_token_kernel(GateArgs<T> a) {
   const int row = blockIdx.x * 4 + wave;
   if (row >= a.B * a.S) return;
   const int H = a.H;
+  if (a.row_live != nullptr && a.row_live[row] == 0) {      // padding row: d fused is an exact zero, so is everything derived from it
+    if (lane == 0) *(floatx4*)(a.dz + (int64_t)row * 4) = floatx4{0.f, 0.f, 0.f, 0.f};
+    const floatx4 z4 = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < H) { store4<T>(a.dbert + (int64_t)row * H + c, z4); store4<T>(a.dpho + (int64_t)row * H + c, z4); store4<T>(a.dres + (int64_t)row * H + c, z4); }
+    }
+    return;
+  }
   floatx4 df[LN_MAXV];
   float dg[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -1530,6 +1805,7 @@ __global__ void __launch_bounds__(256) gate_dw_kernel(GateArgs<T> a, int rows_pe
   if (c < H) {
     for (int r = r0 + ry; r < r1; r += 8) {
       const floatx4 dz = *(const floatx4*)(a.dz + (int64_t)r * 4);
+      if (dz[0] == 0.f && dz[1] == 0.f && dz[2] == 0.f) continue;      // padding rows (and any other all-zero row): nothing to add, nothing read
       const floatx4 x[3] = {load4<T>(a.bert + (int64_t)r * H + c), load4<T>(a.pho + (int64_t)r * H + c), load4<T>(a.res + (int64_t)r * H + c)};
 #pragma unroll
       for (int s = 0; s < 3; ++s)

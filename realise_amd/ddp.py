@@ -63,24 +63,29 @@ class _GradSync:
         return b
 
     def _launch_mesh(self, i):
-        """direct reduce-scatter + all-gather of bucket i (pre-divided like the all-reduce forms: the shard sum IS the mean)"""
+        """direct reduce-scatter + all-gather of bucket i.  fp32 wire: the raw gradients cross the links and the 1 / W rides on the
+        owner's shard sum - a pass over 1 / W of the bucket instead of a pre-divide pass over all of it.
+        bf16 wire: the narrowing pass exists anyway and carries the 1 / W (overflow-safe), the shard sum IS the mean."""
         buf, w = self.buckets[i], self.world
         if self.wire is not None:
             torch.mul(buf, 1.0 / w, out=self.wire[i])
-            src = self.wire[i]
+            src, post = self.wire[i], None
         else:
-            buf.div_(w)
-            src = buf
+            src, post = buf, 1.0 / w
         for k, c in enumerate(self._chunks(src)):
             n = c.numel() - c.numel() % w
             if n:
                 recv, acc, narrow = self._mesh_bufs((i, k), n, c.dtype, c.device)
                 dist.all_to_all_single(recv, c[:n], group=self.group)              # row r of recv = rank r's copy of my shard
                 torch.sum(recv.view(w, n // w), dim=0, dtype=torch.float32, out=acc)
+                if post is not None:
+                    acc.mul_(post)
                 if narrow is not None:
                     narrow.copy_(acc)
                 self.works.append((i, dist.all_gather_into_tensor(c[:n], acc if narrow is None else narrow, group=self.group, async_op=True)))
             if n != c.numel():                                                      # fewer than W trailing elements
+                if post is not None:
+                    c[n:].mul_(post)
                 self.works.append((i, dist.all_reduce(c[n:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
 
     def _launch(self, i):

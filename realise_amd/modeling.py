@@ -376,9 +376,9 @@ class RealiseModule(nn.Module):
             lib.realise_engine_invalidate_frozen(self._engine)
             self._frozen_version = ver[1]
         if self.training or not self.static_weights or self._shadow_version != ver:
-            # FusedAdamW's step wrote the Linear weights' operand copies in the pass that updated them (realise_engine_adamw): what is
-            # left to re-derive is the conv-weight copies.  Anything else that touched the parameters since (a raw p.data write) must
-            # call mark_parameters_updated(), or the module run with trust_fused_optimizer = False (the full refresh, every forward).
+            # Only a loop that OWNS every parameter write opts into `trust_fused_optimizer` (trainer.train(), bench.py): FusedAdamW's step
+            # then wrote the Linear weights' operand copies in the pass that updated them (realise_engine_adamw) and what is left to
+            # re-derive is the conv-weight copies.  The default (False) keeps the guarantee of the comment above: every copy, every forward.
             linear_current = 1 if (self._linear_copies_current and self.trust_fused_optimizer) else 0
             _capi.check(lib.realise_engine_refresh_shadows_ex(self._engine, self._stream(), linear_current), "realise_engine_refresh_shadows")
             self._linear_copies_current = False
@@ -389,11 +389,11 @@ class RealiseModule(nn.Module):
         step and flagged it (include/realise_hip.h: realise_engine_set_id_flag)"""
         f = getattr(self, "_id_flag", None)
         if f is not None and int(f[1]) != 0:
-            f.zero_()
+            f[1] = 0                          # (only the flag being reported: a bad id seen in the same window still raises below / next time)
             raise RuntimeError("a workgroup of the fused dense + LayerNorm launch gave up waiting for the other tiles of its rows in an "
                                "earlier step (results of that step are invalid); realise_set_engine(8, 0) runs the two-launch form")
         if f is not None and int(f[0]) != 0:
-            f.zero_()
+            f[0] = 0
             raise IndexError("index out of range in self: a src_idx outside [0, %d) or a pho_idx outside [0, %d) reached the "
                              "model in an earlier forward" % (self.vocab_size, self._ccfg.pho_vocab))
 
@@ -407,7 +407,10 @@ class RealiseModule(nn.Module):
         torch.cuda.synchronize(self.device)
         self._raise_on_bad_ids()
 
-    trust_fused_optimizer = True        # False: every forward re-derives all operand copies, also right after a FusedAdamW step
+    # False (default): every forward re-derives all operand copies, also right after a FusedAdamW step - a p.data write, an EMA swap or a
+    # second optimizer between step() and forward() is always seen.  True (set by trainer.train() and bench.py, whose loops make no such
+    # write): the forward after a FusedAdamW step trusts the copies that step wrote and re-derives the conv-weight copies only.
+    trust_fused_optimizer = False
     _linear_copies_current = False
 
     def mark_parameters_updated(self, frozen=True, linear_copies_current=False):
@@ -604,9 +607,15 @@ class RealiseModule(nn.Module):
         else:
             self._raise_on_bad_ids()
         self._begin_gradient_pass()
-        if not self.assume_unit_loss_grad:
-            d = self.tap_dlogits()
-            d.mul_(grad_out.to(d.dtype))
+        # the incoming d loss stays on the device: the engine multiplies it into the three gradients that leave the classifier head
+        # (no host read, no pass over the cross-entropy gradient rows); assume_unit_loss_grad skips even that (plain loss.backward())
+        if self.assume_unit_loss_grad or grad_out is None:
+            self._loss_grad_keep = None
+            lib.realise_engine_set_loss_grad(self._engine, None)
+        else:
+            g = grad_out.detach().to(device=self.device, dtype=torch.float32).reshape(1).contiguous()
+            self._loss_grad_keep = g              # (kept alive until the next backward replaces it: the kernels read it later)
+            lib.realise_engine_set_loss_grad(self._engine, g.data_ptr())
         st = self._stream()
         n = len(self._buckets)
         if self.grad_sync is None:

@@ -64,6 +64,10 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
               {"params": [p for n, p in model.named_parameters() if p.requires_grad and any(nd in n for nd in no_decay)],
                "weight_decay": 0.0}]
     opt = FusedAdamW(model, groups, lr=lr, eps=adam_epsilon, max_grad_norm=max_grad_norm)
+    # this loop owns every parameter write between opt.step() and the next forward: the step's operand copies can be trusted
+    # (modeling.py: trust_fused_optimizer; the module default re-derives every copy on every forward)
+    trusted_before = model.trust_fused_optimizer
+    model.trust_fused_optimizer = True
     steps_total = max(1, len(items) // batch_size * epochs)          # t_total of run.py:142-144 (floor)
     sched = get_linear_schedule_with_warmup(opt, warmup_steps, steps_total)
     tr_loss = torch.zeros((), device=device)
@@ -91,6 +95,8 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
             step += 1
             if log_every and step % log_every == 0:
                 print("Step: %d, LR: %.3e, Loss: %.5f" % (step, sched.get_last_lr()[0], tr_loss.item() / step))
+    model.trust_fused_optimizer = trusted_before
+    model.mark_parameters_updated(frozen=False)       # whatever runs next re-derives every operand copy
     if hasattr(model, "check_ids"):
         model.check_ids()                  # a bad id in the last batches must not go unreported
     return tr_loss.item() / max(1, step)

@@ -105,6 +105,7 @@ def test_fused_adamw_writes_the_operand_copies_it_updates(dtype):
                   {"params": [p for n, p in m.named_parameters() if p.requires_grad and any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
         opt = FusedAdamW(m, groups, lr=1e-3, eps=1e-6, max_grad_norm=1.0)
         opt.fused_operand_copies = fused
+        m.trust_fused_optimizer = fused         # (round 5: the module default is False; a loop that owns every parameter write opts in)
         losses = []
         for _ in range(3):
             m.zero_grad()

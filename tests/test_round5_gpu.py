@@ -1,0 +1,281 @@
+"""GPU tests added in round 5: the incoming loss gradient as a device scalar (no pass over the logits gradient), the safe default of the
+fused optimizer's operand copies, live-row steps under the non-default weight-gradient knobs, stale non-finite rows of
+a live-row step, and this round's kernels."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from realise_amd import _capi
+from realise_amd.config import RealiseConfig
+from realise_amd.data import synthetic_batch
+from realise_amd.init import init_state_dict_numpy
+from realise_amd.modeling import SpellBertPho2ResArch3
+
+pytestmark = pytest.mark.gpu
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def build(cfg, sd_np, dtype, train=False, **kw):
+    m = SpellBertPho2ResArch3(cfg, compute_dtype=dtype, **kw)
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()})
+    m.to("cuda")
+    m.train(train)
+    return m
+
+
+def cuda_batch(B, S, seed):
+    b = synthetic_batch(B, S, seed=seed)
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+def grads_of(m):
+    return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_loss_gradient_is_applied_as_a_device_scalar(dtype):
+    """loss.backward() hands d loss to the engine as a DEVICE scalar (realise_engine_set_loss_grad): the classifier head's three
+    gradients are scaled in the kernels that store them, the cross-entropy gradient rows are not touched.  (a) grad_output = 1 gives
+    bit for bit what assume_unit_loss_grad gives on every order-fixed gradient; (b) (0.5 * loss).backward() gives exactly half of
+    every gradient (a power of two commutes with every rounding on the way); (c) the saved logits gradient is left alone."""
+    cfg = RealiseConfig(num_hidden_layers=2, pho_layers=1, out_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = init_state_dict_numpy(cfg, seed=5)
+    batch = cuda_batch(8, 64, 21)
+
+    def run(scale, assume):
+        m = build(cfg, sd, dtype, train=True)
+        m.assume_unit_loss_grad = assume
+        m.zero_grad()
+        loss, _ = m(batch)
+        d0 = m.tap_dlogits().clone()
+        (loss * scale if scale != 1.0 else loss).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(d0, m.tap_dlogits()), "the logits gradient rows were rewritten"
+        return grads_of(m)
+
+    g_assume, g_one, g_half = run(1.0, True), run(1.0, False), run(0.5, False)
+    atomics = ("embeddings", "pho_embeddings", "gru", "gate", "LayerNorm", "bn", "shortcut.1")      # float atomics / order not fixed
+    for n in g_assume:
+        s = g_assume[n].abs().max().item()
+        tol = 0.0 if not any(a in n for a in atomics) else 2e-5 * s + 1e-12
+        assert (g_assume[n] - g_one[n]).abs().max().item() <= (tol if tol else 2e-6 * s + 1e-12), n
+        assert (0.5 * g_assume[n] - g_half[n]).abs().max().item() <= 2e-5 * s + 1e-12, n
+    head = "classifier.bias"
+    assert torch.equal(g_assume[head], g_one[head]) or (g_assume[head] - g_one[head]).abs().max().item() <= 1e-6 * g_assume[head].abs().max().item()
+    assert g_half[head].abs().max().item() > 0.0
+
+
+def test_fused_optimizer_default_sees_a_raw_parameter_write():
+    """the module default re-derives every operand copy on every forward, also right after a FusedAdamW step, so a
+    p.data write between opt.step() and the next forward is seen; a loop that opts into trust_fused_optimizer (trainer.train(),
+    bench.py) and makes such a write must call mark_parameters_updated()."""
+    from realise_amd.optim import FusedAdamW
+    cfg = RealiseConfig(num_hidden_layers=1, pho_layers=1, out_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = init_state_dict_numpy(cfg, seed=2)
+    batch = cuda_batch(4, 32, 3)
+
+    def run(trust, mark):
+        m = build(cfg, sd, "bf16", train=True)
+        assert m.trust_fused_optimizer is False            # the class default
+        m.trust_fused_optimizer = trust
+        opt = FusedAdamW(m, [{"params": [p for p in m.parameters() if p.requires_grad], "weight_decay": 0.0}], lr=1e-4, eps=1e-8)
+        m.zero_grad()
+        m(batch)[0].backward()
+        opt.step()
+        w = dict(m.named_parameters())["bert.encoder.layer.0.intermediate.dense.weight"]
+        w.data.zero_()                                     # a write torch's version counters do not see
+        if mark:
+            m.mark_parameters_updated()
+        m.eval()
+        with torch.no_grad():
+            out = m(batch)[1].float().clone()
+        torch.cuda.synchronize()
+        return out
+
+    seen_default, stale_trusted, seen_marked = run(False, False), run(True, False), run(True, True)
+    assert torch.equal(seen_default, seen_marked)
+    assert not torch.equal(seen_default, stale_trusted), "the trusted run was expected to miss the raw write (that is what the flag trades)"
+
+
+@pytest.mark.parametrize("knob", ["wgrad_group", "tn_group_ring"])
+def test_live_row_step_under_the_other_weight_gradient_forms(knob):
+    """only the grouped two-stage weight-gradient launch walks the live-block list.  With the grouped launch off the
+    step must not run live rows at all (the dense weight gradients would sum stale rows); with the four-stage ring requested the listed
+    launch keeps the two-stage ring.  Either way every gradient equals the default configuration's."""
+    lib = _capi.load()
+    cfg = RealiseConfig(num_hidden_layers=2, pho_layers=1, out_layers=1)
+    sd = init_state_dict_numpy(cfg, seed=11)
+    batch = cuda_batch(8, 64, 17)
+    setter = lib.realise_set_wgrad_group if knob == "wgrad_group" else lib.realise_set_tn_group_ring
+    default, other = (1, 0) if knob == "wgrad_group" else (0, 1)
+
+    def step(v):
+        setter(v)
+        try:
+            m = build(cfg, sd, "bf16", train=True)
+            out = []
+            for _ in range(2):                 # the second step meets stale rows in the workspace
+                m.zero_grad()
+                loss, _ = m(batch)
+                loss.backward()
+                torch.cuda.synchronize()
+                out.append((float(loss.item()), grads_of(m)))
+            return out
+        finally:
+            setter(default)
+
+    a, b = step(default), step(other)
+    for (l0, g0), (l1, g1) in zip(a, b):
+        assert l0 == l1
+        for n in g0:
+            s = g0[n].abs().max().item()
+            assert torch.isfinite(g1[n]).all(), n
+            # (ungrouped weight gradients split their reductions: another summation order, so not bit for bit)
+            assert (g0[n] - g1[n]).abs().max().item() <= 2e-3 * s + 1e-12, n
+
+
+def test_stale_non_finite_rows_do_not_reach_a_live_row_step():
+    """A live-row step does not rewrite the activation rows behind a sentence's last live position; whatever an earlier step left
+    there - here NaN, written through the activation taps between two steps - is selected away, never multiplied by zero
+    (masked mean, gate gradients): loss and every gradient equal the undisturbed second step's."""
+    cfg = RealiseConfig(num_hidden_layers=2, pho_layers=1, out_layers=1)
+    sd = init_state_dict_numpy(cfg, seed=13)
+    B, S = 8, 64
+    batch = cuda_batch(B, S, 19)
+    masks = batch["masks"].bool() | batch["loss_masks"].bool()
+    last = torch.where(masks.any(1), S - masks.flip(1).float().argmax(1), torch.zeros(B, dtype=torch.long, device="cuda"))
+    dead = ~(torch.arange(S, device="cuda")[None, :] < last[:, None]).reshape(-1)
+    # a 16-row block with a live row is computed whole: poison only the rows of blocks that hold no live row
+    blk_dead = dead.view(-1, 16).all(1).repeat_interleave(16)
+    assert blk_dead.any()
+
+    def run(poison):
+        m = build(cfg, sd, "bf16", train=True)
+        out = []
+        for it in range(2):
+            m.zero_grad()
+            loss, _ = m(batch)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((float(loss.item()), grads_of(m)))
+            if poison and it == 0:
+                # what a live-row step leaves alone in the blocks without a live row: the GEMM outputs (qkv, the pre-LayerNorm sums, the
+                # FFN activations) and the attention output; the LayerNorm outputs of those rows are recomputed from the poisoned sums
+                names = ["%s.layer.%d.%s" % (st, l, t) for st, n in (("bert", 2), ("pho_model", 1), ("output_block", 1)) for l in range(n)
+                         for t in ("qkv", "ctx", "inter", "sum1", "sum2")]
+                for name in names:
+                    m.tap(name).view(B * S, -1)[blk_dead] = float("nan")
+                torch.cuda.synchronize()
+        return out
+
+    clean, dirty = run(False), run(True)
+    assert clean[1][0] == dirty[1][0] and np.isfinite(dirty[1][0])
+    for n in clean[1][1]:
+        s = clean[1][1][n].abs().max().item()
+        assert torch.isfinite(dirty[1][1][n]).all(), n
+        assert (clean[1][1][n] - dirty[1][1][n]).abs().max().item() <= 5e-5 * s + 1e-12, n
+
+
+@pytest.mark.parametrize("rows,H,live_frac,drop,blocks", [(8192, 768, 0.65, 0.1, 0), (8192, 768, 1.0, 0.0, 0), (8192, 768, 0.65, 0.1, 128),
+                                                          (5000, 768, 0.5, 0.1, 0), (8192, 1024, 0.8, 0.1, 0), (8192, 256, 0.3, 0.0, 0),
+                                                          (1024, 768, 0.0, 0.1, 0), (200, 768, 0.7, 0.1, 0)])
+def test_layernorm_backward_round5_kernel_against_round4_and_fp32(rows, H, live_frac, drop, blocks):
+    """ln_bwd16v2_kernel (realise_set_ln(5, 1), default): asm row loads behind counted vmcnt waits, four rows of a wave in flight,
+    DPP row sums, branch-free padding rows (their loads parked beyond the buffer), one-barrier epilogue.  Against the round-4 kernel
+    (same arithmetic, another summation order: bf16 outputs within one rounding step, dgamma / dbeta to fp32 rounding) and against
+    fp32 autograd of the same LayerNorm; the xhat rows of padding tokens hold NaN - stale as can be - and must not be read into
+    anything."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(rows + H)
+    x = (torch.randn(rows, H, generator=g) * 1.5 + 0.3).cuda()
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).cuda()
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = (1.0 / torch.sqrt(var + 1e-12)).reshape(-1).contiguous()
+    xhat = ((x - mean) * rstd[:, None]).bfloat16()
+    live = (torch.rand(rows, generator=g) < live_frac).cuda()
+    dy = (torch.randn(rows, H, generator=g) * 0.05).cuda().bfloat16()
+    dy[~live] = 0
+    xh_in = xhat.clone()
+    xh_in[~live] = float("nan")
+    row_live = live.to(torch.uint8).contiguous()
+    slots = torch.empty(2 * 1024 * 1024, device="cuda")
+    thresh, scale = (int(drop * 4294967296.0), 1.0 / (1.0 - drop)) if drop > 0 else (0, 1.0)
+
+    def run(v2):
+        lib.realise_set_ln(5, v2)
+        lib.realise_set_ln(1, blocks)
+        try:
+            dx = torch.full((rows, H), 7.0, device="cuda").bfloat16()
+            dxd = torch.full((rows, H), 7.0, device="cuda").bfloat16()
+            dg, db = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+            _capi.check(lib.realise_layernorm_bwd_live(stream(), P(dy), P(xh_in), P(rstd), P(gamma), P(dx), P(dxd), 77, thresh, C.c_float(scale),
+                                                       P(dg), P(db), P(slots), P(row_live), rows, H), "ln_bwd_live")
+            torch.cuda.synchronize()
+            return dx, dxd, dg, db
+        finally:
+            lib.realise_set_ln(1, 0)
+            lib.realise_set_ln(5, 1)
+
+    new, old = run(1), run(0)
+    for t in new:
+        assert torch.isfinite(t.float()).all()
+    # padding rows: exact zeros in both outputs
+    assert (new[0][~live] == 0).all() and (new[1][~live] == 0).all()
+    # against the round-4 kernel
+    for a, b, name in zip(new[:2], old[:2], ("dx", "dx_drop")):
+        d = (a.float() - b.float()).abs()
+        assert (d <= 2.0 ** -7 * b.float().abs() + 1e-6).all(), (name, d.max().item())
+        assert (d > 0).float().mean().item() < 0.02, name           # a different last bit is rare
+    if drop > 0:
+        keep = new[1] != 0
+        assert torch.equal(keep, old[1] != 0) or ((keep != (old[1] != 0)) & (new[0] != 0)).sum().item() == 0
+        assert abs(keep[live].float().mean().item() - (1 - drop)) < 0.01 or not live.any()
+    for a, b, name in zip(new[2:], old[2:], ("dgamma", "dbeta")):
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-6, name
+    # against fp32 autograd on the same (bf16-rounded) inputs
+    xf = xhat.float()[live]
+    dyf = dy.float()[live]
+    t = dyf * gamma
+    ref_dx = rstd[live, None] * (t - t.mean(1, keepdim=True) - xf * (t * xf).mean(1, keepdim=True))
+    if live.any():
+        assert (new[0].float()[live] - ref_dx).abs().max().item() <= 1e-2 * ref_dx.abs().max().item() + 1e-6
+        assert (new[2] - (dyf * xf).sum(0)).abs().max().item() <= 1e-3 * (dyf * xf).sum(0).abs().max().item() + 1e-5
+        assert (new[3] - dyf.sum(0)).abs().max().item() <= 1e-3 * dyf.sum(0).abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("rows,H", [(8192, 768), (37, 768), (1000, 256)])
+def test_layernorm_forward_dpp_row_sums(rows, H):
+    """ln_fwd16 with the DPP half-wave sums (realise_set_ln(5, 1)) against the ds_bpermute form: y / xhat within one bf16 rounding step, rstd
+    to fp32 rounding."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, H, generator=g) * 2 + 0.5).cuda().bfloat16()
+    gamma = (1 + 0.1 * torch.randn(H, generator=g)).cuda()
+    beta = (0.1 * torch.randn(H, generator=g)).cuda()
+
+    def run(v2):
+        lib.realise_set_ln(5, v2)
+        try:
+            y, xh, rs = torch.empty_like(x), torch.empty_like(x), torch.empty(rows, device="cuda")
+            _capi.check(lib.realise_layernorm_fwd(stream(), 1, P(x), P(gamma), P(beta), C.c_float(1e-12), P(y), P(xh), P(rs), rows, H), "ln")
+            torch.cuda.synchronize()
+            return y, xh, rs
+        finally:
+            lib.realise_set_ln(5, 1)
+
+    a, b = run(1), run(0)
+    assert (a[2] - b[2]).abs().max().item() <= 1e-5 * b[2].abs().max().item()
+    for u, v in zip(a[:2], b[:2]):
+        d = (u.float() - v.float()).abs()
+        assert (d <= 2.0 ** -7 * v.float().abs() + 1e-6).all()
+    ref = torch.nn.functional.layer_norm(x.float(), (H,), gamma, beta, 1e-12)
+    assert (a[0].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
