@@ -272,10 +272,23 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
     // the launch is sized for every block being live; the XCD split is made over the tiles that exist (made over the nominal count,
     // the surplus tiles - the tail of the logical order - would all sit on the last XCDs and leave them idle)
     nlive = *ep.live_count;
-    const int ntl = ((nlive + C::BM / 16 - 1) / (C::BM / 16)) * tiles_n;
-    if ((int)blockIdx.x >= ntl) return;                     // (the whole workgroup leaves before any barrier)
-    tile = xcd_remap(blockIdx.x, ntl);
-    tile_coords(tile, tiles_n, ntl, group_m, tm, tn);
+    const int tml = (nlive + C::BM / 16 - 1) / (C::BM / 16);      // live tile rows
+    const int ntl = tml * tiles_n;
+    if (ep.xcd_gc > 1) {
+      // 2-D XCD split (EpiParams::xcd_gc): XCD x = blockIdx % 8 (as dispatched today; another placement changes speed only) works on row
+      // group x / gc x column group x % gc, row-major inside it
+      const int gc = ep.xcd_gc, gr = 8 / gc, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+      const int rg = x / gc, cg = x - rg * gc, ncl = tiles_n / gc;
+      const int r0 = (rg * tml) / gr, r1 = ((rg + 1) * tml) / gr;
+      if (j >= (r1 - r0) * ncl) return;                     // (the whole workgroup leaves before any barrier)
+      const int lr = j / ncl;
+      tm = r0 + lr; tn = cg * ncl + (j - lr * ncl);
+      tile = tm * tiles_n + tn;
+    } else {
+      if ((int)blockIdx.x >= ntl) return;                   // (the whole workgroup leaves before any barrier)
+      tile = xcd_remap(blockIdx.x, ntl);
+      tile_coords(tile, tiles_n, ntl, group_m, tm, tn);
+    }
   } else {
     tile_coords(tile, tiles_n, ntiles, group_m, tm, tn);
   }
@@ -507,7 +520,9 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
     if (g_nt8_probe == 3) { RL_LAUNCH((gemm_nt8_kernel<C, 3>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
   }
 #endif
-  RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL, XEPI>), dim3(ntiles * (KTAIL || ep.ksplit < 1 ? 1 : ep.ksplit)), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
+  int grid = ntiles * (KTAIL || ep.ksplit < 1 ? 1 : ep.ksplit);
+  if constexpr (XEPI == 3) { if (ep.xcd_gc > 1) grid = (tiles_m + 8 / ep.xcd_gc) * tiles_n; }      // every row group rounded up to whole tile rows
+  RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL, XEPI>), dim3(grid), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -792,11 +807,24 @@ int gemm_nt8_gru(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, 
 }
 
 // the M dimension as a list of live 16-row blocks (EpiParams::live_list / live_count): see gemm.h
+static int g_nt8_live_gc = 0;
+void set_nt8_live_gc(int gc) { g_nt8_live_gc = (gc == 1 || gc == 2 || gc == 4 || gc == 8) ? gc : 0; }
 int gemm_nt8_live(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep) {
   if (ep.live_list == nullptr || ep.live_count == nullptr || ep.m_dev != nullptr || ep.slab != nullptr || ep.rm_hw_shift >= 0 ||
       ep.ln_y != nullptr || ep.gru_table != nullptr || (K % 64) != 0 || (M % 16) != 0 || M < 16 || !nt8_supported(M, N, K, ep, lda, ldb))
     return RL_ERR_ARG;
-  return launch_nt8_cfg<Cfg128x192q, false, 3>(st, A, lda, B, ldb, M, N, K, ep);
+  EpiParams<bf16_t> e2 = ep;
+  // XCD split.  One row band per XCD streams the WHOLE weight panel through each of the eight L2s; a panel beyond ~2 MB (N x K x 2 B:
+  // 3.5 MB qkv, 4.7 MB FFN-up) does not stay resident next to the A rows and is re-read per wave of workgroups.  With column groups
+  // the slice an XCD needs (panel / gc) stays resident and the A rows are read by gc XCDs: traffic gc x A + (8 / gc) x W - for the
+  // wide K = 768 outputs (A 9 MB) two groups are the minimum, for the N = 768 outputs (A 27-36 MB at K = 2304 / 3072) one is.
+  const int tiles_n = (N + 191) / 192;
+  int gc = 1;
+  if ((int64_t)N * K * 2 > (int64_t)(2 << 20) && (int64_t)M * K < (int64_t)N * K * 4) gc = 2;
+  if (g_nt8_live_gc) gc = g_nt8_live_gc;
+  while (gc > 1 && (tiles_n % gc) != 0) gc >>= 1;
+  e2.xcd_gc = gc;
+  return launch_nt8_cfg<Cfg128x192q, false, 3>(st, A, lda, B, ldb, M, N, K, e2);
 }
 
 int gemm_nt8_splitk(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, int nsplit,

@@ -279,3 +279,20 @@ def test_layernorm_forward_dpp_row_sums(rows, H):
         assert (d <= 2.0 ** -7 * v.float().abs() + 1e-6).all()
     ref = torch.nn.functional.layer_norm(x.float(), (H,), gamma, beta, 1e-12)
     assert (a[0].float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("gc", [1, 2, 4])
+@pytest.mark.parametrize("M,N,K,mode,accumulate,blocks", [(8192, 2304, 768, 0, 0, "ragged"), (8192, 3072, 768, 1, 0, "ragged"),
+                                                          (8192, 768, 3072, 2, 0, "ragged"), (2048, 768, 768, 0, 0, "all"),
+                                                          (1024, 768, 768, 2, 0, "one"), (1024, 768, 768, 0, 1, "none")])
+def test_live_row_gemm_under_every_xcd_split(gc, M, N, K, mode, accumulate, blocks):
+    """EpiParams::xcd_gc (realise_set_nt8p(3, gc)): the 2-D XCD split of the live-row GEMM only changes WHICH workgroup computes a
+    tile - every listed row carries the dense launch's bits, unlisted rows are untouched - for every split the shapes divide into
+    (the default picks 2 column groups for the wide K = 768 outputs)."""
+    import test_round4_gpu as r4
+    lib = _capi.load()
+    lib.realise_set_nt8p(3, gc)
+    try:
+        r4.test_nt_gemm_over_a_list_of_live_row_blocks(M, N, K, mode, accumulate, blocks)
+    finally:
+        lib.realise_set_nt8p(3, 0)

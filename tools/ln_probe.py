@@ -47,12 +47,21 @@ def bwd(i, drop=True):
                                  C.c_float(1.0 / 0.9), p(dg), p(db), p(slots), R, H)
 
 
-for fast in (0, 1):
-    lib.realise_set_ln(0, fast)
-    print("fast %d: ln_fwd %.1f us (38 MB -> %.2f TB/s)" % (fast, timeit(fwd), 37.7e6 / timeit(fwd) / 1e6))
-    for blocks in ((0,) if not fast else (256, 512, 768, 1024, 2048)):
-        if blocks:
-            lib.realise_set_ln(1, blocks)
-        t = timeit(bwd)
-        print("fast %d blocks %4d: ln_bwd + fold %.1f us (50 MB -> %.2f TB/s)" % (fast, blocks, t, 50.3e6 / t / 1e6))
-lib.realise_set_ln(0, 1); lib.realise_set_ln(1, 512)
+live = (torch.rand(R, device=dev) < 0.65).to(torch.uint8)
+
+
+def bwd_live(i):
+    lib.realise_layernorm_bwd_live(st(), p(dy[i]), p(x[i]), p(rstd), p(gamma), p(o1[i]), p(o2[i]), 77, 429496730, C.c_float(1.0 / 0.9), p(dg), p(db),
+                                   p(slots), p(live), R, H)
+
+
+# round 5: v2 = asm row loads behind counted waits + DPP row sums + one-barrier epilogue (realise_set_ln(5, 1)); v1 = the round-4 kernels
+for v2 in (0, 1):
+    lib.realise_set_ln(5, v2)
+    print("v2 %d: ln_fwd %.1f us" % (v2, timeit(fwd)))
+    for blocks in ((256, 512, 768) if not v2 else (64, 128, 256, 512)):
+        lib.realise_set_ln(1, blocks)
+        t, tl = timeit(bwd), timeit(bwd_live)
+        print("v2 %d blocks %4d: ln_bwd + fold dense %.1f us (50 MB -> %.2f TB/s); 65 %% live rows %.1f us" % (v2, blocks, t, 50.3e6 / t / 1e6, tl))
+    lib.realise_set_ln(1, 0)
+lib.realise_set_ln(5, 1)
