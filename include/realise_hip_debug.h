@@ -89,7 +89,9 @@ int realise_batchnorm_bwd_ex(void* stream, const void* dy, const void* relu_src,
 /* persistent NT kernel (gemm_nt8p.hip): key 0 = tile walk (1 default: every XCD owns a band of tile rows, 0: chunked tile ids),
  * key 1 = workgroups launched (default 256 = one per CU); key 2 = one-round outputs (at most one 128 x 192 tile per CU) on the
  * three-stage one-per-CU shape (1) or the two-per-CU shape (0, default: faster inside a step) of gemm_nt8.hip; key 3 = column groups of
- * the XCD split of the live-row layer GEMMs (0 default: from the shape - 2 for the wide K = 768 outputs, 1 otherwise; 1 / 2 / 4 / 8 forced) */
+ * the XCD split of the live-row layer GEMMs (0 default: from the shape - 2 for the wide K = 768 outputs, 1 otherwise; 1 / 2 / 4 / 8 forced);
+ * key 4 = the 8-wave kernels add alpha / bias to the accumulators before the epilogue's transposes (1, default: one bias fetch per wave and no
+ * per-item waits in the bias-only epilogues) or per item (0, the round-4 form) - same bits */
 void realise_set_nt8p(int key, int value);
 void realise_set_nt_group_m(int g);        /* tile order of the 8-wave NT GEMM: 0 row-major, g: g tile rows per column step (L2 blocking) */
 /* Diagnostics for the TN kernel: 2 no operand fetches, 3 no MFMA work, 4 skip the slab fold pass. */

@@ -49,6 +49,7 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_n, int ntiles, i
 
 static int g_nt8_probe = 0;
 void set_nt8_probe(int mode) { g_nt8_probe = mode; }
+static int nt8_bias_first_on();
 
 // ---- K4 epilogue: dropout(acc + bias) + residual, then the LayerNorm of the row, whose columns are spread over the N / BN workgroups
 // of a row band (see EpiParams::ln_*).  Same numbers as the unfused pair (GEMM epilogue -> bf16 -> ln_fwd16) up to the order of the
@@ -465,6 +466,33 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   constexpr int RS = C::RS, ER = C::ER, ITEMS = C::RN / 8, NIT = ER * ITEMS / 64;
   float* et = (float*)smem + wave * (ER * RS);
   const int row_w = m0 + wm * C::RM, col_w = n0 + wn * C::RN;
+  // Round 5 (EpiParams::bias_first, realise_set_nt8p key 4): alpha and the bias go into the accumulators BEFORE the transposes.  In the
+  // MFMA layout a lane holds four consecutive columns of one row per tile, so NT float4 of bias serve all its accumulators - loaded
+  // once, together, while nothing else is pending - instead of two float4 per item behind that item's predecessors' stores (hipcc
+  // waits with vmcnt(0) whenever loads and stores are pending together: every item of a wave paid a bias latency plus the drain of
+  // the stores before it; the bias-only epilogues - qkv, FFN-up - now run their items without a single wait).  Same (acc * alpha) +
+  // bias per element as epilogue8: same bits.
+  EpiParams<bf16_t> epx = ep;
+  if constexpr (!KTAIL) {
+    if (ep.bias_first && ep.slab == nullptr) {
+      if (ep.alpha != 1.0f) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] *= ep.alpha;
+      }
+      if (ep.bias != nullptr) {
+        floatx4 bq[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[j] = *(const floatx4*)(ep.bias + min(col_w + j * 16 + 4 * g, N - 4));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] += bq[j];
+      }
+      epx.alpha = 1.0f; epx.bias = nullptr;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < C::RM / ER; ++c) {
     int row_c = row_w + c * ER;
@@ -489,7 +517,7 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
           *(floatx4*)o = v0; *(floatx4*)(o + 4) = v1;
         }
       } else {
-        epilogue8<T>(ep, M, N, row_c + r, col_w + c8 * 8, v0, v1);
+        epilogue8<T>(epx, M, N, row_c + r, col_w + c8 * 8, v0, v1);
       }
     }
   }
@@ -520,9 +548,11 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
     if (g_nt8_probe == 3) { RL_LAUNCH((gemm_nt8_kernel<C, 3>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
   }
 #endif
+  EpiParams<bf16_t> epk = ep;
+  epk.bias_first = nt8_bias_first_on() && (N % 4) == 0 && N >= 4;
   int grid = ntiles * (KTAIL || ep.ksplit < 1 ? 1 : ep.ksplit);
   if constexpr (XEPI == 3) { if (ep.xcd_gc > 1) grid = (tiles_m + 8 / ep.xcd_gc) * tiles_n; }      // every row group rounded up to whole tile rows
-  RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL, XEPI>), dim3(grid), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep);
+  RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL, XEPI>), dim3(grid), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, epk);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
@@ -807,6 +837,9 @@ int gemm_nt8_gru(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, 
 }
 
 // the M dimension as a list of live 16-row blocks (EpiParams::live_list / live_count): see gemm.h
+static int g_nt8_bias_first = 1;        // alpha / bias into the accumulators before the epilogue's transposes (realise_set_nt8p key 4; 0: per item, the round-4 form)
+void set_nt8_epi_pre(int on) { g_nt8_bias_first = on; }
+static int nt8_bias_first_on() { return g_nt8_bias_first; }
 static int g_nt8_live_gc = 0;
 void set_nt8_live_gc(int gc) { g_nt8_live_gc = (gc == 1 || gc == 2 || gc == 4 || gc == 8) ? gc : 0; }
 int gemm_nt8_live(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep) {

@@ -477,20 +477,16 @@ typedef __attribute__((ext_vector_type(4))) int ln_i32x4;
 // Row loads the COMPILER DOES NOT TRACK.  hipcc's waitcnt insertion treats vmcnt as out of order as soon as loads and stores are
 // pending together (one counter for both on gfx9) and then waits with vmcnt(0): in a row loop that stores row k while rows k+1.. are
 // in flight, EVERY use of a loaded row drained the whole queue - the prefetched rows included - which is why the round-3/4 kernel
-// gained nothing from more rows in flight.  The hardware retires a wave's loads and stores in issue order through that counter
-// (gemm_nt8p.hip relies on the same), so a counted wait is exact: these loads are inline asm, the waits are explicit, and
-// ln_pin() keeps the uses of a loaded value behind its wait.  (Device pass only: the host pass cannot place the constraints.)
+// gained nothing from more rows in flight.  LOADS return in issue order among themselves (stores among themselves too, but a younger
+// store may be acknowledged before an older load: the first form of this kernel counted the stores as still pending and read rows
+// that had not landed - NaN on the first GPU run), so the wait for row k counts the younger LOADS only: with three younger rows
+// of four loads each, vmcnt(12) holds exactly when row k has landed or more than that has; pending stores can only make it wait
+// longer.  These loads are inline asm, the waits are explicit, ln_pin() keeps the uses of a loaded value behind its wait.  (Device
+// pass only: the host pass cannot place the constraints.)
 __device__ __forceinline__ ln_u32x4 ln_load16(uint32_t voff, uint32_t soff, ln_i32x4 rsrc) {
   ln_u32x4 v = {0u, 0u, 0u, 0u};
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-#endif
-  return v;
-}
-__device__ __forceinline__ uint32_t ln_load4(uint32_t voff, uint32_t soff, ln_i32x4 rsrc) {
-  uint32_t v = 0u;
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 #endif
   return v;
 }
@@ -499,21 +495,21 @@ template <int N> __device__ __forceinline__ void ln_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 #endif
 }
-struct LnRowA { ln_u32x4 dy[2], xh[2]; uint32_t rstd; };
+struct LnRowA { ln_u32x4 dy[2], xh[2]; };
 __device__ __forceinline__ void ln_pin(LnRowA& r) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(r.dy[0]), "+v"(r.dy[1]), "+v"(r.xh[0]), "+v"(r.xh[1]), "+v"(r.rstd));
+  asm volatile("" : "+v"(r.dy[0]), "+v"(r.dy[1]), "+v"(r.xh[0]), "+v"(r.xh[1]));
 #endif
 }
 
 template <bool DROP>
-__global__ void __launch_bounds__(256, 2) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a) {
+__global__ void __launch_bounds__(256, 1) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a) {
   // Branch-free row path: every global access of the row loop is a raw buffer access - the row's byte offset in the SCALAR offset
   // operand, the lane's column offset in the vector operand, which is parked beyond the buffer for whatever must not happen (a lane
   // beyond H / 16, a row beyond this wave's last, the loads of a padding row): out-of-range loads return zeros and move no bytes,
   // out-of-range stores are dropped (the range check looks at the vector offset only).  A padding row runs the same arithmetic on
   // zeros (dx = 0 * (0 - 0 - 0) = 0, nothing added to dgamma / dbeta) and stores its zero row.  Every row therefore issues exactly
-  // 5 loads and 4 stores, which is what makes the counted waits below compile-time constants.
+  // 4 vector loads (and 4 stores), which is what makes the counted waits below compile-time constants.
   extern __shared__ float ln_lds[];          // [4 waves][2 H]: epilogue only
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int H = a.H, HH = H >> 1;
@@ -524,7 +520,7 @@ __global__ void __launch_bounds__(256, 2) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
     const uint64_t ad = (uint64_t)(uintptr_t)p;
     return ln_i32x4{(int)(uint32_t)ad, (int)(uint32_t)((ad >> 32) & 0xffffu), (int)bytes, 0x00020000};
   };
-  const ln_i32x4 rs_dy = rsrc_words(a.dy, nbytes), rs_xh = rsrc_words(a.xhat, nbytes), rs_rs = rsrc_words(a.rstd, (uint32_t)a.rows * 4u);
+  const ln_i32x4 rs_dy = rsrc_words(a.dy, nbytes), rs_xh = rsrc_words(a.xhat, nbytes);
   const __amdgpu_buffer_rsrc_t rs_dx = __builtin_amdgcn_make_buffer_rsrc((void*)a.dx, 0, (int)nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dx_drop != nullptr ? a.dx_drop : a.dx), 0, a.dx_drop != nullptr ? (int)nbytes : 0, 0x00020000);
   const int c0 = active ? lane * 8 : 0, c1 = active ? HH + lane * 8 : 0;
@@ -542,13 +538,13 @@ __global__ void __launch_bounds__(256, 2) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
     r.dy[1] = ln_load16(v1, sbase, rs_dy);
     r.xh[0] = ln_load16(v0, sbase, rs_xh);
     r.xh[1] = ln_load16(v1, sbase, rs_xh);
-    r.rstd = ln_load4(fetch ? 0u : OOB, fetch ? row * 4u : 0u, rs_rs);
   };
   LnRowA r0, r1, r2, r3;
   // ---- prologue: the liveness flags (lane k: is the wave's k-th row live; no table: every row), gamma and the FIRST row's data are
   // requested together - one memory latency, not three in a row; that row is fetched whether or not it is live
   int live_reg = 1;
   if (a.row_live != nullptr) live_reg = lane < nrow ? (int)a.row_live[(int64_t)row_first + (int64_t)lane * stride] : 0;
+  const float rstd_reg = lane < nrow ? a.rstd[(int64_t)row_first + (int64_t)lane * stride] : 0.f;      // lane k: rstd of the wave's k-th row
   float gm[2][8];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -558,12 +554,13 @@ __global__ void __launch_bounds__(256, 2) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
   load(0, r0, (int)(nrow > 0));
   ln_wait_vm<0>();                           // flags, gamma, row 0
   ln_pin(r0);
-  // the compiler's OWN wait for gamma / the flags (it does not see the asm wait above) must land here, before rows 1-3 are requested:
+  float rstd_keep = rstd_reg;
+  // the compiler's OWN wait for gamma / the flags / rstd (it does not see the asm wait above) must land here, before rows 1-3 are requested:
   // at gamma's first use inside the row loop its vmcnt(0) would drain those rows too
 #if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" : "+v"(gm[0][0]), "+v"(gm[0][1]), "+v"(gm[0][2]), "+v"(gm[0][3]), "+v"(gm[0][4]), "+v"(gm[0][5]), "+v"(gm[0][6]), "+v"(gm[0][7]),
                     "+v"(gm[1][0]), "+v"(gm[1][1]), "+v"(gm[1][2]), "+v"(gm[1][3]), "+v"(gm[1][4]), "+v"(gm[1][5]), "+v"(gm[1][6]), "+v"(gm[1][7]),
-                    "+v"(live_reg));
+                    "+v"(live_reg), "+v"(rstd_keep));
 #endif
   auto live_k = [&](int k) -> int { return (int)(k < nrow) & (int)(__builtin_amdgcn_readlane(live_reg, k & 63) != 0); };      // k wave-uniform
   load(1, r1, live_k(1)); load(2, r2, live_k(2)); load(3, r3, live_k(3));
@@ -572,7 +569,8 @@ __global__ void __launch_bounds__(256, 2) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
-  // keep = 0: the row's data was fetched although it is a padding row (the wave's first row) - its dy counts as zeros
+  // keep = 0: a padding row (its loads were parked and returned zeros - except the wave's first row, fetched before the flags were known) or a row
+  // beyond the wave's last: everything read for it counts as zeros
   auto process = [&](int k, const LnRowA& r, int keep) {
     const int store = (int)(k < nrow);
     const uint32_t row = (uint32_t)(row_first + k * stride);
@@ -596,7 +594,7 @@ __global__ void __launch_bounds__(256, 2) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
     }
     s1 = wave_sum_dpp(s1) / (float)H;
     s2 = wave_sum_dpp(s2) / (float)H;
-    const float rstd = __uint_as_float(r.rstd & msk);
+    const float rstd = keep ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rstd_keep), k & 63)) : 0.f;      // (a padding row's saved rstd is as stale as its xhat)
     const uint32_t sbase = store ? row * row_bytes : 0u;
     // (fences: the dropout hashes and the second unpack are not to be hoisted above the reductions - they would all be live across them)
     __builtin_amdgcn_sched_barrier(0);
@@ -622,12 +620,12 @@ __global__ void __launch_bounds__(256, 2) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, pack8(dx)), rs_dd, voff, sbase, 0);      // (no dx_drop: a zero-size buffer drops it)
     }
   };
-  // Counted waits.  Issue order of a wave's vector-memory operations from here on (L = the 5 loads of a row, S = its 4 stores):
+  // Counted waits.  Issue order of a wave's vector-memory operations from here on (L = the 4 loads of a row, S = its 4 stores):
   //   L1 L2 L3 | S0 L4 | S1 L5 | S2 L6 | S3 L7 | S4 L8 | ...      (row k is processed, then row k + 4 requested into its registers)
-  // so when row k is about to be processed the operations younger than L(k) are: k = 1: L2 L3 S0 L4 = 19, k = 2: L3 S0 L4 S1 L5 = 23,
-  // k >= 3: S(k-3) L(k+1) S(k-2) L(k+2) S(k-1) L(k+3) = 27.  (Loads / stores of parked rows are still issued: the counts do not
-  // depend on the data.)  sched_barrier: the compiler must not move a row's arithmetic across its wait, nor interleave four rows'
-  // arithmetic (> 256 registers).
+  // When row k is about to be processed the LOADS younger than L(k) are L(k+1) L(k+2) L(k+3) = 12: loads complete in order, so
+  // "at most 12 operations pending" implies L(k) has landed whatever the stores do (see ln_load16).  (Loads / stores of parked rows
+  // are still issued: the counts do not depend on the data.)  sched_barrier: the compiler must not move a row's arithmetic across its
+  // wait, nor interleave four rows' arithmetic (> 256 registers).
 #define RL_LN_STEP(K, R, NYOUNGER, KEEP) do { ln_wait_vm<NYOUNGER>(); ln_pin(R); __builtin_amdgcn_sched_barrier(0); \
     process(K, R, KEEP); __builtin_amdgcn_sched_barrier(0); load((K) + 4, R, live_k((K) + 4)); __builtin_amdgcn_sched_barrier(0); } while (0)
   if (nrow > 0) {
@@ -636,14 +634,14 @@ __global__ void __launch_bounds__(256, 2) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
     __builtin_amdgcn_sched_barrier(0);
     load(4, r0, live_k(4));
     __builtin_amdgcn_sched_barrier(0);
-    RL_LN_STEP(1, r1, 19, 1);
-    RL_LN_STEP(2, r2, 23, 1);
-    RL_LN_STEP(3, r3, 27, 1);
+    RL_LN_STEP(1, r1, 12, live_k(1));
+    RL_LN_STEP(2, r2, 12, live_k(2));
+    RL_LN_STEP(3, r3, 12, live_k(3));
     for (int k = 4; k < nrow; k += 4) {
-      RL_LN_STEP(k, r0, 27, 1);
-      RL_LN_STEP(k + 1, r1, 27, 1);
-      RL_LN_STEP(k + 2, r2, 27, 1);
-      RL_LN_STEP(k + 3, r3, 27, 1);
+      RL_LN_STEP(k, r0, 12, live_k(k));
+      RL_LN_STEP(k + 1, r1, 12, live_k(k + 1));
+      RL_LN_STEP(k + 2, r2, 12, live_k(k + 2));
+      RL_LN_STEP(k + 3, r3, 12, live_k(k + 3));
     }
   }
 #undef RL_LN_STEP
