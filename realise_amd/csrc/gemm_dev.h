@@ -105,6 +105,37 @@ __device__ __forceinline__ void epilogue8(const EpiParams<T>& ep, int M, int N, 
   }
 }
 
+// epilogue8 with the row's aux / old-output octet already in registers (`pre`: the residual of EPI_DROP_RESID, the pre-activation of
+// EPI_GELU_BWD, or - `pre_is_old` - the output an accumulating EPI_STORE adds to).  The 8-wave kernels request these octets for ALL
+// of a wave's items before the first store (gemm_nt8.hip): loaded item by item they sat behind their predecessors' stores, and hipcc
+// waits with vmcnt(0) whenever loads and stores are pending together.  Same arithmetic, same order: same bits as epilogue8.
+__device__ __forceinline__ void epilogue8_pre(const EpiParams<bf16_t>& ep, int M, int N, int row, int col, floatx4 a, floatx4 b, uint4 pre) {
+  typedef bf16_t T;
+  if (row >= M || col >= N) return;
+  if (ep.alpha != 1.0f) { a *= ep.alpha; b *= ep.alpha; }
+  if (ep.bias != nullptr) { a += *(const floatx4*)(ep.bias + col); b += *(const floatx4*)(ep.bias + col + 4); }
+  T* o = ep.out + (int64_t)row * ep.ldo + col;
+  floatx4 pa, pb;
+  unpack8(pre, pa, pb);
+  switch (ep.mode) {
+    case EPI_STORE: {
+      if (ep.accumulate) { a += pa; b += pb; }
+      store8<T>(o, a, b);
+    } break;
+    case EPI_DROP_RESID: {
+      const uint32_t idx = (uint32_t)row * (uint32_t)N + (uint32_t)col;
+      a *= drop_mult4(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx);          // N % 8 == 0, col % 8 == 0
+      b *= drop_mult4(ep.drop_seed, ep.drop_thresh, ep.drop_scale, idx + 4);
+      store8<T>(o, a + pa, b + pb);
+    } break;
+    case EPI_GELU_BWD: {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] *= gelu_bwd<T>(pa[j]); b[j] *= gelu_bwd<T>(pb[j]); }
+      store8<T>(o, a, b);
+    } break;
+    default: break;
+  }
+}
 
 // ---- TN (weight-gradient) device helpers shared by gemm.hip and gemm_tn8.hip ---------------------------------------------
 template <typename T> struct TnGeo;

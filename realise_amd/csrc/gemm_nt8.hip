@@ -493,6 +493,69 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
       epx.alpha = 1.0f; epx.bias = nullptr;
     }
   }
+  // Round 5 (same knob): the residual / pre-activation / accumulated-output octets of ALL of the wave's items are requested here, before
+  // the first store, from addresses clamped into the matrix (unconditional loads: nothing between them for the compiler to wait on);
+  // epilogue8_pre then runs item by item on registers.  Two-per-CU shape only (RM / ER chunks x NIT items = 6 octets = 24 registers).
+  if constexpr (!KTAIL && (XEPI == 0 || XEPI == 3) && C::WGS == 2) {
+    const bool use_aux = ep.mode == EPI_DROP_RESID || ep.mode == EPI_GELU_BWD;
+    const bool use_old = ep.mode == EPI_STORE && ep.accumulate != 0;
+    if (ep.bias_first && ep.slab == nullptr && ep.rm_hw_shift < 0 && (use_aux || use_old) && !(ep.mode == EPI_GELU_BWD && ep.accumulate) &&
+        (!use_aux || ep.aux != nullptr) && (N % 8) == 0) {
+      constexpr int NCH = C::RM / ER;
+      const bf16_t* src = use_aux ? ep.aux : (const bf16_t*)ep.out;
+      const int64_t ld = use_aux ? ep.ldaux : ep.ldo;
+      int rcs[NCH];
+      bool cok[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        rcs[c] = row_w + c * ER; cok[c] = true;
+        if constexpr (XEPI == 3) {
+          const int j = tm * (C::BM / 16) + ((wm * C::RM + c * ER) >> 4);
+          cok[c] = j < nlive;
+          rcs[c] = cok[c] ? ep.live_list[j] * 16 : 0;
+        }
+      }
+      EpiParams<bf16_t> e3 = ep;
+      e3.bias = nullptr; e3.alpha = 1.0f;                  // (both are in the accumulators already: bias_first)
+      typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;      // (a register-class type: HIP's uint4 struct cannot be an asm operand)
+      u32x4_t pre[NCH][NIT];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int e = lane + 64 * it, r = e / ITEMS, c8 = e - r * ITEMS;
+          pre[c][it] = *(const u32x4_t*)(src + (int64_t)min(rcs[c] + r, M - 1) * ld + min(col_w + c8 * 8, N - 8));
+        }
+      // first transpose under the loads' latency, then ONE unconditional wait for all six octets: left to their first uses - inside the
+      // items' bounds-check branches - the compiler could not prove them landed on every path and re-waited, with stores pending, by vmcnt(0)
+#pragma unroll
+      for (int i = 0; i < ER / 16; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *(floatx4*)(et + (i * 16 + l15) * RS + j * 16 + 4 * g) = acc[i][j];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" : "+v"(pre[c][it]));
+#endif
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c > 0) {
+#pragma unroll
+          for (int i = 0; i < ER / 16; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) *(floatx4*)(et + (i * 16 + l15) * RS + j * 16 + 4 * g) = acc[c * (ER / 16) + i][j];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int e = lane + 64 * it, r = e / ITEMS, c8 = e - r * ITEMS;
+          const floatx4 v0 = *(const floatx4*)(et + r * RS + c8 * 8), v1 = *(const floatx4*)(et + r * RS + c8 * 8 + 4);
+          if (cok[c]) epilogue8_pre(e3, M, N, rcs[c] + r, col_w + c8 * 8, v0, v1, __builtin_bit_cast(uint4, pre[c][it]));
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int c = 0; c < C::RM / ER; ++c) {
     int row_c = row_w + c * ER;

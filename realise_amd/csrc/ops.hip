@@ -473,34 +473,21 @@ __global__ void __launch_bounds__(256, 3) ln_bwd16_kernel(LnBwdArgs<bf16_t> a) {
 // Same record layout ([dgamma | dbeta] per workgroup), same fold kernels; a wave's rows are summed in row order, the four waves in
 // wave order: deterministic, but another order than the kernel above.
 typedef __attribute__((ext_vector_type(4))) uint32_t ln_u32x4;
-typedef __attribute__((ext_vector_type(4))) int ln_i32x4;
-// Row loads the COMPILER DOES NOT TRACK.  hipcc's waitcnt insertion treats vmcnt as out of order as soon as loads and stores are
-// pending together (one counter for both on gfx9) and then waits with vmcnt(0): in a row loop that stores row k while rows k+1.. are
-// in flight, EVERY use of a loaded row drained the whole queue - the prefetched rows included - which is why the round-3/4 kernel
-// gained nothing from more rows in flight.  LOADS return in issue order among themselves (stores among themselves too, but a younger
-// store may be acknowledged before an older load: the first form of this kernel counted the stores as still pending and read rows
-// that had not landed - NaN on the first GPU run), so the wait for row k counts the younger LOADS only: with three younger rows
-// of four loads each, vmcnt(12) holds exactly when row k has landed or more than that has; pending stores can only make it wait
-// longer.  These loads are inline asm, the waits are explicit, ln_pin() keeps the uses of a loaded value behind its wait.  (Device
-// pass only: the host pass cannot place the constraints.)
-__device__ __forceinline__ ln_u32x4 ln_load16(uint32_t voff, uint32_t soff, ln_i32x4 rsrc) {
-  ln_u32x4 v = {0u, 0u, 0u, 0u};
+// STORES THE COMPILER DOES NOT TRACK.  hipcc's waitcnt insertion treats vmcnt as out of order as soon as loads and stores are pending
+// together (one counter for both on gfx9; a younger store may indeed be acknowledged before an older load) and then waits with
+// vmcnt(0): in a row loop that stores row k while rows k+1.. are in flight, EVERY use of a loaded row drained the whole queue - the
+// prefetched rows included - which is why the round-3/4 kernel gained nothing from more rows in flight.  With the stores as inline asm
+// the compiler sees only loads pending, which complete in issue order: it waits with exact counts (vmcnt(12) before row k = "the
+// three younger rows may still be in flight"); the untracked stores can only make such a wait longer, never too short.  (The first
+// form of this kernel did it the other way round - asm loads, counted waits by hand - and read garbage: the compiler is free to
+// copy or spill a value it believes was defined by the asm statement while the load is still in flight.)  s_nop: the store-data
+// hazard of a > 8-byte VMEM store followed by a write of its data registers, which the compiler cannot see through the asm.
+__device__ __forceinline__ void ln_store16(ln_u32x4 v, uint32_t voff, uint32_t soff, __amdgpu_buffer_rsrc_t rsrc) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-#endif
-  return v;
-}
-template <int N> __device__ __forceinline__ void ln_wait_vm() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 #endif
 }
 struct LnRowA { ln_u32x4 dy[2], xh[2]; };
-__device__ __forceinline__ void ln_pin(LnRowA& r) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(r.dy[0]), "+v"(r.dy[1]), "+v"(r.xh[0]), "+v"(r.xh[1]));
-#endif
-}
 
 template <bool DROP>
 __global__ void __launch_bounds__(256, 1) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a) {
@@ -508,19 +495,15 @@ __global__ void __launch_bounds__(256, 1) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
   // operand, the lane's column offset in the vector operand, which is parked beyond the buffer for whatever must not happen (a lane
   // beyond H / 16, a row beyond this wave's last, the loads of a padding row): out-of-range loads return zeros and move no bytes,
   // out-of-range stores are dropped (the range check looks at the vector offset only).  A padding row runs the same arithmetic on
-  // zeros (dx = 0 * (0 - 0 - 0) = 0, nothing added to dgamma / dbeta) and stores its zero row.  Every row therefore issues exactly
-  // 4 vector loads (and 4 stores), which is what makes the counted waits below compile-time constants.
+  // zeros (dx = 0 * (0 - 0 - 0) = 0, nothing added to dgamma / dbeta) and stores its zero row: the row loop is straight-line code.
   extern __shared__ float ln_lds[];          // [4 waves][2 H]: epilogue only
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int H = a.H, HH = H >> 1;
   const bool active = lane * 16 < H;
   constexpr uint32_t OOB = 0xFFFFFF00u;
   const uint32_t nbytes = (uint32_t)a.rows * (uint32_t)H * 2u;              // < 4 GiB - 256 (launcher)
-  auto rsrc_words = [](const void* p, uint32_t bytes) {      // raw buffer descriptor: base, stride 0, num_records = bytes, DST_SEL / format word of a 32-bit raw buffer
-    const uint64_t ad = (uint64_t)(uintptr_t)p;
-    return ln_i32x4{(int)(uint32_t)ad, (int)(uint32_t)((ad >> 32) & 0xffffu), (int)bytes, 0x00020000};
-  };
-  const ln_i32x4 rs_dy = rsrc_words(a.dy, nbytes), rs_xh = rsrc_words(a.xhat, nbytes);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_xh = __builtin_amdgcn_make_buffer_rsrc((void*)a.xhat, 0, (int)nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dx = __builtin_amdgcn_make_buffer_rsrc((void*)a.dx, 0, (int)nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dx_drop != nullptr ? a.dx_drop : a.dx), 0, a.dx_drop != nullptr ? (int)nbytes : 0, 0x00020000);
   const int c0 = active ? lane * 8 : 0, c1 = active ? HH + lane * 8 : 0;
@@ -534,10 +517,10 @@ __global__ void __launch_bounds__(256, 1) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
     const uint32_t row = (uint32_t)(row_first + k * stride);
     const uint32_t sbase = fetch ? row * row_bytes : 0u;
     const uint32_t v0 = fetch ? lo0 : OOB, v1 = fetch ? lo1 : OOB;
-    r.dy[0] = ln_load16(v0, sbase, rs_dy);
-    r.dy[1] = ln_load16(v1, sbase, rs_dy);
-    r.xh[0] = ln_load16(v0, sbase, rs_xh);
-    r.xh[1] = ln_load16(v1, sbase, rs_xh);
+    r.dy[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, v0, sbase, 0);
+    r.dy[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, v1, sbase, 0);
+    r.xh[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_xh, v0, sbase, 0);
+    r.xh[1] = __builtin_amdgcn_raw_buffer_load_b128(rs_xh, v1, sbase, 0);
   };
   LnRowA r0, r1, r2, r3;
   // ---- prologue: the liveness flags (lane k: is the wave's k-th row live; no table: every row), gamma and the FIRST row's data are
@@ -552,16 +535,7 @@ __global__ void __launch_bounds__(256, 1) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
     *(floatx4*)&gm[i][0] = *(const floatx4*)(a.gamma + c); *(floatx4*)&gm[i][4] = *(const floatx4*)(a.gamma + c + 4);
   }
   load(0, r0, (int)(nrow > 0));
-  ln_wait_vm<0>();                           // flags, gamma, row 0
-  ln_pin(r0);
-  float rstd_keep = rstd_reg;
-  // the compiler's OWN wait for gamma / the flags / rstd (it does not see the asm wait above) must land here, before rows 1-3 are requested:
-  // at gamma's first use inside the row loop its vmcnt(0) would drain those rows too
-#if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("" : "+v"(gm[0][0]), "+v"(gm[0][1]), "+v"(gm[0][2]), "+v"(gm[0][3]), "+v"(gm[0][4]), "+v"(gm[0][5]), "+v"(gm[0][6]), "+v"(gm[0][7]),
-                    "+v"(gm[1][0]), "+v"(gm[1][1]), "+v"(gm[1][2]), "+v"(gm[1][3]), "+v"(gm[1][4]), "+v"(gm[1][5]), "+v"(gm[1][6]), "+v"(gm[1][7]),
-                    "+v"(live_reg), "+v"(rstd_keep));
-#endif
+  const float rstd_keep = rstd_reg;
   auto live_k = [&](int k) -> int { return (int)(k < nrow) & (int)(__builtin_amdgcn_readlane(live_reg, k & 63) != 0); };      // k wave-uniform
   load(1, r1, live_k(1)); load(2, r2, live_k(2)); load(3, r3, live_k(3));
   float dg[2][8], db[2][8];
@@ -608,7 +582,7 @@ __global__ void __launch_bounds__(256, 1) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
 #pragma unroll
       for (int j = 0; j < 8; ++j) dx[j] = rstd * (dy[j] * gm[i][j] - s1 - xh[j] * s2);
       const uint32_t voff = store ? (i ? lo1 : lo0) : OOB;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, pack8(dx)), rs_dx, voff, sbase, 0);
+      ln_store16(__builtin_bit_cast(ln_u32x4, pack8(dx)), voff, sbase, rs_dx);
       if constexpr (DROP) {
 #pragma unroll
         for (int hq = 0; hq < 2; ++hq) {
@@ -617,35 +591,20 @@ __global__ void __launch_bounds__(256, 1) ln_bwd16v2_kernel(LnBwdArgs<bf16_t> a)
           for (int j = 0; j < 4; ++j) dx[4 * hq + j] *= dm[j];
         }
       }
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, pack8(dx)), rs_dd, voff, sbase, 0);      // (no dx_drop: a zero-size buffer drops it)
+      ln_store16(__builtin_bit_cast(ln_u32x4, pack8(dx)), voff, sbase, rs_dd);      // (no dx_drop: a zero-size buffer drops it)
     }
   };
-  // Counted waits.  Issue order of a wave's vector-memory operations from here on (L = the 4 loads of a row, S = its 4 stores):
-  //   L1 L2 L3 | S0 L4 | S1 L5 | S2 L6 | S3 L7 | S4 L8 | ...      (row k is processed, then row k + 4 requested into its registers)
-  // When row k is about to be processed the LOADS younger than L(k) are L(k+1) L(k+2) L(k+3) = 12: loads complete in order, so
-  // "at most 12 operations pending" implies L(k) has landed whatever the stores do (see ln_load16).  (Loads / stores of parked rows
-  // are still issued: the counts do not depend on the data.)  sched_barrier: the compiler must not move a row's arithmetic across its
-  // wait, nor interleave four rows' arithmetic (> 256 registers).
-#define RL_LN_STEP(K, R, NYOUNGER, KEEP) do { ln_wait_vm<NYOUNGER>(); ln_pin(R); __builtin_amdgcn_sched_barrier(0); \
-    process(K, R, KEEP); __builtin_amdgcn_sched_barrier(0); load((K) + 4, R, live_k((K) + 4)); __builtin_amdgcn_sched_barrier(0); } while (0)
-  if (nrow > 0) {
-    __builtin_amdgcn_sched_barrier(0);
-    process(0, r0, live_k(0));               // (row 0 landed in the prologue)
-    __builtin_amdgcn_sched_barrier(0);
-    load(4, r0, live_k(4));
-    __builtin_amdgcn_sched_barrier(0);
-    RL_LN_STEP(1, r1, 12, live_k(1));
-    RL_LN_STEP(2, r2, 12, live_k(2));
-    RL_LN_STEP(3, r3, 12, live_k(3));
-    for (int k = 4; k < nrow; k += 4) {
-      RL_LN_STEP(k, r0, 12, live_k(k));
-      RL_LN_STEP(k + 1, r1, 12, live_k(k + 1));
-      RL_LN_STEP(k + 2, r2, 12, live_k(k + 2));
-      RL_LN_STEP(k + 3, r3, 12, live_k(k + 3));
-    }
+  // Row k is processed, then row k + 4 requested into its registers: four rows of a wave in flight.  The waits are the compiler's (exact
+  // counts: only loads are pending as far as it knows).  sched_barrier: it must not interleave four rows' arithmetic (> 256 registers).
+#define RL_LN_STEP(K, R, KEEP) do { __builtin_amdgcn_sched_barrier(0); process(K, R, KEEP); __builtin_amdgcn_sched_barrier(0); \
+    load((K) + 4, R, live_k((K) + 4)); __builtin_amdgcn_sched_barrier(0); } while (0)
+  for (int k = 0; k < nrow; k += 4) {
+    RL_LN_STEP(k, r0, live_k(k));
+    RL_LN_STEP(k + 1, r1, live_k(k + 1));
+    RL_LN_STEP(k + 2, r2, live_k(k + 2));
+    RL_LN_STEP(k + 3, r3, live_k(k + 3));
   }
 #undef RL_LN_STEP
-  ln_wait_vm<0>();                           // the parked loads of the rows beyond the last must not land in registers the epilogue re-uses
   // ---- epilogue: [dgamma | dbeta] of the workgroup = the four waves' partials added in wave order
   float* mine = ln_lds + (size_t)wave * 2 * H;
   if (active) {

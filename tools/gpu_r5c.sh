@@ -1,8 +1,8 @@
 #!/bin/bash
 # round-5 GPU call B: new tests + regression subset, LayerNorm probe, step A/B of this round's knobs
-mkdir -p gpurun_out/r5b; export PYTHONDONTWRITEBYTECODE=1
-O=gpurun_out/r5b
-timeout 600 python -m pytest tests/test_round5_gpu.py -m gpu -q --no-header -rfE -p no:cacheprovider --timeout=300 -x > $O/pytest_new.log 2>&1; echo "new tests exit $?" >> $O/pytest_new.log
+mkdir -p gpurun_out/r5c; export PYTHONDONTWRITEBYTECODE=1
+O=gpurun_out/r5c
+timeout 600 python -m pytest tests/test_round5_gpu.py -m gpu -q --no-header -rfE -p no:cacheprovider --timeout=300 > $O/pytest_new.log 2>&1; echo "new tests exit $?" >> $O/pytest_new.log
 tail -n 25 $O/pytest_new.log
 timeout 700 python -m pytest tests/test_kernels_gpu.py tests/test_round4_gpu.py tests/test_engine_gpu.py tests/test_round3_gpu.py -m gpu -q --no-header -rfE -p no:cacheprovider --timeout=300 \
   -k "layernorm or padding or live_row or grouped or trajectory or fused_adamw or full_size or reference_trainer or gemm_nt or nt8 or split_k" > $O/pytest_reg.log 2>&1; echo "regression exit $?" >> $O/pytest_reg.log
