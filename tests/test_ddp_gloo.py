@@ -138,3 +138,24 @@ def test_ddp_wrapper_world2_gloo(model_type):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in res), res
+
+
+def test_scale_sweep_tool_world2_gloo(tmp_path):
+    """tools/scale_sweep.py (the table the first 8-GPU run prints: gpus x exchange x wire dtype with exposed_tail_ms) driven end to end on
+    CPU: world sizes 1 and 2 over gloo, both exchanges, both wire dtypes, through torch.distributed.run - with tests/fake_bench_ddp.py
+    standing in for bench.py (the real _GradSync exchange on engine-shaped buckets, checked against the mean on every rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "rows.json"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "scale_sweep.py"), "--gpus", "1", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--bench", os.path.join(root, "tests", "fake_bench_ddp.py"), "--master-port", "29741", "--json", str(out), "--timeout", "300"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = json.load(open(out))
+    assert [(x["gpus"], x["algo"], x["grad_dtype"]) for x in rows] == [(1, "-", "-"), (2, "allreduce", "fp32"), (2, "allreduce", "bf16"),
+                                                                     (2, "mesh", "fp32"), (2, "mesh", "bf16")]
+    assert all(x["error"] is None and x["value"] > 0 for x in rows)
+    assert rows[3]["collectives"] == 14 and rows[1]["collectives"] == 7 and rows[2]["wire_mb"] < rows[1]["wire_mb"]
+    assert "exposed_tail_ms" in r.stdout and "| 2 | mesh | bf16 |" in r.stdout
