@@ -102,8 +102,12 @@ def test_fused_optimizer_default_sees_a_raw_parameter_write():
         return out
 
     seen_default, stale_trusted, seen_marked = run(False, False), run(True, False), run(True, True)
-    assert torch.equal(seen_default, seen_marked)
-    assert not torch.equal(seen_default, stale_trusted), "the trusted run was expected to miss the raw write (that is what the flag trades)"
+    # (the arena-level AdamW of the untrusted run and the engine sweep of the trusted one round a step differently in the last bits)
+    seen = (seen_default - seen_marked).abs().max().item()
+    missed = (seen_default - stale_trusted).abs().max().item()
+    print("zeroed FFN weight: default vs marked %.3e, default vs trusted-unmarked %.3e" % (seen, missed))
+    assert seen <= 2e-2
+    assert missed > 20 * max(seen, 1e-3), "the trusted run was expected to miss the raw write (that is what the flag trades)"
 
 
 @pytest.mark.parametrize("knob", ["wgrad_group", "tn_group_ring"])
