@@ -197,7 +197,12 @@ template <typename T> struct ConvLoader {
   static constexpr uint32_t RECORDS = 0xFFFFFE00u;
   struct Row32 { uint32_t off; int y0, x0; };
   struct Tap32 { int kh, kw, ch, k; uint32_t toff; };
-  __device__ __forceinline__ Row32 prepare32(int row) const {
+  __device__ __forceinline__ Row32 prepare32(int row) const { return prepare32_t<true>(row); }
+  // IDX = false: the caller knows img_index == nullptr (ConvLoaderDirect).  Not a micro-optimisation: the weight-gradient kernel calls
+  // this per fetched piece INSIDE its K loop, and a conditional global load there - never executed, img_index being null in every engine
+  // call - still made hipcc wait with vmcnt(0) at the merge behind it: every gathered fetch of every K-tile was issued alone, after the
+  // previous one had landed (found in the ISA in round 5; the conv weight gradients ran at 0.13 of the MFMA peak).
+  template <bool IDX> __device__ __forceinline__ Row32 prepare32_t(int row) const {
     Row32 r; r.off = 0u; r.y0 = -(1 << 24); r.x0 = -(1 << 24);          // out of range: every tap fails the bounds test
     if (row < rows) {
       int n, rem, y, x;
@@ -212,7 +217,8 @@ template <typename T> struct ConvLoader {
         n = row / hw; rem = row - n * hw;
         y = rem / Wr; x = rem - y * Wr;
       }
-      const int64_t ns = img_index ? img_index[n] : (int64_t)n;
+      int64_t ns = (int64_t)n;
+      if constexpr (IDX) { if (img_index) ns = img_index[n]; }
       const int64_t img = ns * Hs * Ws;
       if (mode == 0) { r.y0 = y * stride - pad; r.x0 = x * stride - pad; }
       else { r.y0 = y + pad; r.x0 = x + pad; }
@@ -280,6 +286,13 @@ template <typename T> struct ConvLoader {
   }
 };
 
+// the same geometry for callers that gather straight from `src` (img_index == nullptr): no index load anywhere in the device code
+template <typename T> struct ConvLoaderDirect : ConvLoader<T> {
+  ConvLoaderDirect() = default;
+  explicit ConvLoaderDirect(const ConvLoader<T>& b) : ConvLoader<T>(b) {}
+  __device__ __forceinline__ typename ConvLoader<T>::Row32 prepare32(int row) const { return this->template prepare32_t<false>(row); }
+};
+
 // Stride-2 data gradient by parity classes: class c = 2*py + px of a KH x KW / pad convolution uses the taps (kh0 + 2i, kw0 + 2j);
 // the dgrad weight copy stores the taps class by class (class 0's taps, then class 1's, ...), each class i-major.  Returns the
 // number of taps of class c, its first slot in that order, and (optionally) the original tap index of every slot.
@@ -308,6 +321,7 @@ inline int conv_s2_slot(int KH, int KW, int pad, int kh, int kw) {
 
 // ---- TN (weight-gradient) epilogue ---------------------------------------------------------------
 enum TnMode { TN_PLAIN = 0, TN_CONVW = 1 };
+constexpr int TN_LIST_LDS = 4096;      // bytes of LDS a TN kernel keeps its live-block list in: 1024 entries (16384 token rows in 16-row blocks)
 struct TnEpi {
   int mode = TN_PLAIN;
   float* out = nullptr;     // fp32, accumulated (out += result)

@@ -525,23 +525,25 @@ template <typename L, int NB> struct ConvTaps {
   __device__ __forceinline__ void init(const L&) {}
   __device__ __forceinline__ void fetch(const L&, int, int, bool, char*) {}
 };
-template <typename T, int NB> struct ConvTaps<ConvLoader<T>, NB> {
+template <typename L, typename T, int NB> struct ConvTapsImpl {      // L = ConvLoader<T> or ConvLoaderDirect<T> (whose prepare32 loads nothing)
   typename ConvLoader<T>::Tap32 t[NB];
   __amdgpu_buffer_rsrc_t rs;
-  __device__ __forceinline__ void set(const ConvLoader<T>& lb, int q, int col) {
+  __device__ __forceinline__ void set(const L& lb, int q, int col) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) if (i == q) t[i] = lb.tap32(col);
   }
-  __device__ __forceinline__ void init(const ConvLoader<T>& lb) {
+  __device__ __forceinline__ void init(const L& lb) {
     rs = __builtin_amdgcn_make_buffer_rsrc((void*)lb.src, 0, (int)ConvLoader<T>::RECORDS, 0x00020000);
   }
-  __device__ __forceinline__ void fetch(const ConvLoader<T>& lb, int q, int p, bool live, char* lds_wave_piece) {
+  __device__ __forceinline__ void fetch(const L& lb, int q, int p, bool live, char* lds_wave_piece) {
     uint32_t voff = ConvLoader<T>::OOB;
 #pragma unroll
     for (int i = 0; i < NB; ++i) if (i == q && live) voff = lb.voff32(lb.prepare32(p), t[i]);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_piece, 16, voff, 0, 0, 0);
   }
 };
+template <typename T, int NB> struct ConvTaps<ConvLoader<T>, NB> : ConvTapsImpl<ConvLoader<T>, T, NB> {};
+template <typename T, int NB> struct ConvTaps<ConvLoaderDirect<T>, NB> : ConvTapsImpl<ConvLoaderDirect<T>, T, NB> {};
 
 // One (split, tile) of a TN problem; `logical` = split * ntiles + tile.
 // NST LDS stages of BP = TnGeo::BP / BPD reduction rows each (default: 2 stages of full tiles; the grouped kernel runs 4 stages of half
@@ -707,18 +709,26 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
   const int n_list = listed ? *ep.n_tiles : 0;
   const int nt = sub16 ? min((n_list + 3) >> 2, (p_end - p_begin) / BP) : listed ? min(n_list, (p_end - p_begin) / BP) : (p_end - p_begin + BP - 1) / BP;
   int issued = 0;
-  // the live-tile list is read 64 entries at a time into one register per lane (a load per tile would sit in front of every issue)
+  // The live-tile list is copied to LDS once (TN_LIST_LDS bytes behind the stages) and read from there, one broadcast ds_read per tile.
+  // Round 4 kept 64 entries in a register and re-loaded it every 16 tiles INSIDE the loop; that load sat in a conditional block, and at the
+  // merge hipcc's waitcnt pass could no longer tell whether the register (shared with a fetch pointer by the allocator) still had a load
+  // pending: it put an s_waitcnt vmcnt(0) between the first and the second LDS-DMA fetch of EVERY tile (found in the ISA in round 5) -
+  // every K-tile of every weight-gradient launch paid a full memory latency with one fetch in flight.  LDS reads are counted by lgkmcnt:
+  // nothing the fetch queue's counter has to be drained for.
   const int n_ent = sub16 ? min(n_list, 4 * nt) : nt;
-  int list_reg = (listed && lane < n_ent) ? ep.tile_list[lane] : -1;
+  int* lds_list = (int*)(smem + NST * STAGE);
+  if (listed) {
+    for (int e = tid; e < n_ent; e += 256) lds_list[e] = ep.tile_list[e];
+    __syncthreads();
+  }
   auto issue_next = [&]() {
     if (issued < nt) {
       int pt = p_begin + issued * BP;
       if (sub16) {
-        if (issued != 0 && (issued & 15) == 0) list_reg = (4 * issued + lane < n_ent) ? ep.tile_list[4 * issued + lane] : -1;
-        pt = __builtin_amdgcn_readlane(list_reg, ((issued & 15) << 2) + wave);
+        const int e = 4 * issued + wave;
+        pt = e < n_ent ? __builtin_amdgcn_readfirstlane(lds_list[e]) : -1;
       } else if (listed) {
-        if (issued != 0 && (issued & 63) == 0) list_reg = (issued + lane < nt) ? ep.tile_list[issued + lane] : 0;
-        pt = __builtin_amdgcn_readlane(list_reg, issued & 63) * BP;
+        pt = __builtin_amdgcn_readfirstlane(lds_list[issued]) * BP;
       }
       issue(pt, issued % NST);
       ++issued;
@@ -936,7 +946,8 @@ static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader
     }
   }
   const int how = nsplit == 1 ? TN_OUT_DIRECT : (ep.slab != nullptr ? TN_OUT_SLAB : TN_OUT_ATOMIC);
-  const size_t lds = 2 * (size_t)G::BP * (BI + BJ) * sizeof(T);
+  if (ep.tile_list != nullptr && (int64_t)P / (ep.list_rows ? ep.list_rows : G::BP) > TN_LIST_LDS / 4) return RL_ERR_ARG;
+  const size_t lds = 2 * (size_t)G::BP * (BI + BJ) * sizeof(T) + (ep.tile_list != nullptr ? TN_LIST_LDS : 0);
   dim3 grid(ntiles * nsplit);
   {
     ProfScope ps(st, sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos) ? PK_GEMM_TN : PK_CONV_TN, 2.0 * P * I * J);
@@ -1008,7 +1019,9 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
   }
   grp.total_tiles = total;
   const int pchunk = ((P + G::BP - 1) / G::BP) * G::BP;
-  const size_t lds = 2 * (size_t)G::BP * 256 * sizeof(T);
+  // (+ the live-block list: at most TN_LIST_LDS / 4 entries)
+  if (grp.tile_list != nullptr && (int64_t)P / grp.list_rows > TN_LIST_LDS / 4) return RL_ERR_ARG;
+  const size_t lds = 2 * (size_t)G::BP * 256 * sizeof(T) + (grp.tile_list != nullptr ? TN_LIST_LDS : 0);
   ProfScope ps(st, PK_GEMM_TN, flops);
   if (grp.tile_list != nullptr) prof_set_exec(grp.n_tiles, flops / P * grp.list_rows, sizeof(T) == 2 && grp.list_rows == 16 ? 4 : 1, P / grp.list_rows);   // live blocks only
   // ring: the 2 full stages of the single-problem kernel (default) or 4 stages of half tiles (three tiles in flight per workgroup,
@@ -1054,6 +1067,7 @@ int gemm_tn_conv(hipStream_t st, const T* A, int64_t lda, const ConvLoader<T>& l
         ep.slab_elems >= 64 * 576 && (int64_t)P * 128 < 0xFFFFFE00ll)
       return conv_wgrad_c64(st, A, lb.src, P, lb.rows_dev, ep);
   }
+  if (lb.img_index == nullptr) return launch_tn<T, ConvLoaderDirect<T>>(st, A, lda, ConvLoaderDirect<T>(lb), P, I, J, ep);      // (every engine call)
   return launch_tn<T, ConvLoader<T>>(st, A, lda, lb, P, I, J, ep);
 }
 template int gemm_tn<bf16_t>(hipStream_t, const bf16_t*, int64_t, const bf16_t*, int64_t, int, int, int, const TnEpi&, const int*);
