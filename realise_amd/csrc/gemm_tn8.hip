@@ -103,20 +103,23 @@ __device__ __forceinline__ void tn8_body(const bf16_t* __restrict__ A, int64_t l
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)0xFFFFFE00u, 0x00020000);
   const uint32_t strideA = (uint32_t)(C::BP * lda * 2), strideB = (uint32_t)(C::BP * ldb * 2);
   const uint32_t baseA = (uint32_t)((int64_t)p_begin * lda * 2), baseB = (uint32_t)((int64_t)p_begin * ldb * 2);
-  // listed mode: 64 list entries (= 16 K-tiles) sit in one register per lane, re-read when an issue crosses into the next group
-  int list_reg = (listed && lane < n_list) ? ep.tile_list[lane] : -1;
-  int list_grp = 0;
+  // listed mode: the list is copied to LDS once (TN_LIST_LDS bytes behind the ring) and read from there by a broadcast ds_read per
+  // fetch.  Round 4 kept 64 entries in a register re-loaded INSIDE the issue path: a tracked global load in a conditional block, after
+  // which hipcc could not count the fetch queue any more and drained it (vmcnt(0)) before every fetch - 555 us per launch listed, and
+  // waits at the merges of the unlisted path too (gemm.hip tn_tile_body has the same story)
+  int* lds_list = (int*)(smem + C::LDS);
+  if (listed) {
+    for (int e = tid; e < n_list; e += 512) lds_list[e] = ep.tile_list[e];
+    __syncthreads();
+  }
   auto issue = [&](auto s_c, int stage, int ktile) {
     constexpr int s = decltype(s_c)::value;
     constexpr bool is_b = (s * 8 >= C::NPA);                // pieces 0..31 are A, 32..47 B: s = 0..3 -> A, 4..5 -> B for every wave
     static_assert(C::NPA % 8 == 0, "operand boundary falls between two piece rounds");
     if (listed) {
-      if ((ktile >> 4) != list_grp) {                       // (wave-uniform)
-        list_grp = ktile >> 4;
-        list_reg = (list_grp * 64 + lane < n_list) ? ep.tile_list[list_grp * 64 + lane] : -1;
-      }
       const int quarter = is_b ? (s - 4) * 2 + (wave >> 2) : s;
-      const int blk = __builtin_amdgcn_readlane(list_reg, ((ktile & 15) << 2) + quarter);
+      const int e = (ktile << 2) + quarter;
+      const int blk = e < n_list ? __builtin_amdgcn_readfirstlane(lds_list[e]) : -1;
       const uint32_t voff = (colok[s] && blk >= 0) ? go[s] : 0xFFFFFF00u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(is_b ? rsB : rsA, (__attribute__((address_space(3))) void*)(smem + stage * C::STAGE + lo[s]), 16,
                                                voff, (uint32_t)max(blk, 0) * ((is_b ? strideB : strideA) >> 2), 0, 0);
@@ -271,15 +274,16 @@ int gemm_tn8_group(hipStream_t st, int n, const TnGroupProblem<bf16_t>* probs, i
   }
   grp.total_tiles = total;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_tn8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS); attr_set = true; }
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_tn8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + TN_LIST_LDS); attr_set = true; }
+  if (grp.tile_list != nullptr && P / 16 > TN_LIST_LDS / 4) return RL_ERR_ARG;
   ProfScope ps(st, PK_GEMM_TN, flops);
   if (grp.tile_list != nullptr) prof_set_exec(grp.n_tiles, flops / P * 16, 4, P / 16);
-  RL_LAUNCH(gemm_tn8_group_kernel, dim3(total), dim3(512), C::LDS, st, grp, P, P);
+  RL_LAUNCH(gemm_tn8_group_kernel, dim3(total), dim3(512), C::LDS + (grp.tile_list != nullptr ? TN_LIST_LDS : 0), st, grp, P, P);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
 bool tn8_supported(int64_t lda, int64_t ldb, int P, int I, int J, const TnEpi& ep) {
-  return ep.mode == TN_PLAIN && P >= 1024 && I >= 256 && J >= 128 && (J % 4) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (I % 8) == 0 &&
+  return ep.mode == TN_PLAIN && ep.tile_list == nullptr &&      // (a live-block list needs the grouped launch's LDS list area) P >= 1024 && I >= 256 && J >= 128 && (J % 4) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (I % 8) == 0 &&
          (J % 8) == 0 && (int64_t)P * lda * 2 < 0xFFFFFE00ll && (int64_t)P * ldb * 2 < 0xFFFFFE00ll && (ep.ldo % 4) == 0;
 }
 
