@@ -647,16 +647,10 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
   int ptr_tile = p_begin / BP;           // the reduction tile pa / pb point at (live-tile list mode)
   int ptr_sub = 0;                       // sub16: the 16-row block this wave's pointers stand on
   bool sub_ok = true;                    // sub16: this wave has a block in the tile being issued (the last tile may hold fewer than four)
-  // A tile's fetches in two parts, so that the main loop can spread them between its MFMAs: issue_begin() moves the running pointers to
-  // the tile (scalar work), issue_piece(k) emits fetch k of this wave (k < NA: operand A, else B) and steps its pointer.  Issued in one
-  // block in front of the MFMAs - the round-1..4 form - a wave spent the ~100 issue slots of its eight fetches (address selects, 64-bit
-  // pointer steps, M0 set-up, ~60-100 clk per LDS-DMA instruction) with its MFMA pipe idle.
-  char* ibase = smem;
-  int ipt = 0;
-  bool ifull = true;
-  auto issue_begin = [&](int pt, int stage) {
-    ibase = smem + stage * STAGE; ipt = pt;
-    ifull = sub16 || pt + BP <= p_end;
+  auto issue = [&](int pt, int stage) {
+    if (RL_PROBES && ep.probe == 2) return;
+    char* base = smem + stage * STAGE;
+    const bool full = sub16 || pt + BP <= p_end;
     if (sub16) {
       // pt = this wave's block index (wave-uniform) or -1.  Blocks are mostly 4 apart (consecutive tiles of live rows): the running
       // pointers advance by one tile after every issue and only the difference to that is applied here
@@ -671,7 +665,9 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
         }
       }
       ptr_sub = (sub_ok ? pt : ptr_sub) + 4;
-    } else if (listed) {
+    } else
+    // listed tiles are not consecutive: the pointers are rebuilt from the tile's first row (pa / pb hold the addresses of row 0 then)
+    if (listed) {
       // listed tiles are mostly consecutive: the running pointers only jump (a wave-uniform number of tiles) over a run of dead blocks
       const int d = pt / BP - ptr_tile;
       if (d != 0) {
@@ -684,31 +680,28 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
       }
       ptr_tile = pt / BP + 1;
     }
-  };
-  auto issue_piece = [&](int k) {            // k: compile-time after unrolling
-    if (RL_PROBES && ep.probe == 2) return;
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-      if (q != k) continue;
       const void* src = pa[q];
-      if (!ifull && ipt + apl[q] >= p_end) src = zero;
+      if (!full && pt + apl[q] >= p_end) src = zero;
       if (sub16 && !sub_ok) src = zero;
-      glds16(src, ibase + (wave * NA + q) * 1024);
+      glds16(src, base + (wave * NA + q) * 1024);
       pa[q] += inca[q];
     }
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-      if (q + NA != k) continue;
+      const void* src = zero;
       if constexpr (kDenseB) {
-        const void* src = pb[q];
-        if (!ifull && ipt + bpl[q] >= p_end) src = zero;
+        src = pb[q];
+        if (!full && pt + bpl[q] >= p_end) src = zero;
         if (sub16 && !sub_ok) src = zero;
         pb[q] += incb[q];
-        glds16(src, ibase + A_BYTES + (wave * NB + q) * 1024);
       } else {
-        const int p = ipt + bpl[q];
-        ctap.fetch(lb, q, p, p < p_end && bok[q], ibase + A_BYTES + (wave * NB + q) * 1024);
+        const int p = pt + bpl[q];
+        ctap.fetch(lb, q, p, p < p_end && bok[q], base + A_BYTES + (wave * NB + q) * 1024);
+        continue;
       }
+      glds16(src, base + A_BYTES + (wave * NB + q) * 1024);
     }
   };
 
@@ -728,28 +721,21 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
     for (int e = tid; e < n_ent; e += 256) lds_list[e] = ep.tile_list[e];
     __syncthreads();
   }
-  // scalar half of the next tile's issue; false when there is none
-  auto begin_next = [&]() -> bool {
-    if (issued >= nt) return false;
-    int pt = p_begin + issued * BP;
-    if (sub16) {
-      const int e = 4 * issued + wave;
-      pt = e < n_ent ? __builtin_amdgcn_readfirstlane(lds_list[e]) : -1;
-    } else if (listed) {
-      pt = __builtin_amdgcn_readfirstlane(lds_list[issued]) * BP;
+  auto issue_next = [&]() {
+    if (issued < nt) {
+      int pt = p_begin + issued * BP;
+      if (sub16) {
+        const int e = 4 * issued + wave;
+        pt = e < n_ent ? __builtin_amdgcn_readfirstlane(lds_list[e]) : -1;
+      } else if (listed) {
+        pt = __builtin_amdgcn_readfirstlane(lds_list[issued]) * BP;
+      }
+      issue(pt, issued % NST);
+      ++issued;
     }
-    issue_begin(pt, issued % NST);
-    ++issued;
-    return true;
   };
 #pragma unroll
-  for (int q = 0; q < NST - 1; ++q) {
-    if (begin_next()) {
-#pragma unroll
-      for (int k = 0; k < NL; ++k) issue_piece(k);
-    }
-  }
-  constexpr int SLOTS = 4 * KST;                       // MFMA rows of a tile: one fetch behind each
+  for (int q = 0; q < NST - 1; ++q) issue_next();
   for (int t = 0; t < nt; ++t) {
     // tile t has landed once at most the (issued - 1 - t) younger tiles' fetches are outstanding (counted vmcnt; raw barrier:
     // __syncthreads() would drain vmcnt to 0)
@@ -759,17 +745,11 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const bool more = begin_next();                    // into the stage every wave finished reading before this barrier
+    issue_next();                                      // into the stage every wave finished reading before this barrier
     const int cur = t % NST;
     const char* At = smem + cur * STAGE;
     const char* Bt = At + A_BYTES;
-    if (RL_PROBES && ep.probe == 3) {
-      if (more) {
-#pragma unroll
-        for (int k = 0; k < NL; ++k) issue_piece(k);
-      }
-      continue;
-    }
+    if (RL_PROBES && ep.probe == 3) continue;
 #pragma unroll
     for (int ks = 0; ks < KST; ++ks) {
       typename Mma::Frag a[4], b[4];
@@ -786,22 +766,12 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = Mma::mma(b[j], a[i], acc[i][j]);
-        if (do_colsum) csum[i] = Mma::mma(ones, a[i], csum[i]);   // every row of the result = sum_p A[p, i]
-        // the next tile's fetch number (ks * 4 + i) goes out behind this row of MFMAs (LDS reads may still be moved across: mask 0x180)
-        if (ks * 4 + i < NL) {
-          __builtin_amdgcn_sched_barrier(0x180);
-          if (more) issue_piece(ks * 4 + i);
-          __builtin_amdgcn_sched_barrier(0x180);
-        }
-      }
-    }
-    if constexpr (NL > SLOTS) {
-      if (more) {
+      if (do_colsum) {
 #pragma unroll
-        for (int k = SLOTS; k < NL; ++k) issue_piece(k);
+        for (int f = 0; f < 4; ++f) csum[f] = Mma::mma(ones, a[f], csum[f]);   // every row of the result = sum_p A[p, i]
       }
     }
   }
