@@ -16,7 +16,7 @@ Rank 0 prints ONE JSON line.
 * `roofline`         the dominant kernel family - the bf16 MFMA NT GEMMs (every nn.Linear forward / data gradient, classifier,
                      GRU step) - timed per launch with HIP events recorded on the launch stream during the timed region;
                      `traffic` = HBM bytes per launch from the committed PMC passes of this same command, null when the
-                     kernels changed since those passes (profiles/round2_pmc_traffic.json carries a hash of csrc/).
+                     kernels changed since those passes (profiles/round5_pmc_traffic.json carries a hash of csrc/).
 * `forward`          forward-only timings (eval mode and train mode) with their MFMA utilisation - the north-star's own target
                      metric (>= 40 % bf16 MFMA utilisation on the fused forward).
 * FLOP accounting    `nominal` = dense FLOPs of the reference's graph; `executed` = what the engine
@@ -51,8 +51,8 @@ RESNET_FLOPS_PER_STACK = 126418944      # CharResNet forward on one 3 x 32 x 32 
 # HIP-event pairs around every launch of the MFMA kernel families cost ~4 us of stream time each (~8 % of a step when every
 # step is bracketed): the timed region brackets every 10th step, which leaves the averages intact and the cost below 1 %.
 PROFILE_EVERY = 10
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "round4_pmc_traffic.json")
-ROCPROF_STATS = os.path.join(ROOT, "profiles", "round4_final_kernel_stats.md")
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "round5_pmc_traffic.json")
+ROCPROF_STATS = os.path.join(ROOT, "profiles", "round5_final_kernel_stats.md")
 NT_KERNEL_PREFIXES = ["gemm_nt8_kernel", "gemm_nt8p_kernel", "gemm_nt_kernel<bf16_t, DenseLoader<bf16_t>", "gemm_nt_ln_kernel"]
 
 
@@ -95,7 +95,7 @@ def pmc_traffic_per_launch(prefixes):
 
 def rocprof_family_avg(prefixes):
     """launch-weighted average duration (us) and ms/step of a kernel family in the committed rocprofv3 --kernel-trace --stats summary
-    of this same command (profiles/round4_final_kernel_stats.md, branches serial); None when that file is absent.  The summary is a
+    of this same command (profiles/round5_final_kernel_stats.md, branches serial); None when that file is absent.  The summary is a
     record of an earlier run of the same kernels: `roofline.avg_launch_us` (measured live, below) must agree with it."""
     try:
         rows = [l.split("|") for l in open(ROCPROF_STATS) if l.startswith("| `")]
