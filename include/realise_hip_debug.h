@@ -33,7 +33,11 @@ void realise_set_nt_variant(int v);
  * time step as one launch (recurrent GEMM with the gate math in its epilogue: 1, default) or as GEMM + gate kernel (0); key 10 = bf16
  * training steps run the layer GEMMs of the transformer stacks (forward and data gradients) and the attention forward over the live
  * 16-row blocks of the padded batch only (1, default: loss, live-row logits and gradients bit-identical to the dense step; the rows
- * behind a sentence's last attended / loss position keep stale activations) or over all rows (0) */
+ * behind a sentence's last attended / loss position keep stale activations) or over all rows (0); key 11 = the layer GEMMs with enough
+ * K-tiles to share out (qkv, FFN-up / -down and their data gradients) on the stream-K 256 x 192 kernel (1) or on the 128 x 192 two-per-CU
+ * kernels (0, default: measured faster on every layer shape, and their live-row results are bit-identical to the dense step's - a tile that
+ * stream-K cuts sums its K range in two or three chains); key 12 = the least K-tiles per workgroup of a launch that select the stream-K
+ * kernel under key 11 (default 10; 0: every shape it supports) */
 void realise_set_engine(int key, int value);
 /* realise_gemm_tn_grouped over a list of live reduction blocks, as the engine's backward calls it: live[k] (device, ascending) = index
  * of the k-th block of `list_rows` rows that holds anything but exact zeros in the A operands, *n_live (device) = how many; the other
@@ -50,6 +54,15 @@ int realise_gemm_nt_rows(void* stream, int dtype, const void* A, int64_t lda, co
  * are neither read nor written. */
 int realise_gemm_nt_live(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
                          const realise_epilogue* ep, const int* live_list, const int* live_count);
+/* The stream-K form of the layer GEMMs (bf16, K % 128 == 0; gemm_nt8s.hip): ONE round of 256 workgroups over 256 x 192 tiles, the
+ * (tile, K-tile) space cut into 256 equal ranges, tiles that a cut splits folded in-kernel in workgroup order.  live_list / live_count
+ * as realise_gemm_nt_live, or both NULL (all rows).  part: exchange buffer of 256 * 24 * 512 * 16 bytes; flags: 256 x 64 ints (a flag every 256 bytes), zero before the
+ * first launch; tag: never 0, different from the previous launch's on the same buffers; timeout (nullable): set to 1 if a workgroup gave
+ * up waiting for a partial tile.  Reproducible bit for bit for given (shape, live count); differs in the last bits from
+ * realise_gemm_nt / realise_gemm_nt_live where a tile's K range is cut (two or three accumulation chains instead of one). */
+int realise_gemm_nt_streamk(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                            const realise_epilogue* ep, const int* live_list, const int* live_count, float* part, int* flags, int tag,
+                            int* timeout);
 /* Split-K form of the 8-wave NT GEMM as the classifier's data gradient uses it (bf16, K % 64 == 0): slab[s][m][n] (fp32, row pitch N,
  * plane pitch slab_stride floats) = A[m, K-range s] . B[n, K-range s]^T; rows at or beyond *m_dev (device, nullable) are not computed. */
 int realise_gemm_nt_splitk(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K, int nsplit,
@@ -60,6 +73,10 @@ int realise_gemm_tn_grouped_live(void* stream, int dtype, int n, const realise_t
  * [dgamma | dbeta] records in `slots` (8 MiB scratch) folded in a fixed order.  tools/ln_probe.py times it. */
 int realise_layernorm_bwd_ex(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,
                              uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* dgamma, float* dbeta, float* slots, int rows, int H);
+/* realise_layernorm_fwd (bf16, rows % 16 == 0) as a live-row training step launches it: row_live = one byte per row (0 = padding).  A
+ * 16-row block without a live row is not visited - its y / xhat / rstd rows keep what they held -, a block with one is computed whole. */
+int realise_layernorm_fwd_live(void* stream, const void* x, const float* gamma, const float* beta, float eps, void* y, void* xhat, float* rstd,
+                               const uint8_t* row_live, int rows, int H);
 /* the same with the row-liveness bytes of a padded batch (row_live[r] == 0: dy[r] is an exact zero - the row is not read, its outputs are zeros) */
 int realise_layernorm_bwd_live(void* stream, const void* dy, const void* xhat, const float* rstd, const float* gamma, void* dx, void* dx_drop,
                                uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, float* dgamma, float* dbeta, float* slots,

@@ -78,6 +78,7 @@ SYMBOLS = {
     "realise_gemm_tn_grouped": (_I, [_P, _I, _I, C.POINTER(TnProblem), _I]),
     "realise_gemm_nt_rows": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue), _P]),
     "realise_gemm_nt_live": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue), _P, _P]),
+    "realise_gemm_nt_streamk": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue), _P, _P, _P, _P, _I, _P]),
     "realise_gemm_nt_splitk": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
     "realise_gemm_tn_grouped_live": (_I, [_P, _I, _I, C.POINTER(TnProblem), _I, _P, _P, _I, _I]),
     "realise_conv_tn": (_I, [_P, _I, _P, _L, C.POINTER(ConvGeom), _I, _I, _I, _P, _P, _L]),
@@ -90,6 +91,7 @@ SYMBOLS = {
     "realise_set_ln": (None, [_I, _I]),
     "realise_set_engine": (None, [_I, _I]),
     "realise_layernorm_bwd_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_float, _P, _P, _P, _I, _I]),
+    "realise_layernorm_fwd_live": (_I, [_P, _P, _P, _P, C.c_float, _P, _P, _P, _P, _I, _I]),
     "realise_layernorm_bwd_live": (_I, [_P, _P, _P, _P, _P, _P, _P, C.c_uint32, C.c_uint32, C.c_float, _P, _P, _P, _P, _I, _I]),
     "realise_batchnorm_stats_ex": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, C.c_float, C.c_float] + [_P] * 9),
     "realise_batchnorm_bwd_ex": (_I, [_P, _P, _P, _I, _I, _I, _P, _I] + [_P] * 7 + [_P] * 7 + [_P, _P]),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "librealise_hip.so")
-SOURCES = ["gemm.hip", "gemm_nt8.hip", "gemm_nt8p.hip", "gemm_tn8.hip", "conv_wgrad_c64.hip", "conv_c64_nt.hip", "attention.hip", "ops.hip", "ops2.hip", "engine.hip", "capi.hip", "prof.hip"]
+SOURCES = ["gemm.hip", "gemm_nt8.hip", "gemm_nt8p.hip", "gemm_nt8s.hip", "gemm_tn8.hip", "conv_wgrad_c64.hip", "conv_c64_nt.hip", "attention.hip", "ops.hip", "ops2.hip", "engine.hip", "capi.hip", "prof.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc"]
 
 

@@ -81,6 +81,14 @@ void set_cls_splitk(int n) { g_cls_splitk = n < 0 ? 0 : (n > 4 ? 4 : n); }
 // accumulation order per row; tests/test_round4_gpu.py).  Evaluation / inference forwards are always dense.
 static int g_live_rows = 1;
 void set_live_rows(int on) { g_live_rows = on; }
+// realise_set_engine(11, v): 1 = the layer GEMMs of the transformer stacks on the stream-K 256 x 192 kernel (gemm_nt8s.hip) where its
+// one-round launch has at least g_streamk_min (realise_set_engine(12, n), default 10) K-tiles per workgroup to share out; 0 (default): the
+// 128 x 192 two-per-CU kernels only.  Measured (tools/streamk_probe.py, profiles/round5_streamk_probe.log): correct, reproducible,
+// and slower than the two-per-CU kernel on every layer shape - DESIGN.md section 6.6.
+static int g_streamk = 0;
+static int g_streamk_min = 10;
+void set_streamk(int v) { g_streamk = v > 0 ? 1 : 0; }
+void set_streamk_min(int n) { g_streamk_min = n > 0 ? n : 0; }
 static int g_stream_pri[3] = {0, 0, 0};
 void set_stream_priority(int which, int pri) { if (which >= 0 && which < 3) g_stream_pri[which] = pri < 0 ? -1 : (pri > 0 ? 1 : 0); }
 static hipError_t create_stream(hipStream_t* s, int which) {
@@ -146,6 +154,7 @@ template <typename T> struct Engine : EngineBase {
     BlockAct blk[5];
     int64_t mask_add, out_d, dlogits, count, loss_internal;
     int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc, cls_slab;
+    int64_t sk_part[3] = {0, 0, 0}, sk_flag[3] = {0, 0, 0};       // stream-K GEMMs: exchange buffer + workgroup flags, one set per stack (= stream)
     int64_t ln_part[3] = {0, 0, 0}, ln_flag[3] = {0, 0, 0};       // fused GEMM + LayerNorm: per-row tile partials + arrival counters, one set per stack (= stream)
     int64_t row_live, live_t64, live_t32, live_t16, live_n, live_rlen;          // padding rows: exact-zero gradient rows the backward skips (row_liveness)     // classifier backward over the rows that enter the loss only (stage_head)
     int64_t ids_clean = 0, pho_clean = 0;                 // range-checked copies of src_idx / pho_idx (sanitize_ids)
@@ -233,13 +242,25 @@ template <typename T> struct Engine : EngineBase {
   int live_list_rows() const { return sizeof(T) == 2 ? (live16() ? 16 : 64) : 32; }
   bool rows_live = false;                  // the last forward ran its layer GEMMs over the live 16-row blocks (g_live_rows); the backward follows
   // a layer GEMM over the token rows: the live blocks of a live-row step (no dense fall-back: the dead rows of its operands are stale)
+  int nt_sid = -1;                         // stack whose layers are being enqueued (stack_forward / layers_backward): selects the stream-K buffers
+  unsigned sk_epoch[3] = {0, 0, 0};
   int nt_rows(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep) {
     if constexpr (sizeof(T) == 2) {
-      if (rows_live) {
-        EpiParams<T> e2 = ep;
-        e2.live_list = wp<int>(pl.live_t16); e2.live_count = wp<int>(pl.live_n) + 2;
-        return gemm_nt8_live(st, A, lda, B, ldb, M, N, K, e2);
+      EpiParams<T> e2 = ep;
+      if (rows_live) { e2.live_list = wp<int>(pl.live_t16); e2.live_count = wp<int>(pl.live_n) + 2; }
+      // one round of 256 workgroups over 256 x 192 tiles (stream-K) where there is enough to share out; a stack's launches are
+      // serialised by its stream, so one exchange buffer per stack does
+      if (g_streamk && nt_sid >= 0 && nt_sid < 3 && pl.sk_part[nt_sid] != 0 &&
+          (int64_t)((M + 255) / 256) * ((N + 191) / 192) * (K / 64) >= (int64_t)g_streamk_min * NT8S_GRID) {
+        e2.sk_part = wp<float>(pl.sk_part[nt_sid]); e2.sk_flag = wp<int>(pl.sk_flag[nt_sid]);
+        e2.sk_tag = (int)(sk_epoch[nt_sid] % 0x7FFFFFF0u) + 1;
+        e2.sk_timeout = id_flag != nullptr ? id_flag + 1 : nullptr;
+        const int rc = gemm_nt8s(st, A, lda, B, ldb, M, N, K, e2);
+        if (rc == RL_OK) { ++sk_epoch[nt_sid]; return RL_OK; }
+        if (rc != RL_ERR_ARG) return rc;
+        e2.sk_part = nullptr; e2.sk_flag = nullptr; e2.sk_tag = 0; e2.sk_timeout = nullptr;
       }
+      if (rows_live) return gemm_nt8_live(st, A, lda, B, ldb, M, N, K, e2);
     }
     return gemm_nt<T>(st, A, lda, B, ldb, M, N, K, ep);
   }
@@ -488,6 +509,7 @@ template <typename T> struct Engine : EngineBase {
     p.cls_slab = (!glyph_only && sizeof(T) == 2) ? b.take(4 * Tk * H * 4) : 0;      // fp32 planes of the split-K classifier data gradient
     if (!glyph_only && sizeof(T) == 2) {
       for (int k = 0; k < 3; ++k) {
+        p.sk_part[k] = b.take(NT8S_PART_BYTES); p.sk_flag[k] = b.take((int64_t)NT8S_GRID * NT8S_FLAG_STRIDE * 4 + 256);      // (flags: zero with the workspace; tags are never 0)
         p.ln_part[k] = b.take(Tk * 8 * 2 * 8);
         p.ln_flag[k] = 0;
         p.zero_once.push_back({p.ln_part[k], Tk * 8 * 2 * 8});
@@ -621,6 +643,7 @@ template <typename T> struct Engine : EngineBase {
   int stack_forward(hipStream_t st, int sid, const StackOff& so, const std::vector<LayerSh>& shs, StackAct& a,
                     const int64_t* ids, const T* embeds, int pos_zero, const T** out) {
     const int B = pl.B, S = pl.S, Tk = B * S;
+    nt_sid = sid;
     {
       LnFwdArgs<T> ln;
       ln.rows = Tk; ln.H = H; ln.S = S;
@@ -693,6 +716,7 @@ template <typename T> struct Engine : EngineBase {
   int layers_backward(hipStream_t st, int sid, const StackOff& so, const std::vector<LayerSh>& shs, StackAct& a, int hi, int lo,
                       T* gA) {
     const int B = pl.B, S = pl.S, Tk = B * S;
+    nt_sid = sid;
     const typename Plan::Scratch& sc = pl.sc[cs];
     T* gB = wp<T>(sc.gB); T* gE = wp<T>(sc.gE);
     const bool ov = g_wgrad_overlap && (!branch_mode || cs == 0) && side_ok();      // under branch overlap only the bert branch owns two dY sets
@@ -1073,6 +1097,7 @@ template <typename T> struct Engine : EngineBase {
     RL_TRY(nt_rows(st, a, K, w, K, Tk, H, K, ep));
     LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = s_xhat; ln.gamma = gamma; ln.beta = beta;
     ln.eps = cfg.ln_eps; ln.y = y; ln.xhat = s_xhat; ln.rstd = rstd;
+    if (rows_live && (Tk % 16) == 0) ln.row_live = live_rows();      // x holds fresh rows in the listed blocks only: the others are not worth a pass
     return ln_fwd<T>(st, ln);
   }
   int install_plan(hipStream_t st, const Plan& p) {

@@ -85,7 +85,17 @@ template <typename T> struct EpiParams {
   T* gru_gh = nullptr;                  // [M][3H]: only the n third is written
   T* gru_out = nullptr;                 // [N tokens][H], original order
   int gru_Tp = 0, gru_t = 0;
+  // Stream-K form (gemm_nt8s): the exchange buffer of the launch (NT8S_PART_BYTES, private to the stream while the launch runs), one
+  // flag per workgroup (NT8S_GRID x NT8S_FLAG_STRIDE ints, zero-filled once), the launch tag (never 0, different from the previous launch's on the same
+  // buffers) and an optional word that is set to 1 if a finisher gave up waiting for a partial
+  float* sk_part = nullptr;
+  int* sk_flag = nullptr;
+  int sk_tag = 0;
+  int* sk_timeout = nullptr;
 };
+constexpr int NT8S_GRID = 256;                                    // one workgroup per CU
+constexpr int NT8S_FLAG_STRIDE = 64;                              // ints between two workgroups' flags (256 B: different memory channels)
+constexpr int64_t NT8S_PART_BYTES = (int64_t)NT8S_GRID * 24 * 512 * 16;      // 256 x 192 fp32 per workgroup
 
 // ---- operand loaders ---------------------------------------------------------------------------
 // A loader maps (row, k) of a logical K-contiguous operand to the global address of a 16-byte chunk
@@ -403,6 +413,10 @@ bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda
 // persistent 256 x 192 kernel with the LDS-free epilogue (gemm_nt8p.hip): EPI_STORE / EPI_GELU / EPI_GELU_BWD, K % 64 == 0
 bool nt8p_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb);
 int gemm_nt8p(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
+// stream-K persistent 256 x 192 kernel (gemm_nt8s.hip): one round of NT8S_GRID workgroups over equal K-tile ranges, partial tiles folded
+// in-kernel in a fixed order; optional live-block list; EPI_STORE (+ accumulate) / EPI_GELU / EPI_GELU_BWD / EPI_DROP_RESID, K % 128 == 0
+bool nt8s_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb);
+int gemm_nt8s(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
 void set_nt8p_wgs(int n);
 void set_nt8_epi_pre(int on);      // 1 (default): alpha / bias into the accumulators before the 8-wave kernels' epilogue transposes (one bias fetch per wave, no per-item waits)
 void set_nt8_live_gc(int gc);      // live-row GEMMs: 0 (default) column groups of the XCD split from the shape, 1 / 2 / 4 / 8 forced

@@ -29,7 +29,8 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 __device__ __forceinline__ u32x4 asm_buffer_load_b128(uint32_t voff, i32x4 rsrc) {
   u32x4 v = {0u, 0u, 0u, 0u};
 #if defined(__HIP_DEVICE_COMPILE__)
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(rsrc) : "memory");
+  // (s_nop 4: 5 wait states behind a VALU write - a spill restore - of the descriptor, which hipcc does not pad for asm text: tools/isa_hazard_scan.py)
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(v) : "v"(voff), "s"(rsrc) : "memory");
 #endif
   return v;
 }

@@ -50,6 +50,10 @@ template <typename T> struct LnFwdArgs {
   T* xhat = nullptr;               // may alias x
   float* rstd = nullptr;
   DropParams drop;                 // applied to y (embeddings)
+  // optional (bf16 fast path, in_mode 0): one byte per row, 0 = padding (engine row_liveness; readable up to the next multiple of 16
+  // rows).  A 16-row block without a live row is not visited - y / xhat / rstd keep what they held, as the rows of an unlisted block do in
+  // the live-row GEMM that produced x (gemm_nt8_live); blocks with a live row are computed whole.
+  const uint8_t* row_live = nullptr;
 };
 template <typename T> int ln_fwd(hipStream_t st, const LnFwdArgs<T>& a);
 

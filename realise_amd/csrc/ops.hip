@@ -105,6 +105,11 @@ __global__ void __launch_bounds__(256) ln_fwd16_kernel(LnFwdArgs<bf16_t> a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
   const int H = a.H;
   const int row0 = (blockIdx.x * 4 + wave) * (2 * RP) + half;
+  if (a.row_live != nullptr) {           // (the wave's 2 RP rows lie in one 16-row block: wave-uniform)
+    static_assert(16 % (2 * RP) == 0, "a wave's rows must not straddle 16-row blocks");
+    const uint4 lv = *(const uint4*)(a.row_live + (((blockIdx.x * 4 + wave) * (2 * RP)) & ~15));
+    if ((lv.x | lv.y | lv.z | lv.w) == 0u) return;
+  }
   uint4 raw[RP][NV8];
 #pragma unroll
   for (int r = 0; r < RP; ++r) {

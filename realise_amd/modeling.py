@@ -390,7 +390,7 @@ class RealiseModule(nn.Module):
         f = getattr(self, "_id_flag", None)
         if f is not None and int(f[1]) != 0:
             f[1] = 0                          # (only the flag being reported: a bad id seen in the same window still raises below / next time)
-            raise RuntimeError("a workgroup of the fused dense + LayerNorm launch gave up waiting for the other tiles of its rows in an "
+            raise RuntimeError("a workgroup of a fused dense + LayerNorm launch (or a stream-K layer GEMM: realise_set_engine(11, 1)) gave up waiting for another workgroup in an "
                                "earlier step (results of that step are invalid); realise_set_engine(8, 0) runs the two-launch form")
         if f is not None and int(f[0]) != 0:
             f[0] = 0

@@ -300,3 +300,109 @@ def test_live_row_gemm_under_every_xcd_split(gc, M, N, K, mode, accumulate, bloc
         r4.test_nt_gemm_over_a_list_of_live_row_blocks(M, N, K, mode, accumulate, blocks)
     finally:
         lib.realise_set_nt8p(3, 0)
+
+
+def _streamk_probe():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("streamk_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "streamk_probe.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("M,N,K,mode,accumulate,kind", [
+    (8192, 2304, 768, 0, 0, "bench"),           # qkv over a batch-shaped live list: tiles cut between workgroups
+    (8192, 3072, 768, 1, 0, "dense"),           # FFN-up + GELU, all rows: two whole tiles per workgroup, no cut - bit-identical
+    (8192, 768, 3072, 2, 0, "ragged"),          # FFN-down + dropout + residual: a tile's K range spread over three or four workgroups
+    (8192, 3072, 768, 4, 0, "bench"),           # GELU' data gradient
+    (8192, 768, 2304, 0, 1, "bench"),           # accumulating data gradient
+    (1024, 768, 768, 2, 0, "one"),              # one listed block: most workgroups have nothing to do
+    (256, 192, 128, 0, 0, "odd"),               # one tile, two K-tiles
+    (1008, 776, 128, 0, 0, "dense"),            # ragged N, rows not a multiple of 256
+    (512, 200, 256, 0, 1, "dense")])
+def test_stream_k_layer_gemm_against_the_one_chain_kernels(M, N, K, mode, accumulate, kind):
+    """gemm_nt8s (realise_gemm_nt_streamk; realise_set_engine(11, 1) - off by default, measured slower): one round of 256 workgroups over
+    equal K-tile ranges of 256 x 192 tiles, cut tiles folded in-kernel in workgroup order.  Same operands, same dropout masks as the
+    128 x 192 kernels: results within one bf16 rounding step (a cut tile sums its K range in two or three fp32 chains; uncut tiles are
+    bit-identical), rows of unlisted blocks untouched although their A rows are NaN, two launches bit-identical, no wait gave up."""
+    sp = _streamk_probe()
+    assert sp.check(sp.Ctx(), M, N, K, mode, accumulate, kind, "test")
+
+
+def test_stream_k_training_step_is_reproducible_and_close_to_the_default():
+    """realise_set_engine(11, 1) + (12, 0): every layer GEMM the stream-K kernel supports runs on it (forward and data gradients, live
+    rows).  Two runs from the same state give the same bits; against the default kernels the loss and every gradient agree to the
+    tolerance the other summation-order knobs are held to; no finisher gave up waiting (the engine's flag word stays 0)."""
+    lib = _capi.load()
+    cfg = RealiseConfig(num_hidden_layers=2, pho_layers=1, out_layers=1)
+    sd = init_state_dict_numpy(cfg, seed=11)
+    batch = cuda_batch(16, 128, 23)
+
+    def run(on):
+        lib.realise_set_engine(11, on)
+        lib.realise_set_engine(12, 0 if on else 10)
+        try:
+            m = build(cfg, sd, "bf16", train=True)
+            out = []
+            for _ in range(2):
+                m.zero_grad()
+                loss, _ = m(batch)
+                loss.backward()
+                torch.cuda.synchronize()
+                out.append((float(loss.item()), grads_of(m)))
+            m.check_ids()                      # raises if a stream-K wait gave up
+            return out
+        finally:
+            lib.realise_set_engine(11, 0)
+            lib.realise_set_engine(12, 10)
+
+    ref, a, b = run(0), run(1), run(1)
+    for (l0, g0), (l1, g1), (l2, g2) in zip(ref, a, b):
+        assert l1 == l2
+        assert abs(l0 - l1) <= 2e-3 * abs(l0)
+        layer_w = [n for n in g0 if ".layer." in n and n.endswith("weight") and "LayerNorm" not in n]
+        assert layer_w and all(torch.equal(g1[n], g2[n]) for n in layer_w)      # order-fixed kernels: bit for bit run to run
+        for n in g0:
+            s = g0[n].abs().max().item()
+            assert torch.isfinite(g1[n]).all(), n
+            assert (g1[n] - g2[n]).abs().max().item() <= 2e-5 * s + 1e-12, n      # (the tensors behind float atomics: last bits)
+            assert (g0[n] - g1[n]).abs().max().item() <= 2e-2 * s + 1e-12, n
+
+
+@pytest.mark.parametrize("rows,H,S", [(8192, 768, 128), (640, 768, 40), (512, 256, 64)])
+def test_layernorm_forward_skips_blocks_without_a_live_row(rows, H, S):
+    """ln_fwd with LnFwdArgs::row_live (realise_layernorm_fwd_live), as dense_resid_ln launches it in a live-row step: 16-row blocks
+    without a live row are not visited (outputs keep their contents, NaN inputs there do no harm), every other row - dead rows of a
+    partly live block included - carries the plain launch's bits."""
+    lib = _capi.load()
+    g = torch.Generator().manual_seed(rows + H)
+    x = torch.randn(rows, H, generator=g).bfloat16().cuda()
+    gamma = (1.0 + 0.1 * torch.randn(H, generator=g)).float().cuda()
+    beta = (0.1 * torch.randn(H, generator=g)).float().cuda()
+    live = torch.zeros(rows + 64, dtype=torch.uint8)
+    rng = np.random.default_rng(rows)
+    for b0 in range(0, rows, S):                 # a live prefix per sentence (S = 40: blocks straddle sentences)
+        live[b0:b0 + int(rng.integers(1, S + 1))] = 1
+    live = live.cuda()
+    blk_live = live[:rows].view(-1, 16).any(1).repeat_interleave(16)
+
+    def run(use_live):
+        y = torch.full((rows, H), 7.0, dtype=torch.bfloat16, device="cuda")
+        xh = torch.full((rows, H), 7.0, dtype=torch.bfloat16, device="cuda")
+        rs = torch.full((rows,), 7.0, dtype=torch.float32, device="cuda")
+        xin = x.clone()
+        if use_live:
+            xin[~blk_live] = float("nan")
+            _capi.check(lib.realise_layernorm_fwd_live(stream(), P(xin), P(gamma), P(beta), 1e-12, P(y), P(xh), P(rs), P(live), rows, H), "ln_fwd_live")
+        else:
+            _capi.check(lib.realise_layernorm_fwd(stream(), _capi.BF16, P(xin), P(gamma), P(beta), 1e-12, P(y), P(xh), P(rs), rows, H), "ln_fwd")
+        torch.cuda.synchronize()
+        return y, xh, rs
+
+    y1, xh1, rs1 = run(True)
+    y0, xh0, rs0 = run(False)
+    assert torch.equal(y1[blk_live], y0[blk_live]) and torch.equal(xh1[blk_live], xh0[blk_live]) and torch.equal(rs1[blk_live], rs0[blk_live])
+    dead = ~blk_live
+    if dead.any():
+        assert (y1[dead].float() == 7.0).all() and (xh1[dead].float() == 7.0).all() and (rs1[dead] == 7.0).all()
