@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""400 back-to-back stream-K launches per layer shape (realise_gemm_nt_streamk): median / p99 / worst launch time and the give-up flag -
+how the rare 30 - 60 ms launches of the first polling forms were found (profiles/round5_streamk_probe.log).  GPU box: python tools/streamk_stress.py"""
 import sys, numpy as np, torch, ctypes as C
 sys.path.insert(0, "."); sys.path.insert(0, "tools")
 import streamk_probe as sp
