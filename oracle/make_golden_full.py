@@ -14,6 +14,8 @@ TEST INFRASTRUCTURE; run only where /root/reference exists (a few minutes on 8 c
 * ``arch3_b64s128_train`` - the reference's TRAINING step at the same size (train mode, dropout 0): loss, forward taps, the
   gradient of every gradient-receiving parameter (L2 norm, sum, |sum|, 192 strided samples) after ``loss.backward()``
   (src/run.py:191-200) and the updated BatchNorm buffers.
+* ``arch3_b8s256_train`` / ``arch3_b4s512_train`` - the same training step at B=8, S=256 and B=4, S=512 (max_seq_length beyond the
+  default 128: src/run.py:304; position table of 512 rows).
 * ``resnet_b256s128_bwd`` - the reference CharResNet's backward on the 32768 glyph stacks for a seeded upstream gradient
   (``glyph_upstream_grad``): gradient norm / sums / samples of its 45 parameters.
 
@@ -203,6 +205,10 @@ def main():
         case_full_train(models, BertConfig)
     if "resnet_bwd" in which:
         case_resnet_bwd(models, BertConfig)
+    if "train256" in which:                               # S > 128 (run.py:304 --max_seq_length 256): the tiled attention kernels
+        case_full_train(models, BertConfig, name="arch3_b8s256_train", B=8, S=256, seed=12)
+    if "train512" in which:
+        case_full_train(models, BertConfig, name="arch3_b4s512_train", B=4, S=512, seed=13)
 
 
 if __name__ == "__main__":

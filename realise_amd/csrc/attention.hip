@@ -1,4 +1,4 @@
-// Fused single-tile self-attention for S <= 128, head_dim 64 (K3 + its backward, K14).
+// Fused self-attention, head_dim 64 (K3 + its backward, K14): single-tile kernels for S <= 128 (the tuned path), tiled kernels beyond.
 // Reference math: transformers/modeling_bert.py:239-260 -
 //   scores = Q K^T / 8 + (1 - mask) * -10000 ; softmax ; dropout(p) ; ctx = P V.
 // One workgroup (4 waves) per (batch, head).  The whole [S,S] score tile stays in registers;
@@ -503,6 +503,362 @@ attn_bwd_dq_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* 
   }
 }
 
+// ================================= S > 128: tiles of 128 keys / queries ==========================
+// The same products on the same register layouts, with the sequence cut into tiles of SMAX rows: the forward keeps a running row maximum
+// and sum and rescales its output accumulators per key tile (the probabilities are never normalised before the last tile: O = (sum_k
+// p_k dm_k v_k) / sum_k p_k, exactly softmax -> dropout -> P V), the gradients recompute the probabilities from the saved row
+// log-sum-exp and need no rescaling.  One workgroup per (batch, head, tile); a workgroup walks the tiles of the other dimension, staging
+// one pair of [128][64] images per step.  Dropout multipliers hash the same (batch, head, query, key) index as the one-tile kernels.
+// Not tuned (one pair of tiles in flight, two barriers per step): the reference's default length is 128 (run.py:304); this is what makes
+// max_seq_length 256 / 512 run at all.
+template <typename T>
+__global__ void __launch_bounds__(256, 1)
+attn_fwd_long_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
+                     const float* __restrict__ mask_add, T* __restrict__ ctx, int64_t ldc, float* __restrict__ lse, int B, int nh, int S,
+                     uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* __restrict__ rlen) {
+  typedef typename MmaOf<T>::type Mma;
+  typedef AttnGeo<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = smem + G::KT_BYTES;
+  float* madd = (float*)(smem + 2 * G::KT_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
+  const T* Q = q_ + (int64_t)b * S * ldq + h * HD;
+  const T* K = k_ + (int64_t)b * S * ldq + h * HD;
+  const T* V = v_ + (int64_t)b * S * ldq + h * HD;
+  const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;       // rows >= Sl: padding (never read as queries, exact-zero probabilities as keys)
+  if ((int)blockIdx.y * SMAX >= Sl) return;                    // (the whole workgroup: before any barrier)
+  const int q0 = blockIdx.y * SMAX + wave * 32;
+  const bool on = q0 < Sl;                                     // waves without a live query still take part in the staging barriers
+  typename Mma::Frag qf[2][G::KSTEPS];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) qf[m][ks] = gfrag<T>(Q, ldq, q0 + 16 * m + l15, Sl, ks, g);
+  float mxr[2] = {-3.0e38f, -3.0e38f}, lr[2] = {0.f, 0.f};
+  floatx4 o[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) o[m][dn] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int KT = (Sl + SMAX - 1) / SMAX;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int kb = kt * SMAX, krows = min(SMAX, Sl - kb);
+    __syncthreads();                                           // the previous tile's images are no longer read
+    stage_tile<T>(K + (int64_t)kb * ldq, ldq, krows, Ks, tid, 0);
+    stage_tile<T>(V + (int64_t)kb * ldq, ldq, krows, Vs, tid, 0);
+    if (tid < SMAX) madd[tid] = kb + tid < S ? mask_add[b * S + kb + tid] : 0.0f;
+    stage_wait<T>();
+    __syncthreads();
+    if (!on) continue;
+    floatx4 sc[8][2];
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) sc[n][m] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      if (16 * n < krows) {
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+          const typename Mma::Frag kf = ktile_frag<T, HD>(Ks, 16 * n + l15, ks, g);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) sc[n][m] = Mma::mma(kf, qf[m][ks], sc[n][m]);
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int q = q0 + 16 * m + l15;
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const floatx4 ma = *(const floatx4*)(madd + 16 * n + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + 16 * n + 4 * g + r;
+          const float sv = key < S ? sc[n][m][r] * 0.125f + ma[r] : -3.0e38f;
+          sc[n][m][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mxr[m], mx);                    // (finite: the tile holds a key < S)
+      const float alpha = exp_t<T>(mxr[m] - mnew);
+      float sum = 0.f;
+#pragma unroll
+      for (int n = 0; n < 8; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + 16 * n + 4 * g + r;
+          const float pv = key < S ? exp_t<T>(sc[n][m][r] - mnew) : 0.0f;
+          sc[n][m][r] = pv;
+          sum += pv;
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      lr[m] = lr[m] * alpha + sum;
+      mxr[m] = mnew;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) o[m][dn] *= alpha;
+      if (drop_thresh != 0u) {
+        const uint32_t rowbase = ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)kb;
+        if ((S & 3) == 0) {
+#pragma unroll
+          for (int n = 0; n < 8; ++n) sc[n][m] *= drop_mult4(drop_seed, drop_thresh, drop_scale, rowbase + 16 * n + 4 * g);
+        } else {
+#pragma unroll
+          for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[n][m][r] *= drop_mult(drop_seed, drop_thresh, drop_scale, rowbase + 16 * n + 4 * g + r);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        if (32 * kk < krows) contract_seq32<T>(o[m], Vs, 32 * kk, sc[2 * kk][m], sc[2 * kk + 1][m], l15, g);
+    }
+  }
+  if (!on) return;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int q = q0 + 16 * m + l15;
+    if (q < S) {
+      const float inv = 1.0f / lr[m];
+      if (g == 0 && lse != nullptr) lse[(int64_t)bh * S + q] = mxr[m] + logf(lr[m]);
+      T* dst = ctx + ((int64_t)b * S + q) * ldc + h * HD + 4 * g;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) store4<T>(dst + 16 * dn, o[m][dn] * inv);
+    }
+  }
+}
+
+// dK, dV of one tile of 128 keys: walks the query tiles (Q and dO images, their row dots and log-sum-exps); the workgroups of key tile 0
+// also leave the row dots for the dQ kernel
+template <typename T>
+__global__ void __launch_bounds__(256, 1)
+attn_bwd_dkv_long_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
+                         const float* __restrict__ mask_add, const T* __restrict__ ctx, const T* __restrict__ dctx, int64_t ldc,
+                         const float* __restrict__ lse, float* __restrict__ rowdot, T* __restrict__ dk_, T* __restrict__ dv_,
+                         int64_t ldd, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* __restrict__ rlen) {
+  typedef typename MmaOf<T>::type Mma;
+  typedef AttnGeo<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = Qs + G::KT_BYTES;
+  float* lse_s = (float*)(dOs + G::KT_BYTES);
+  float* dot_s = lse_s + SMAX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
+  const int64_t H = ldc;
+  const T* Q = q_ + (int64_t)b * S * ldq + h * HD;
+  const T* K = k_ + (int64_t)b * S * ldq + h * HD;
+  const T* V = v_ + (int64_t)b * S * ldq + h * HD;
+  const T* O = ctx + (int64_t)b * S * H + h * HD;
+  const T* dO = dctx + (int64_t)b * S * H + h * HD;
+  const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;
+  const int k0 = blockIdx.y * SMAX + wave * 32;                // this wave's 32 keys (two tiles of 16)
+  typename Mma::Frag kf[2][G::KSTEPS], vf[2][G::KSTEPS];
+  float ma[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int key = k0 + 16 * n + l15;
+    ma[n] = key < S ? mask_add[b * S + key] : 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) { kf[n][ks] = gfrag<T>(K, ldq, key, S, ks, g); vf[n][ks] = gfrag<T>(V, ldq, key, S, ks, g); }
+  }
+  floatx4 dv[2][4], dk[2][4];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) { dv[n][dn] = floatx4{0.f, 0.f, 0.f, 0.f}; dk[n][dn] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+  const int QT = (Sl + SMAX - 1) / SMAX;
+  for (int qt = 0; qt < QT; ++qt) {
+    const int qb = qt * SMAX, qrows = min(SMAX, Sl - qb);
+    __syncthreads();
+    stage_tile<T>(Q + (int64_t)qb * ldq, ldq, qrows, Qs, tid, 0);
+    stage_tile<T>(dO + (int64_t)qb * H, H, qrows, dOs, tid, 0);
+    {  // rowdot[q] = sum_d dO[q,d] * O[q,d]  (two threads per row)
+      const int row = tid >> 1, half = tid & 1;
+      float acc = 0.f;
+      if (row < qrows) {
+        const T* po = O + (int64_t)(qb + row) * H + half * 32;
+        const T* pd = dO + (int64_t)(qb + row) * H + half * 32;
+#pragma unroll
+        for (int j = 0; j < 32; j += 4) {
+          const floatx4 x = load4<T>(po + j), y = load4<T>(pd + j);
+          acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+        }
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      if (half == 0) {
+        dot_s[row] = acc;
+        lse_s[row] = row < qrows ? lse[(int64_t)bh * S + qb + row] : 0.0f;
+        if (blockIdx.y == 0 && qb + row < S) rowdot[(int64_t)bh * S + qb + row] = acc;
+      }
+    }
+    stage_wait<T>();
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      if (k0 + 16 * n >= Sl) continue;                         // a tile of padding keys: dK = dV = 0
+      const int key = k0 + 16 * n + l15;
+      for (int mm = 0; mm < 4; ++mm) {
+        if (32 * mm >= qrows) break;
+        floatx4 sx[2], dp[2];   // [mi] : queries qb + 32mm + 16mi + 4g + r, key k0 + 16n + l15
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          sx[mi] = floatx4{0.f, 0.f, 0.f, 0.f}; dp[mi] = floatx4{0.f, 0.f, 0.f, 0.f};
+          const int qrow = 32 * mm + 16 * mi + l15;
+#pragma unroll
+          for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            sx[mi] = Mma::mma(ktile_frag<T, HD>(Qs, qrow, ks, g), kf[n][ks], sx[mi]);
+            dp[mi] = Mma::mma(ktile_frag<T, HD>(dOs, qrow, ks, g), vf[n][ks], dp[mi]);
+          }
+        }
+        floatx4 pd[2], ds[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const floatx4 l4 = *(const floatx4*)(lse_s + 32 * mm + 16 * mi + 4 * g);
+          const floatx4 d4 = *(const floatx4*)(dot_s + 32 * mm + 16 * mi + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = qb + 32 * mm + 16 * mi + 4 * g + r;
+            const bool ok = (q < S) && (key < S);
+            const float pr = ok ? exp_t<T>(sx[mi][r] * 0.125f + ma[n] - l4[r]) : 0.0f;
+            const float dm = drop_mult(drop_seed, drop_thresh, drop_scale, ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)key);
+            pd[mi][r] = pr * dm;
+            ds[mi][r] = pr * (dp[mi][r] * dm - d4[r]) * 0.125f;
+          }
+        }
+        contract_seq32<T>(dv[n], dOs, 32 * mm, pd[0], pd[1], l15, g);
+        contract_seq32<T>(dk[n], Qs, 32 * mm, ds[0], ds[1], l15, g);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int key = k0 + 16 * n + l15;
+    if (key < S) {
+      T* pk = dk_ + ((int64_t)b * S + key) * ldd + h * HD + 4 * g;
+      T* pv = dv_ + ((int64_t)b * S + key) * ldd + h * HD + 4 * g;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) { store4<T>(pk + 16 * dn, dk[n][dn]); store4<T>(pv + 16 * dn, dv[n][dn]); }
+    }
+  }
+}
+
+// dQ of one tile of 128 queries: walks the key tiles
+template <typename T>
+__global__ void __launch_bounds__(256, 1)
+attn_bwd_dq_long_kernel(const T* __restrict__ q_, const T* __restrict__ k_, const T* __restrict__ v_, int64_t ldq,
+                        const float* __restrict__ mask_add, const T* __restrict__ dctx, int64_t ldc, const float* __restrict__ lse,
+                        const float* __restrict__ rowdot, T* __restrict__ dq_out, int64_t ldd, int B, int nh, int S,
+                        uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* __restrict__ rlen) {
+  typedef typename MmaOf<T>::type Mma;
+  typedef AttnGeo<T> G;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ks = smem;
+  char* Vs = Ks + G::KT_BYTES;
+  float* madd = (float*)(Vs + G::KT_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int bh = blockIdx.x, b = bh / nh, h = bh - b * nh;
+  const int64_t H = ldc;
+  const T* Q = q_ + (int64_t)b * S * ldq + h * HD;
+  const T* K = k_ + (int64_t)b * S * ldq + h * HD;
+  const T* V = v_ + (int64_t)b * S * ldq + h * HD;
+  const T* dO = dctx + (int64_t)b * S * H + h * HD;
+  const int Sl = rlen != nullptr ? min(S, rlen[b]) : S;
+  const int q0 = blockIdx.y * SMAX + wave * 32;
+  const bool on = q0 < Sl;
+  typename Mma::Frag qf[2][G::KSTEPS], dof[2][G::KSTEPS];
+  float lq[2], dq_[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int q = q0 + 16 * m + l15;
+    lq[m] = q < Sl ? lse[(int64_t)bh * S + q] : 0.0f;
+    dq_[m] = q < Sl ? rowdot[(int64_t)bh * S + q] : 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks) {
+      qf[m][ks] = gfrag<T>(Q, ldq, q, Sl, ks, g);
+      dof[m][ks] = gfrag<T>(dO, H, q, Sl, ks, g);
+    }
+  }
+  floatx4 dq[2][4];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int dn = 0; dn < 4; ++dn) dq[m][dn] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int KT = (int)blockIdx.y * SMAX < Sl ? (Sl + SMAX - 1) / SMAX : 0;      // a tile of padding queries: dQ = 0, nothing to walk (workgroup-uniform)
+  for (int kt = 0; kt < KT; ++kt) {
+    const int kb = kt * SMAX, krows = min(SMAX, Sl - kb);
+    __syncthreads();
+    stage_tile<T>(K + (int64_t)kb * ldq, ldq, krows, Ks, tid, 0);
+    stage_tile<T>(V + (int64_t)kb * ldq, ldq, krows, Vs, tid, 0);
+    if (tid < SMAX) madd[tid] = kb + tid < S ? mask_add[b * S + kb + tid] : 0.0f;
+    stage_wait<T>();
+    __syncthreads();
+    if (!on) continue;
+    for (int nn = 0; nn < 4; ++nn) {
+      if (32 * nn >= krows) break;
+      floatx4 sx[2][2], dp[2][2];   // [ni][m] : keys kb + 32nn + 16ni + 4g + r, query q0 + 16m + l15
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { sx[ni][m] = floatx4{0.f, 0.f, 0.f, 0.f}; dp[ni][m] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int krow = 32 * nn + 16 * ni + l15;
+#pragma unroll
+        for (int ks = 0; ks < G::KSTEPS; ++ks) {
+          const typename Mma::Frag kx = ktile_frag<T, HD>(Ks, krow, ks, g);
+          const typename Mma::Frag vx = ktile_frag<T, HD>(Vs, krow, ks, g);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            sx[ni][m] = Mma::mma(kx, qf[m][ks], sx[ni][m]);
+            dp[ni][m] = Mma::mma(vx, dof[m][ks], dp[ni][m]);
+          }
+        }
+      }
+      floatx4 ds[2][2];
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const floatx4 ma = *(const floatx4*)(madd + 32 * nn + 16 * ni + 4 * g);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const int q = q0 + 16 * m + l15;
+          const uint32_t idx0 = ((uint32_t)bh * (uint32_t)S + (uint32_t)q) * (uint32_t)S + (uint32_t)(kb + 32 * nn + 16 * ni + 4 * g);
+          floatx4 dm4 = floatx4{1.0f, 1.0f, 1.0f, 1.0f};
+          if ((S & 3) == 0) dm4 = drop_mult4(drop_seed, drop_thresh, drop_scale, idx0);
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dm4[r] = drop_mult(drop_seed, drop_thresh, drop_scale, idx0 + r);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kb + 32 * nn + 16 * ni + 4 * g + r;
+            const bool ok = (q < S) && (key < S);
+            const float pr = ok ? exp_t<T>(sx[ni][m][r] * 0.125f + ma[r] - lq[m]) : 0.0f;
+            ds[ni][m][r] = pr * (dp[ni][m][r] * dm4[r] - dq_[m]) * 0.125f;
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) contract_seq32<T>(dq[m], Ks, 32 * nn, ds[0][m], ds[1][m], l15, g);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int q = q0 + 16 * m + l15;
+    if (q < S) {
+      T* pq = dq_out + ((int64_t)b * S + q) * ldd + h * HD + 4 * g;
+#pragma unroll
+      for (int dn = 0; dn < 4; ++dn) store4<T>(pq + 16 * dn, dq[m][dn]);
+    }
+  }
+}
+
 // ================================= launchers ====================================================
 template <typename K> static void set_lds(K kernel, size_t bytes) {
   (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -511,12 +867,17 @@ template <typename K> static void set_lds(K kernel, size_t bytes) {
 template <typename T>
 int attn_fwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, const float* mask_add, T* ctx, int64_t ldc,
              float* lse, int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* rlen) {
-  if (S < 1 || S > SMAX || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC)) return RL_ERR_ARG;
+  if (S < 1 || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC) || (double)B * nh * (double)S * S >= 4294967296.0) return RL_ERR_ARG;
   typedef AttnGeo<T> G;
   const size_t lds = 2 * G::KT_BYTES + SMAX * sizeof(float);
   static bool once = false;
-  if (!once) { set_lds(attn_fwd_kernel<T>, lds); once = true; }
+  if (!once) { set_lds(attn_fwd_kernel<T>, lds); set_lds(attn_fwd_long_kernel<T>, lds); once = true; }
   ProfScope ps(st, PK_ATTN_FWD, 4.0 * B * nh * (double)S * S * 64);
+  if (S > SMAX) {        // tiles of 128 keys, one workgroup per (batch, head, 128 queries)
+    RL_LAUNCH((attn_fwd_long_kernel<T>), dim3(B * nh, (S + SMAX - 1) / SMAX), dim3(256), lds, st, q, k, v, ldq, mask_add, ctx, ldc, lse, B, nh, S,
+              drop_seed, drop_thresh, drop_scale, rlen);
+    return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+  }
   RL_LAUNCH((attn_fwd_kernel<T>), dim3(B * nh), dim3(256), lds, st, q, k, v, ldq, mask_add, ctx, ldc, lse, B, nh, S,
                      drop_seed, drop_thresh, drop_scale, g_attn_probe, rlen);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
@@ -526,12 +887,30 @@ template <typename T>
 int attn_bwd(hipStream_t st, const T* q, const T* k, const T* v, int64_t ldq, const float* mask_add, const T* ctx,
              const T* dctx, int64_t ldc, const float* lse, float* rowdot, T* dq, T* dk, T* dv, int64_t ldd,
              int B, int nh, int S, uint32_t drop_seed, uint32_t drop_thresh, float drop_scale, const int* rlen) {
-  if (S < 1 || S > SMAX || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC) || (ldd & 3)) return RL_ERR_ARG;
+  if (S < 1 || (ldq % AttnGeo<T>::VEC) || (ldc % AttnGeo<T>::VEC) || (ldd & 3) || (double)B * nh * (double)S * S >= 4294967296.0) return RL_ERR_ARG;
   typedef AttnGeo<T> G;
   const size_t lds1 = 2 * G::KT_BYTES + 2 * SMAX * sizeof(float);
   const size_t lds2 = 2 * G::KT_BYTES + SMAX * sizeof(float);
   static bool once = false;
-  if (!once) { set_lds(attn_bwd_dkv_kernel<T>, lds1); set_lds(attn_bwd_dq_kernel<T>, lds2); once = true; }
+  if (!once) {
+    set_lds(attn_bwd_dkv_kernel<T>, lds1); set_lds(attn_bwd_dq_kernel<T>, lds2);
+    set_lds(attn_bwd_dkv_long_kernel<T>, lds1); set_lds(attn_bwd_dq_long_kernel<T>, lds2);
+    once = true;
+  }
+  if (S > SMAX) {
+    const dim3 grid(B * nh, (S + SMAX - 1) / SMAX);
+    {
+      ProfScope ps(st, PK_ATTN_BWD, 6.0 * B * nh * (double)S * S * 64);
+      RL_LAUNCH((attn_bwd_dkv_long_kernel<T>), grid, dim3(256), lds1, st, q, k, v, ldq, mask_add, ctx, dctx, ldc, lse, rowdot, dk, dv, ldd, B, nh, S,
+                drop_seed, drop_thresh, drop_scale, rlen);
+    }
+    {
+      ProfScope ps(st, PK_ATTN_BWD, 4.0 * B * nh * (double)S * S * 64);
+      RL_LAUNCH((attn_bwd_dq_long_kernel<T>), grid, dim3(256), lds2, st, q, k, v, ldq, mask_add, dctx, ldc, lse, rowdot, dq, ldd, B, nh, S,
+                drop_seed, drop_thresh, drop_scale, rlen);
+    }
+    return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
+  }
   // the algorithmic 10 * B * nh * S^2 * 64 FLOPs of the attention gradient (dV, dP, dK, dQ + the score recompute), booked 6 : 4
   // on the two kernels so that each launch carries its own dispatch timestamps
   {

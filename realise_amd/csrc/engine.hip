@@ -1112,7 +1112,7 @@ template <typename T> struct Engine : EngineBase {
   }
   int forward(hipStream_t st, const realise_batch& b) override {
     if (!sh || !ws) return RL_ERR_ARG;
-    if (b.B < 1 || b.S < 1 || b.S > 128 || b.S > cfg.max_pos) return RL_ERR_ARG;
+    if (b.B < 1 || b.S < 1 || b.S > cfg.max_pos) return RL_ERR_ARG;       // (S > 128: the tiled attention kernels, attention.hip)
     const int Tp = cfg.model_type == 1 ? b.Tp : 1;
     if (cfg.model_type == 1 && (Tp < 1 || !b.pho_idx || !b.pho_perm || !b.pho_lens_sorted || (!b.n_alive && !b.n_alive_dev))) return RL_ERR_ARG;
     if (pl.B != b.B || pl.S != b.S || pl.Tp != Tp) {

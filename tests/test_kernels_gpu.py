@@ -327,7 +327,8 @@ def _attn_ref(q, k, v, mask_add, nh):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-@pytest.mark.parametrize("B,nh,S", [(2, 3, 16), (2, 2, 40), (3, 12, 128), (1, 1, 97)])
+@pytest.mark.parametrize("B,nh,S", [(2, 3, 16), (2, 2, 40), (3, 12, 128), (1, 1, 97),
+                                    (2, 3, 256), (1, 2, 200), (2, 12, 512), (1, 1, 129), (2, 2, 301)])      # S > 128: the tiled kernels
 def test_attention_fwd_bwd(dt, B, nh, S):
     lib = _capi.load()
     code, tdt, tol = DT[dt]
@@ -366,11 +367,12 @@ def test_attention_fwd_bwd(dt, B, nh, S):
     close(dqkv[:, :H].reshape(B, S, H), qf.grad, btol, "attention dQ")
 
 
-@pytest.mark.parametrize("S", [48, 45])
+@pytest.mark.parametrize("S", [48, 45, 160, 261])
 def test_attention_dropout_backward_consistency(S):
     """with dropout ON the backward must use the same regenerated mask as the forward:
     directional finite differences of sum(ctx * R) in exact-fp32 mode.  S % 4 == 0: one dropout hash per four keys (forward, dQ) and
-    the quad exchange between the four lanes of a key quad (dK / dV); S = 45: the per-element form."""
+    the quad exchange between the four lanes of a key quad (dK / dV); S = 45: the per-element form; S = 160 / 261: the tiled kernels
+    (two and three tiles of 128 keys / queries; the hash index is the absolute (query, key) pair in every kernel)."""
     lib = _capi.load()
     B, nh = 1, 2
     H = nh * 64

@@ -337,7 +337,7 @@ def test_nt_gemm_over_a_list_of_live_row_blocks(M, N, K, mode, accumulate, block
             assert (out_l[rows].float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("B,S,layers", [(8, 64, 2), (64, 128, 1), (8, 40, 1)])      # (S = 40: 16-row blocks straddle sentences)
+@pytest.mark.parametrize("B,S,layers", [(8, 64, 2), (64, 128, 1), (8, 40, 1), (8, 256, 1)])      # (S = 40: 16-row blocks straddle sentences; S = 256: the tiled attention kernels)
 def test_live_row_training_step_equals_the_dense_step(B, S, layers):
     """realise_set_engine(10, 1) (default): a bf16 training step runs the layer GEMMs of the three transformer stacks - forward and data
     gradients - and the attention forward over the live 16-row blocks only.  Against the dense step (10, 0) on the same module state, the
