@@ -91,7 +91,9 @@ int realise_conv_tn(void* stream, int dtype, const void* A, int64_t lda, const r
 /* A/B knobs, probe modes and the per-launch timing hooks live in include/realise_hip_debug.h (diagnostics, not operators). */
 
 /* BertSelfAttention core (modeling_bert.py:239-260): softmax(QK^T/8 + mask_add) -> dropout -> .V
- * q/k/v: [B*S][ldq] token-major, head h at columns 64h..64h+63; ctx [B*S][ldc]; lse [B][nh][S]. */
+ * q/k/v: [B*S][ldq] token-major, head h at columns 64h..64h+63; ctx [B*S][ldc]; lse [B][nh][S].
+ * S <= 128: one workgroup per (batch, head), the whole score tile in registers; S > 128 (max_seq_length 256 / 512, run.py:304): tiles of
+ * 128 keys / queries, the forward with a running row maximum and sum (B * nh * S * S < 2^32). */
 int realise_attention_fwd(void* stream, int dtype, const void* q, const void* k, const void* v, int64_t ldq,
                           const float* mask_add, void* ctx, int64_t ldc, float* lse, int B, int nh, int S,
                           uint32_t drop_seed, uint32_t drop_thresh, float drop_scale);
