@@ -360,13 +360,18 @@ def test_glyph_branch_is_bitwise_reproducible():
             assert torch.equal(a, b)
 
 
-def test_rejects_sequences_longer_than_the_kernels_support():
+def test_rejects_sequences_longer_than_the_position_table():
+    """S > 128 runs (round 5: tiled attention kernels; the reference pads to --max_seq_length, run.py:304) up to the position table
+    (config.max_position_embeddings = 512, modeling_bert.py:160); beyond it the reference's embedding lookup fails and so does the engine."""
     from realise_amd import _capi
     from realise_amd.data import synthetic_batch
     cfg = RealiseConfig(num_hidden_layers=1)
     m = SpellBert(cfg, compute_dtype="bf16").to("cuda").eval()
+    with torch.no_grad():
+        loss, logits = m(synthetic_batch(1, 160, with_pho=False))
+    assert tuple(logits.shape[:2]) == (1, 160) and torch.isfinite(logits.float()).all() and torch.isfinite(loss)
     with pytest.raises(_capi.RealiseHipError):
-        m(synthetic_batch(1, 160, with_pho=False))          # the reference caps max_seq_length at 128 (run.py:304)
+        m(synthetic_batch(1, cfg.max_position_embeddings + 16, with_pho=False))
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

@@ -391,7 +391,7 @@ def test_layernorm_forward_skips_blocks_without_a_live_row(rows, H, S):
     for b0 in range(0, rows, S):                 # a live prefix per sentence (S = 40: blocks straddle sentences)
         live[b0:b0 + int(rng.integers(1, S + 1))] = 1
     live = live.cuda()
-    blk_live = live[:rows].view(-1, 16).any(1).repeat_interleave(16)
+    blk_live = (live[:rows].view(-1, 16).sum(1) > 0).repeat_interleave(16)
 
     def run(use_live):
         y = torch.full((rows, H), 7.0, dtype=torch.bfloat16, device="cuda")
