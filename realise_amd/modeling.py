@@ -478,6 +478,15 @@ class RealiseModule(nn.Module):
             Tp = int(pho_idx.shape[1])
             if lens.min() < 1 or lens.max() > Tp:
                 raise ValueError("pho_lens out of range")            # pack_padded_sequence would raise too
+            # build_batch makes pho_idx as wide as the batch's longest pinyin (models.py:797-804: 4 .. 7 columns from batch to batch), and the
+            # engine's workspace plan is keyed by (B, S, Tp): every new key re-zeroes the workspace (~2 ms at B = 64, S = 128).  Widen to the
+            # widest batch seen so far with pad columns (id 0, beyond every length: those GRU steps have no live row and are not launched),
+            # so the key settles after a few batches.
+            tp_high = max(Tp, getattr(self, "_tp_high", 0))
+            self._tp_high = tp_high
+            if tp_high > Tp:
+                pho_idx = torch.nn.functional.pad(pho_idx, (0, tp_high - Tp))
+                Tp = tp_high
             perm = np.argsort(-lens, kind="stable").astype(np.int32)
             lens_sorted = lens[perm]
             alive = (C.c_int32 * Tp)(*[int((lens > t).sum()) for t in range(Tp)])

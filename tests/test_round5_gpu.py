@@ -481,3 +481,39 @@ def test_long_sequence_bf16_step_and_live_rows(golden_dir):
     layer_w = [n for n in g0 if ".layer." in n and n.endswith("weight") and "LayerNorm" not in n]
     moved = [n for n in layer_w if not torch.equal(g0[n], g1[n])]
     assert layer_w and not moved, moved[:8]
+
+
+def test_host_built_batches_of_different_pinyin_width_share_one_workspace_plan():
+    """build_batch (models.py:797-804) makes pho_idx as wide as the batch's longest pinyin, so the width changes from batch to batch; the
+    engine's plan is keyed by (B, S, Tp) and a new key re-zeroes the workspace.  The module widens a narrower batch to the widest seen
+    so far (pad columns are beyond every length: those GRU steps are not launched): same loss / logits / gradients as a module that only
+    ever saw the narrow batch, and the plan key stays put."""
+    cfg = RealiseConfig(num_hidden_layers=1, pho_layers=1, out_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd = init_state_dict_numpy(cfg, seed=5)
+    wide = synthetic_batch(4, 32, seed=3)
+    narrow = synthetic_batch(4, 32, seed=4)
+    Tw = wide["pho_idx"].shape[1]
+    lens = np.minimum(np.asarray(narrow["pho_lens"]), 3)              # a batch whose longest pinyin has 3 letters
+    narrow["pho_lens"] = [int(x) for x in lens]
+    narrow["pho_idx"] = narrow["pho_idx"][:, :3].contiguous() * (torch.arange(3)[None, :] < torch.from_numpy(lens)[:, None])
+    assert Tw > 3
+
+    def run(m, b):
+        m.zero_grad()
+        loss, logits = m(b)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.item()), logits.detach().clone(), grads_of(m)
+
+    m1 = build(cfg, sd, "fp32", train=True)
+    run(m1, wide)
+    key = m1._ws_key
+    l1, z1, g1 = run(m1, narrow)
+    assert m1._ws_key == key and key[2] == Tw
+    m2 = build(cfg, sd, "fp32", train=True)
+    l2, z2, g2 = run(m2, narrow)
+    assert m2._ws_key[2] == 3
+    assert l1 == l2 and torch.equal(z1, z2)
+    for n in g2:
+        s = g2[n].abs().max().item()
+        assert (g1[n] - g2[n]).abs().max().item() <= 1e-5 * s + 1e-12, n
