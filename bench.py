@@ -51,8 +51,17 @@ RESNET_FLOPS_PER_STACK = 126418944      # CharResNet forward on one 3 x 32 x 32 
 # HIP-event pairs around every launch of the MFMA kernel families cost ~4 us of stream time each (~8 % of a step when every
 # step is bracketed): the timed region brackets every 10th step, which leaves the averages intact and the cost below 1 %.
 PROFILE_EVERY = 10
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "round5_pmc_traffic.json")
-ROCPROF_STATS = os.path.join(ROOT, "profiles", "round5_final_kernel_stats.md")
+def _latest_profile(name):
+    """the newest round's committed summary of that name (profiles/roundN_<name>)"""
+    for r in (6, 5):
+        p = os.path.join(ROOT, "profiles", "round%d_%s" % (r, name))
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "round6_%s" % name)
+
+
+PMC_TRAFFIC = _latest_profile("pmc_traffic.json")
+ROCPROF_STATS = _latest_profile("final_kernel_stats.md")
 NT_KERNEL_PREFIXES = ["gemm_nt8_kernel", "gemm_nt8p_kernel", "gemm_nt_kernel<bf16_t, DenseLoader<bf16_t>", "gemm_nt_ln_kernel"]
 
 
@@ -205,7 +214,7 @@ def cpu_baseline(sd_cpu, cfg, sample_b, S):
     torch.set_num_threads(threads)
     # `value` / `cores` = the FASTEST configuration found (the thread count actually used for it); the all-physical-cores figure - the
     # pessimal one on a 128-core host, which flattered the GPU / CPU ratio by ~6x in round 4's line - is kept beside it
-    return {"value": best["value"], "unit": "sentences/s", "cores": best_t, "kind": "port",
+    return {"value": best["value"], "unit": "sentences/s", "cores": best_t, "kind": "port", "sample_batch": sample_b, "sample_seq_len": S,
             "cpu_model": model, "physical_cores": physical, "logical_cpus": logical,
             "eval_forward_sentences_per_s": best["eval_forward_sentences_per_s"],
             "all_physical_cores": {"threads": threads, "value": round(sample_b / tr, 4), "eval_forward_sentences_per_s": round(sample_b / ev, 4)},
@@ -214,6 +223,58 @@ def cpu_baseline(sd_cpu, cfg, sample_b, S):
                       "clip_grad_norm + AdamW, dropout on) 1 warm-up (%.1f s) + %d timed (mean %.2f s); eval forward 1 warm-up + 3 timed "
                       "(mean %.2f s); thread sweep: 1 warm-up + 1 timed eval forward per count, train step 1 warm-up + 1 timed at the best"
                       % (sample_b, S, threads, warm_t, len(tt), tr, ev)}
+
+
+def golden_parity(dev):
+    """The parity band of both numeric modes, MEASURED here on the reference's own full-size vector (tests/golden/arch3_b64s128_eval.npz:
+    B = 64, S = 128, all 19 layers; arg-max ids, top-1 / top-2 margins and one sampled logit per token of the reference's fp32 CPU
+    forward, made by oracle/make_golden_full.py importing the reference): one eval forward per mode.  The fixture is data - the oracle
+    is not imported here."""
+    import numpy as np
+    from realise_amd.config import RealiseConfig
+    from realise_amd.data import synthetic_batch
+    from realise_amd.init import init_state_dict_numpy
+    from realise_amd.modeling import SpellBertPho2ResArch3
+    path = os.path.join(ROOT, "tests", "golden", "arch3_b64s128_eval.npz")
+    if not os.path.exists(path):
+        return None
+    g = dict(np.load(path))
+    B, S, seed, nl = int(g["meta/B"]), int(g["meta/S"]), int(g["meta/seed"]), int(g["meta/n_layers"])
+    cfg = RealiseConfig(num_hidden_layers=nl, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    sd_np = init_state_dict_numpy(cfg, "arch3", seed=seed, scheme="perturbed")
+    batch = synthetic_batch(B, S, seed=seed, with_pho=True)
+    real = batch["masks"].numpy() == 1
+    slot = torch.from_numpy(g["sample_slot"].astype(np.int64)).to(dev)
+    out = {"vector": "tests/golden/arch3_b64s128_eval.npz (the reference's fp32 CPU eval forward at B=%d, S=%d, %d+4+3 layers; "
+                     "%d tokens, %d of them real)" % (B, S, nl, B * S, int(real.sum())),
+           "reference_min_margin": float(g["margin"].min())}
+    for dtype in ("fp32", "bf16"):
+        m = SpellBertPho2ResArch3(cfg, compute_dtype=dtype)
+        m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()})
+        m.to(dev).eval()
+        with torch.no_grad():
+            loss, logits = m(batch)
+        flat = logits.reshape(-1, logits.shape[-1]).float()
+        tok = torch.arange(flat.shape[0], device=dev)
+        mine = flat[tok, slot].cpu().numpy()
+        am = m.decode(logits).cpu().numpy().astype(np.int32)
+        eq = am == g["argmax"]
+        r = {"max_logit_err": float(np.abs(mine - g["sample_logit"]).max()), "loss_abs_err": abs(float(loss.item()) - float(g["loss"])),
+             "argmax_equal_frac": float(eq.mean()), "argmax_equal_frac_real_tokens": float(eq[real].mean()),
+             "argmax_mismatches": int((~eq).sum())}
+        if dtype == "fp32":
+            und = g["margin"] <= 1e-4
+            r["undecided_tokens"] = int(und.sum())                       # reference top-1 / top-2 margin within fp32 noise of 19 layers
+            r["argmax_mismatches_where_margin_gt_1e-4"] = int((~eq & ~und).sum())
+            r["tolerance"] = "north_star: logits <= 1e-3, arg-max equal wherever the reference margin > 1e-4"
+        else:
+            wide = g["margin"] > 8e-2
+            r["argmax_mismatches_where_margin_gt_8e-2_real"] = int((~eq & wide & real).sum())
+            r["tolerance"] = "band: logits <= 4e-2, arg-max equal on real tokens wherever the reference margin > 8e-2, agreement > 0.92"
+        out[dtype] = r
+        del m
+    torch.cuda.empty_cache()
+    return out
 
 
 def read_families(lib, sampled):
@@ -287,6 +348,7 @@ def main():
     ap.add_argument("--dump-launches", default=None, help="write the per-launch durations of the first sampled step to this JSON file")
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only measurements")
     ap.add_argument("--no-fp32-parity", action="store_true", help="skip the fp32 parity-mode throughput sub-measurement")
+    ap.add_argument("--no-golden-parity", action="store_true", help="skip the measured parity band (`parity`: both modes on the reference's full-size vector)")
     ap.add_argument("--host-batch", action="store_true",
                     help="hand the model the reference's host-built batch (pho_idx + the host list pho_lens: an argsort and an H2D copy per "
                          "forward) instead of the device-side build_batch (model.set_pinyin_table)")
@@ -565,6 +627,10 @@ def main():
             out["forward"] = fwd
         if parity is not None:
             out["fp32_parity"] = parity
+        if world == 1 and not ddp and not args.no_golden_parity and not args.no_fp32_parity and args.dtype == "bf16":
+            gp = golden_parity(dev)
+            if gp is not None:
+                out["parity"] = gp
         if dense_ab is not None:
             out["dense_rows"] = dense_ab
         if ddp_stats is not None:

@@ -198,6 +198,11 @@ int64_t realise_engine_workspace_bytes(const realise_engine* e, int B, int S, in
 /* hand the engine its operand-shadow arena and its activation workspace (caller-allocated).  The shadow arena must be
  * ZERO-FILLED by the caller: padded operand rows (the classifier's W^T copy is pitched to 64 columns) rely on it. */
 int realise_engine_bind(realise_engine* e, void* shadow, void* workspace, int64_t workspace_bytes);
+/* Workspace slots (round 6).  The engine installs one plan per (B, S, Tp) INTO the bound workspace (zero-filled once, then kept
+ * self-cleaning) and remembers it per workspace address: a caller that keeps one buffer per batch shape (train batch, eval batch, the
+ * short last batch of run.py:104-123's windows, the glyph-only plan) and re-binds the matching one before a forward pays the zero
+ * fill once per shape instead of on every switch.  Call this before freeing a buffer the engine has been bound to. */
+void realise_engine_forget_workspace(realise_engine* e, void* workspace);
 /* re-derive the compute-dtype operand copies from the fp32 masters (after any parameter update) */
 int realise_engine_refresh_shadows(realise_engine* e, void* stream);
 /* the same, for a caller whose last parameter update was realise_engine_adamw (which wrote the Linear weights' copies itself):

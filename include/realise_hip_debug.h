@@ -160,6 +160,17 @@ int realise_profile_dump(int kernel_family, int max_records, float* ms_out, doub
 int realise_profile_read_ex(int kernel_family, long long* count, double* total_ms, double* total_work, double* total_work_executed);
 int realise_profile_dump_ex(int kernel_family, int max_records, float* ms_out, double* work_out, double* work_executed_out);
 
+/* Host-side support predicates of the weight-gradient kernels, exported so that a CPU test can pin them (a comment
+ * once swallowed half of the first one's conditions).  realise_debug_tn8_supported: 1 when the 8-wave TN kernel takes the problem
+ * (plain epilogue, no live-block list), 0 when the caller must fall back to the 4-wave kernel.  realise_debug_tn_list_lds: bytes of
+ * LDS a listed TN launch reserves for `entries` live blocks, -1 when the list does not fit (the engine then runs dense reductions). */
+int realise_debug_tn8_supported(int64_t lda, int64_t ldb, int P, int I, int J, int64_t ldo);
+int realise_debug_tn_list_lds(int64_t entries);
+
+/* how many workspace plans the engine has installed (= whole-workspace zero fills) since it was created: a loop that alternates
+ * batch shapes over per-shape workspace buffers (realise_engine_forget_workspace in realise_hip.h) must count one per shape */
+int64_t realise_engine_plan_installs(const realise_engine* e);
+
 
 #ifdef __cplusplus
 }

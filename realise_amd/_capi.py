@@ -134,6 +134,10 @@ SYMBOLS = {
     "realise_engine_destroy": (None, [_P]),
     "realise_engine_shadow_bytes": (_L, [_P]),
     "realise_engine_workspace_bytes": (_L, [_P, _I, _I, _I]),
+    "realise_engine_forget_workspace": (None, [_P, _P]),
+    "realise_engine_plan_installs": (_L, [_P]),
+    "realise_debug_tn8_supported": (_I, [_L, _L, _I, _I, _I, _L]),
+    "realise_debug_tn_list_lds": (_I, [_L]),
     "realise_engine_bind": (_I, [_P, _P, _P, _L]),
     "realise_engine_refresh_shadows": (_I, [_P, _P]),
     "realise_engine_refresh_shadows_ex": (_I, [_P, _P, _I]),

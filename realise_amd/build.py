@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "librealise_hip.so")
-SOURCES = ["gemm.hip", "gemm_nt8.hip", "gemm_nt8p.hip", "gemm_nt8s.hip", "gemm_tn8.hip", "conv_wgrad_c64.hip", "conv_c64_nt.hip", "attention.hip", "ops.hip", "ops2.hip", "engine.hip", "capi.hip", "prof.hip"]
+SOURCES = ["gemm.hip", "gemm_nt8.hip", "gemm_nt8p.hip", "gemm_tn8.hip", "conv_wgrad_c64.hip", "conv_c64_nt.hip", "attention.hip", "ops.hip", "ops2.hip", "engine.hip", "capi.hip", "prof.hip"]
+PROBE_SOURCES = ["gemm_nt8s.hip"]      # measured-and-rejected kernels with their own translation unit: the probe build only
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC", "-fno-gpu-rdc"]
 
 
@@ -52,7 +53,7 @@ def build(force=False, verbose=False, probes=False):
     rejected kernel variants + the no-fetch / no-MFMA probe modes, for tools/*_probe.cpp); the production library has none of them."""
     objdir = OBJ + ("_probes" if probes else "")
     lib = LIB.replace(".so", "_probes.so") if probes else LIB
-    sources = SOURCES
+    sources = SOURCES + (PROBE_SOURCES if probes else [])
     os.makedirs(objdir, exist_ok=True)
     if force:
         for f in os.listdir(objdir):

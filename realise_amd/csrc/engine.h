@@ -26,6 +26,8 @@ struct EngineBase {
   virtual int64_t shadow_bytes() const = 0;
   virtual int64_t workspace_bytes(int B, int S, int Tp) = 0;
   virtual int bind(void* shadow, void* workspace, int64_t bytes) = 0;
+  virtual void forget_workspace(void* workspace) = 0;
+  virtual int64_t plan_install_count() const = 0;
   virtual int refresh_shadows(hipStream_t st) = 0;
   virtual int refresh_shadows_ex(hipStream_t st, int skip_linear) = 0;
   virtual int adamw_step(hipStream_t st, float* m, float* v, const uint8_t* group_of_block, const struct AdamwGroups& gs, const float* norm_sq,

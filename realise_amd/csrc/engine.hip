@@ -85,9 +85,11 @@ void set_live_rows(int on) { g_live_rows = on; }
 // one-round launch has at least g_streamk_min (realise_set_engine(12, n), default 10) K-tiles per workgroup to share out; 0 (default): the
 // 128 x 192 two-per-CU kernels only.  Measured (tools/streamk_probe.py, profiles/round5_streamk_probe.log): correct, reproducible,
 // and slower than the two-per-CU kernel on every layer shape - DESIGN.md section 6.6.
+// Round 6: the kernel lives in the PROBE build only (librealise_hip_probes.so, python -m realise_amd.build --probes), like every other
+// measured-and-rejected variant; in the production library the knob stays 0 and no exchange buffers are planned.
 static int g_streamk = 0;
 static int g_streamk_min = 10;
-void set_streamk(int v) { g_streamk = v > 0 ? 1 : 0; }
+void set_streamk(int v) { g_streamk = (RL_PROBES && v > 0) ? 1 : 0; }
 void set_streamk_min(int n) { g_streamk_min = n > 0 ? n : 0; }
 static int g_stream_pri[3] = {0, 0, 0};
 void set_stream_priority(int which, int pri) { if (which >= 0 && which < 3) g_stream_pri[which] = pri < 0 ? -1 : (pri > 0 ? 1 : 0); }
@@ -250,6 +252,7 @@ template <typename T> struct Engine : EngineBase {
       if (rows_live) { e2.live_list = wp<int>(pl.live_t16); e2.live_count = wp<int>(pl.live_n) + 2; }
       // one round of 256 workgroups over 256 x 192 tiles (stream-K) where there is enough to share out; a stack's launches are
       // serialised by its stream, so one exchange buffer per stack does
+#if RL_PROBES
       if (g_streamk && nt_sid >= 0 && nt_sid < 3 && pl.sk_part[nt_sid] != 0 &&
           (int64_t)((M + 255) / 256) * ((N + 191) / 192) * (K / 64) >= (int64_t)g_streamk_min * NT8S_GRID) {
         e2.sk_part = wp<float>(pl.sk_part[nt_sid]); e2.sk_flag = wp<int>(pl.sk_flag[nt_sid]);
@@ -260,6 +263,7 @@ template <typename T> struct Engine : EngineBase {
         if (rc != RL_ERR_ARG) return rc;
         e2.sk_part = nullptr; e2.sk_flag = nullptr; e2.sk_tag = 0; e2.sk_timeout = nullptr;
       }
+#endif
       if (rows_live) return gemm_nt8_live(st, A, lda, B, ldb, M, N, K, e2);
     }
     return gemm_nt<T>(st, A, lda, B, ldb, M, N, K, ep);
@@ -509,7 +513,9 @@ template <typename T> struct Engine : EngineBase {
     p.cls_slab = (!glyph_only && sizeof(T) == 2) ? b.take(4 * Tk * H * 4) : 0;      // fp32 planes of the split-K classifier data gradient
     if (!glyph_only && sizeof(T) == 2) {
       for (int k = 0; k < 3; ++k) {
-        p.sk_part[k] = b.take(NT8S_PART_BYTES); p.sk_flag[k] = b.take((int64_t)NT8S_GRID * NT8S_FLAG_STRIDE * 4 + 256);      // (flags: zero with the workspace; tags are never 0)
+        if (g_streamk) {       // (default off, DESIGN 6.6: 150 MB of exchange buffers are planned only for a plan built with the knob set)
+          p.sk_part[k] = b.take(NT8S_PART_BYTES); p.sk_flag[k] = b.take((int64_t)NT8S_GRID * NT8S_FLAG_STRIDE * 4 + 256);      // (flags: zero with the workspace; tags are never 0)
+        }
         p.ln_part[k] = b.take(Tk * 8 * 2 * 8);
         p.ln_flag[k] = 0;
         p.zero_once.push_back({p.ln_part[k], Tk * 8 * 2 * 8});
@@ -611,12 +617,49 @@ template <typename T> struct Engine : EngineBase {
     taps = keep;
     return p.total;
   }
+  // Workspace slots (round 6): a plan lives IN a workspace buffer (self-cleaning accumulators at zero, finite
+  // stale rows where a live-row step leaves them), so the engine remembers, per caller buffer it has been bound to, the plan installed
+  // there.  A caller that keeps one buffer per (B, S, Tp) key - modeling.py: train batch, eval batch, the short last batch, the
+  // glyph-only plan - pays the zero fill of install_plan ONCE per key; re-binding a remembered buffer restores its plan as it was.
+  // forget_workspace() before the caller frees a buffer (an allocator may hand the same address out again).
+  struct Slot { char* ws; int64_t bytes; Plan pl; std::map<std::string, std::pair<int64_t, int64_t>> taps; int ln_epoch[3]; unsigned sk_epoch[3]; uint64_t stamp; };
+  std::vector<Slot> slots;
+  uint64_t slot_clock = 0;
+  static constexpr size_t MAX_SLOTS = 8;
+  void stash_current() {
+    if (ws == nullptr) return;
+    Slot* s = nullptr;
+    for (Slot& x : slots) if (x.ws == ws) s = &x;
+    if (s == nullptr) {
+      if (slots.size() >= MAX_SLOTS) {       // (callers forget what they free; this bound only guards a caller that never does)
+        size_t old = 0;
+        for (size_t i = 1; i < slots.size(); ++i) if (slots[i].stamp < slots[old].stamp) old = i;
+        slots.erase(slots.begin() + old);
+      }
+      slots.push_back(Slot());
+      s = &slots.back();
+    }
+    s->ws = ws; s->bytes = ws_bytes; s->pl = pl; s->taps = taps; s->stamp = ++slot_clock;
+    for (int k = 0; k < 3; ++k) { s->ln_epoch[k] = ln_epoch[k]; s->sk_epoch[k] = sk_epoch[k]; }
+  }
   int bind(void* shadow, void* workspace, int64_t bytes) override {
     // everything the engine keeps inside the caller's shadow buffer (operand copies, the cast descriptor table, the chunk table of the
     // fresh-gradient zero fill) is rebuilt after a re-bind to another buffer
     if (shadow != (void*)sh) { glyph_built = false; descs_built = false; fill_built = false; n_fill = 0; skip_built = false; }
-    sh = (char*)shadow; ws = (char*)workspace; ws_bytes = bytes; pl = Plan(); have_fwd = false;
+    stash_current();
+    sh = (char*)shadow; ws = (char*)workspace; ws_bytes = bytes; pl = Plan(); have_fwd = false; have_glyph_fwd = false;
+    ln_epoch[0] = ln_epoch[1] = ln_epoch[2] = 0;
+    for (Slot& x : slots)
+      if (x.ws == ws && x.bytes == bytes) {
+        pl = x.pl; taps = x.taps; x.stamp = ++slot_clock;
+        for (int k = 0; k < 3; ++k) { ln_epoch[k] = x.ln_epoch[k]; sk_epoch[k] = x.sk_epoch[k]; }
+        break;
+      }
     return RL_OK;
+  }
+  void forget_workspace(void* workspace) override {
+    for (size_t i = 0; i < slots.size();) { if (slots[i].ws == (char*)workspace) slots.erase(slots.begin() + i); else ++i; }
+    if (ws == (char*)workspace) { ws = nullptr; ws_bytes = 0; pl = Plan(); have_fwd = false; have_glyph_fwd = false; }
   }
   void invalidate_frozen() override { glyph_built = false; }
   int* id_flag = nullptr;
@@ -667,6 +710,10 @@ template <typename T> struct Engine : EngineBase {
       {
         const DropParams d = site(sid * 1000 + (int)l * 10 + 1, cfg.attn_dropout);
         const T* q = wp<T>(t.qkv);
+        // INVARIANT: rlen goes to the attention FORWARD on live-row steps only.  With rlen the kernels leave the
+        // ctx / lse rows in [rlen[b], S) unwritten (attn_fwd_long: in some waves, zeros from others): only a step whose every consumer
+        // skips or masks those rows (rows_live: the layer GEMMs walk the live blocks, the backward masks what it reads) may pass it;
+        // a dense forward (evaluation, taps, engine:10=0) always gets nullptr and writes every row.
         RL_TRY(attn_fwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), H, wp<float>(t.lse), B, nh, S,
                            d.seed, d.thresh, d.scale, rows_live ? live_rlen() : nullptr));
       }
@@ -786,7 +833,7 @@ template <typename T> struct Engine : EngineBase {
       {
         const T* q = wp<T>(t.qkv);
         RL_TRY(attn_bwd<T>(st, q, q + H, q + 2 * H, 3 * H, wp<float>(pl.mask_add), wp<T>(t.ctx), gE, H, wp<float>(t.lse),
-                           wp<float>(sc.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale, dead_ok ? wp<int>(pl.live_rlen) : nullptr));
+                           wp<float>(sc.rowdot), gF, gF + H, gF + 2 * H, 3 * H, B, nh, S, d1.seed, d1.thresh, d1.scale, dead_ok ? wp<int>(pl.live_rlen) : nullptr));      // (backward: padding rows' gradients are exact zeros either way)
       }
       RL_TRY(wgrad(3, gF, 3 * H, x_in, H, 3 * H, H, gp(o.qkv_b), gp(o.qkv_w)));
       if (grouped) {
@@ -1100,9 +1147,12 @@ template <typename T> struct Engine : EngineBase {
     if (rows_live && (Tk % 16) == 0) ln.row_live = live_rows();      // x holds fresh rows in the listed blocks only: the others are not worth a pass
     return ln_fwd<T>(st, ln);
   }
+  int64_t plan_installs = 0;               // workspace zero fills so far (realise_engine_plan_installs: tests / bench count them)
+  int64_t plan_install_count() const override { return plan_installs; }
   int install_plan(hipStream_t st, const Plan& p) {
     if (p.total > ws_bytes) { fprintf(stderr, "[realise_hip] workspace too small: need %lld have %lld\n", (long long)p.total, (long long)ws_bytes); return RL_ERR_ARG; }
     pl = p;
+    ++plan_installs;
     ln_epoch[0] = ln_epoch[1] = ln_epoch[2] = 0;           // (the arrival counters are zero-filled below)
     // The whole workspace starts at zero (once per plan): the self-cleaning accumulators need it (zero_once), and a live-row step
     // leaves the activation rows of padding tokens as they are - what they hold must be finite wherever a later pass multiplies it by
@@ -1142,7 +1192,8 @@ template <typename T> struct Engine : EngineBase {
     // activation row there is an exact zero (the embedding scatter has relied on it since round 1).  The backward skips them
     // (LayerNorm backward rows, blocks of the weight-gradient reductions), and a live-row step (g_live_rows) does not compute
     // their forward activations in the transformer stacks either.
-    dead_ok = b.tgt_idx != nullptr && b.loss_masks != nullptr && g_skip_dead && b.want_dlogits && b.masks != nullptr && (Tk % 64) == 0;
+    dead_ok = b.tgt_idx != nullptr && b.loss_masks != nullptr && g_skip_dead && b.want_dlogits && b.masks != nullptr && (Tk % 64) == 0 &&
+              Tk / live_list_rows() <= TN_LIST_MAX_ENTRIES;      // (the weight-gradient kernels keep the block list in LDS: beyond 65536 bf16 token rows the step is dense)
     if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_t16), wp<int>(pl.live_n), wp<int>(pl.live_rlen)));
     // (the weight gradients of a live-row step must walk the same block list - only the grouped launch takes one: ADVICE round 4)
     rows_live = dead_ok && b.training && g_live_rows && g_wgrad_group && live16() && (H % 64) == 0 && (I % 64) == 0 && (int64_t)Tk * I * 2 < 0xFFFFFF00ll;

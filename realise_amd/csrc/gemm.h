@@ -331,7 +331,18 @@ inline int conv_s2_slot(int KH, int KW, int pad, int kh, int kw) {
 
 // ---- TN (weight-gradient) epilogue ---------------------------------------------------------------
 enum TnMode { TN_PLAIN = 0, TN_CONVW = 1 };
-constexpr int TN_LIST_LDS = 4096;      // bytes of LDS a TN kernel keeps its live-block list in: 1024 entries (16384 token rows in 16-row blocks)
+// LDS a TN kernel keeps its live-block list in, sized per launch from the number of list entries (a fixed 4 KB refused
+// batches beyond 16384 token rows): 4 KB (1024 entries = 16384 token rows in 16-row blocks, the bench shape: two 64 KB workgroups per
+// CU as before) up to TN_LIST_LDS_MAX = 16 KB (4096 entries = 65536 token rows; 2 x (64 + 16) KB still fit the 160 KB of a CU).
+// Longer lists are refused (RL_ERR_ARG); the engine does not build liveness tables for such batches (dense reductions).
+constexpr int TN_LIST_LDS = 4096;
+constexpr int TN_LIST_LDS_MAX = 16384;
+constexpr int TN_LIST_MAX_ENTRIES = TN_LIST_LDS_MAX / 4;
+inline int tn_list_lds_bytes(int64_t entries) {
+  if (entries > TN_LIST_MAX_ENTRIES) return -1;
+  const int64_t b = (entries * 4 + 1023) & ~(int64_t)1023;
+  return (int)(b < TN_LIST_LDS ? TN_LIST_LDS : b);
+}
 struct TnEpi {
   int mode = TN_PLAIN;
   float* out = nullptr;     // fp32, accumulated (out += result)

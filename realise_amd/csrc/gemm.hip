@@ -946,8 +946,10 @@ static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader
     }
   }
   const int how = nsplit == 1 ? TN_OUT_DIRECT : (ep.slab != nullptr ? TN_OUT_SLAB : TN_OUT_ATOMIC);
-  if (ep.tile_list != nullptr && (int64_t)P / (ep.list_rows ? ep.list_rows : G::BP) > TN_LIST_LDS / 4) return RL_ERR_ARG;
-  const size_t lds = 2 * (size_t)G::BP * (BI + BJ) * sizeof(T) + (ep.tile_list != nullptr ? TN_LIST_LDS : 0);
+  const int list_lds = ep.tile_list != nullptr ? tn_list_lds_bytes((int64_t)P / (ep.list_rows ? ep.list_rows : G::BP)) : 0;
+  if (list_lds < 0) return RL_ERR_ARG;
+  const size_t lds = 2 * (size_t)G::BP * (BI + BJ) * sizeof(T) + (size_t)list_lds;
+  const int lds_attr = (int)(2 * (size_t)G::BP * (BI + BJ) * sizeof(T)) + TN_LIST_LDS_MAX;
   dim3 grid(ntiles * nsplit);
   {
     ProfScope ps(st, sizeof(typename BLoader::KPos) == sizeof(typename DenseLoader<T>::KPos) ? PK_GEMM_TN : PK_CONV_TN, 2.0 * P * I * J);
@@ -955,11 +957,11 @@ static int launch_tn_tile(hipStream_t st, const T* A, int64_t lda, const BLoader
       if (lb.rows_dev != nullptr) prof_set_exec(lb.rows_dev, 2.0 * I * J, G::BP, P);       // the reduction stops at the device-side row bound
     if (sizeof(T) == 2 && g_tn_tr) {
       static bool a1 = false;
-      if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, true, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a1 = true; }
+      if (!a1) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, true, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr); a1 = true; }
       RL_LAUNCH((gemm_tn_kernel<T, BLoader, true, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
     } else {
       static bool a2 = false;
-      if (!a2) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, false, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); a2 = true; }
+      if (!a2) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, BLoader, false, WI, WJ>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr); a2 = true; }
       RL_LAUNCH((gemm_tn_kernel<T, BLoader, false, WI, WJ>), grid, dim3(256), lds, st, A, lda, lb, P, I, J, tiles_j, ntiles, nsplit, pchunk, how, ep);
     }
     if (how == TN_OUT_SLAB && ep.probe != 4) tn_fold_launch(st, ep, nsplit, I, J);
@@ -1019,16 +1021,18 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
   }
   grp.total_tiles = total;
   const int pchunk = ((P + G::BP - 1) / G::BP) * G::BP;
-  // (+ the live-block list: at most TN_LIST_LDS / 4 entries)
-  if (grp.tile_list != nullptr && (int64_t)P / grp.list_rows > TN_LIST_LDS / 4) return RL_ERR_ARG;
-  const size_t lds = 2 * (size_t)G::BP * 256 * sizeof(T) + (grp.tile_list != nullptr ? TN_LIST_LDS : 0);
+  // (+ the live-block list: sized from the entry count, at most TN_LIST_MAX_ENTRIES)
+  const int list_lds = grp.tile_list != nullptr ? tn_list_lds_bytes((int64_t)P / grp.list_rows) : 0;
+  if (list_lds < 0) return RL_ERR_ARG;
+  const size_t lds = 2 * (size_t)G::BP * 256 * sizeof(T) + (size_t)list_lds;
+  const int lds_attr = (int)(2 * (size_t)G::BP * 256 * sizeof(T)) + TN_LIST_LDS_MAX;
   ProfScope ps(st, PK_GEMM_TN, flops);
   if (grp.tile_list != nullptr) prof_set_exec(grp.n_tiles, flops / P * grp.list_rows, sizeof(T) == 2 && grp.list_rows == 16 ? 4 : 1, P / grp.list_rows);   // live blocks only
   // ring: the 2 full stages of the single-problem kernel (default) or 4 stages of half tiles (three tiles in flight per workgroup,
   // g_tn_group_ring = 1: built to test the fetch-latency hypothesis - 11 % slower)
 #define RL_TN_GROUP(TRV, NSTV, BPDV) do { \
     static bool attr = false; \
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<T, TRV, NSTV, BPDV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; } \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel<T, TRV, NSTV, BPDV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr); attr = true; } \
     RL_LAUNCH((gemm_tn_group_kernel<T, TRV, NSTV, BPDV>), dim3(total), dim3(256), lds, st, grp, P, pchunk); } while (0)
   const bool tr = sizeof(T) == 2 && g_tn_tr;
   if (ring4) { if (tr) RL_TN_GROUP(true, 4, 2); else RL_TN_GROUP(false, 4, 2); }

@@ -274,16 +274,18 @@ int gemm_tn8_group(hipStream_t st, int n, const TnGroupProblem<bf16_t>* probs, i
   }
   grp.total_tiles = total;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_tn8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + TN_LIST_LDS); attr_set = true; }
-  if (grp.tile_list != nullptr && P / 16 > TN_LIST_LDS / 4) return RL_ERR_ARG;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_tn8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + TN_LIST_LDS_MAX); attr_set = true; }
+  const int list_lds = grp.tile_list != nullptr ? tn_list_lds_bytes(P / 16) : 0;
+  if (list_lds < 0) return RL_ERR_ARG;
   ProfScope ps(st, PK_GEMM_TN, flops);
   if (grp.tile_list != nullptr) prof_set_exec(grp.n_tiles, flops / P * 16, 4, P / 16);
-  RL_LAUNCH(gemm_tn8_group_kernel, dim3(total), dim3(512), C::LDS + (grp.tile_list != nullptr ? TN_LIST_LDS : 0), st, grp, P, P);
+  RL_LAUNCH(gemm_tn8_group_kernel, dim3(total), dim3(512), C::LDS + list_lds, st, grp, P, P);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 
 bool tn8_supported(int64_t lda, int64_t ldb, int P, int I, int J, const TnEpi& ep) {
-  return ep.mode == TN_PLAIN && ep.tile_list == nullptr &&      // (a live-block list needs the grouped launch's LDS list area) P >= 1024 && I >= 256 && J >= 128 && (J % 4) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (I % 8) == 0 &&
+  // (a live-block list needs the grouped launch's LDS list area: ep.tile_list must be null here)
+  return ep.mode == TN_PLAIN && ep.tile_list == nullptr && P >= 1024 && I >= 256 && J >= 128 && (J % 4) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (I % 8) == 0 &&
          (J % 8) == 0 && (int64_t)P * lda * 2 < 0xFFFFFE00ll && (int64_t)P * ldb * 2 < 0xFFFFFE00ll && (ep.ldo % 4) == 0;
 }
 

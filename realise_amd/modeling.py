@@ -11,6 +11,7 @@ model so ``loss.backward()`` is a single C call that accumulates into the gradie
 There is no PyTorch / CPU fallback: forward on a non-CUDA device or without the built library
 raises.
 """
+import collections
 import ctypes as C
 import json
 import os
@@ -84,6 +85,8 @@ class RealiseModule(nn.Module):
         self._shadow = None
         self._ws = None
         self._ws_key = None
+        self._ws_cache = collections.OrderedDict()      # (B, S, Tp) -> workspace buffer, least recently used first
+        self.workspace_slots = 3
         self._shadow_version = None
         self._linear_copies_current = False
         self._step_seed = int(seed) * 1000003 + 12345
@@ -167,6 +170,7 @@ class RealiseModule(nn.Module):
         self._shadow = None
         self._ws = None
         self._ws_key = None
+        self._ws_cache = collections.OrderedDict()
         self._shadow_version = None
         self._linear_copies_current = False
         self._frozen_version = None
@@ -356,11 +360,26 @@ class RealiseModule(nn.Module):
             self._id_flag = torch.zeros(2, dtype=torch.int32).pin_memory()        # [0] id range, [1] fused-LayerNorm wait gave up
             lib.realise_engine_set_id_flag(self._engine, self._id_flag.data_ptr())
             self._ws = None
+            self._ws_key = None
+            self._ws_cache = collections.OrderedDict()
             self._frozen_version = None
+        # One workspace buffer per (B, S, Tp) key, the `workspace_slots` most recently used ones kept (round 6): the engine installs a
+        # plan INTO a buffer (one zero fill, ~0.3 - 2 ms) and remembers it per buffer, so a loop that alternates shapes - training
+        # batches and evaluation batches of another size, the short last batch of a window (run.py:104-123), the glyph-only plan -
+        # pays that fill once per shape, not at every switch.  9 GB per slot at B = 64, S = 128 (288 GB of HBM per GPU).
         key = (B, S, Tp)
-        need = lib.realise_engine_workspace_bytes(self._engine, B, S, Tp)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if key != self._ws_key or self._ws is None:
+            cache = self._ws_cache
+            if key in cache:
+                cache.move_to_end(key)
+            else:
+                while len(cache) >= max(1, int(self.workspace_slots)):
+                    _, old = cache.popitem(last=False)
+                    lib.realise_engine_forget_workspace(self._engine, old.data_ptr())
+                    del old
+                need = lib.realise_engine_workspace_bytes(self._engine, B, S, Tp)
+                cache[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws = cache[key]
             _capi.check(lib.realise_engine_bind(self._engine, self._shadow.data_ptr(), self._ws.data_ptr(), self._ws.numel()),
                         "realise_engine_bind")
         self._ws_key = key

@@ -50,13 +50,36 @@ def shard(items, rank, world):
 
 def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5, adam_epsilon=1e-8, weight_decay=0.0,
           warmup_steps=0, max_grad_norm=1.0, device="cuda", distributed=False, build_batch=None, tokenizer=None,
-          log_every=0, seed=17):
-    """the hot loop of run.py:125-237 with the fused optimizer; returns the mean loss."""
+          gradient_accumulation_steps=1, max_steps=-1, logging_steps=0, save_steps=0, output_dir=None, training_args=None,
+          log_every=0, log_fn=None, seed=17, return_global_step=False):
+    """the hot loop of run.py:125-237 with the fused optimizer.  Returns the mean loss per optimizer step (``tr_loss / global_step``,
+    run.py:237); with ``return_global_step=True`` the reference's pair ``(global_step, tr_loss / global_step)``.
+
+    Call sites reproduced (same names, same arithmetic):
+    * ``gradient_accumulation_steps`` (run.py:193-194, 203): the loss is divided before ``backward()`` (the division reaches the
+      engine as the device-side scalar d loss - no pass over the gradients), the optimizer steps every N-th batch, ``t_total``
+      counts optimizer steps (run.py:139-143), batches left over at the end of an epoch carry into the next one like the
+      reference's (its ``step`` restarts per epoch: so does this one);
+    * ``max_steps`` (run.py:139-141, 232-236): overrides the epoch count, the loop stops once ``global_step > max_steps``;
+    * ``logging_steps`` (run.py:214-221): every N optimizer steps, ``(tr_loss - logging_loss) / logging_steps`` and the
+      scheduler's rate go to ``log_fn`` (default ``print``) as "Step: {}, LR: {}, Loss: {}" - rank 0 only;
+      ``log_every`` is the older name of the same knob;
+    * ``save_steps`` (run.py:223-230): every N optimizer steps rank 0 writes ``output_dir/saved_ckpt-{global_step}`` with
+      ``save_pretrained`` and ``training_args.bin`` (``torch.save(training_args, ...)``: whatever object the caller hands over,
+      the reference saves its argparse namespace).
+    The per-step ``loss.item()`` of run.py:202 is a device-side accumulation here (no host synchronisation in the loop); the
+    windowed log line reads it back once per ``logging_steps``."""
+    import os
     build_batch = build_batch or type(model).build_batch
+    gas = max(1, int(gradient_accumulation_steps))
+    logging_steps = int(logging_steps or log_every or 0)
+    log_fn = log_fn or print
     model.to(device)
+    rank = 0
     if distributed:                    # run.py:130-137: every rank trains on its own strided shard
         import torch.distributed as dist
-        items = shard(list(items), dist.get_rank(), dist.get_world_size())
+        rank = dist.get_rank()
+        items = shard(list(items), rank, dist.get_world_size())
     wrapped = DistributedDataParallel(model) if distributed else model
     no_decay = ["bias", "LayerNorm.weight"]
     groups = [{"params": [p for n, p in model.named_parameters() if p.requires_grad and not any(nd in n for nd in no_decay)],
@@ -64,42 +87,70 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
               {"params": [p for n, p in model.named_parameters() if p.requires_grad and any(nd in n for nd in no_decay)],
                "weight_decay": 0.0}]
     opt = FusedAdamW(model, groups, lr=lr, eps=adam_epsilon, max_grad_norm=max_grad_norm)
-    # this loop owns every parameter write between opt.step() and the next forward: the step's operand copies can be trusted
-    # (modeling.py: trust_fused_optimizer; the module default re-derives every copy on every forward)
-    trusted_before = model.trust_fused_optimizer
-    model.trust_fused_optimizer = True
-    steps_total = max(1, len(items) // batch_size * epochs)          # t_total of run.py:142-144 (floor)
+    per_epoch = len(items) // batch_size // gas                       # optimizer steps per epoch (run.py:139-143, floor)
+    if max_steps > 0:
+        steps_total = max_steps
+        epochs = max_steps // max(1, per_epoch) + 1
+    else:
+        steps_total = max(1, per_epoch * epochs)
     sched = get_linear_schedule_with_warmup(opt, warmup_steps, steps_total)
     tr_loss = torch.zeros((), device=device)
-    step = 0
-    model.zero_grad()
-    for ep in range(epochs):
-        for batch in data_helper(items, batch_size, max_seq_length, build_batch, tokenizer, seed=seed + ep):
-            model.train()
-            for k, v in batch.items():
-                if torch.is_tensor(v):
-                    batch[k] = v.to(device)
-            loss = wrapped(batch)[0]
-            loss.backward()
-            tr_loss += loss.detach()
-            # nn.Embedding raises on an out-of-range id before anything is updated (modeling_bert.py:183-186).  The device-side check
-            # of this step ran at the head of its forward; poll its flag (host-mapped, no synchronisation) before the weights move,
-            # or wait for it when the model runs in strict mode
-            if getattr(model, "strict_ids", False):
-                model.check_ids()
-            elif hasattr(model, "_raise_on_bad_ids"):
-                model._raise_on_bad_ids()
-            opt.step()
-            sched.step()
-            model.zero_grad()
-            step += 1
-            if log_every and step % log_every == 0:
-                print("Step: %d, LR: %.3e, Loss: %.5f" % (step, sched.get_last_lr()[0], tr_loss.item() / step))
-    model.trust_fused_optimizer = trusted_before
-    model.mark_parameters_updated(frozen=False)       # whatever runs next re-derives every operand copy
+    logging_loss = 0.0
+    global_step = 0
+    # this loop owns every parameter write between opt.step() and the next forward: the step's operand copies can be trusted
+    # (modeling.py: trust_fused_optimizer; the module default re-derives every copy on every forward).  Restored on ANY exit
+    # (an exception inside the loop left the module trusting the optimizer's copies).
+    trusted_before = model.trust_fused_optimizer
+    model.trust_fused_optimizer = True
+    try:
+        model.zero_grad()
+        stop = False
+        for ep in range(epochs):
+            for step, batch in enumerate(data_helper(items, batch_size, max_seq_length, build_batch, tokenizer, seed=seed + ep)):
+                model.train()
+                for k, v in batch.items():
+                    if torch.is_tensor(v):
+                        batch[k] = v.to(device)
+                loss = wrapped(batch)[0]
+                if gas > 1:
+                    loss = loss / gas
+                loss.backward()
+                tr_loss += loss.detach()
+                if (step + 1) % gas == 0:
+                    # nn.Embedding raises on an out-of-range id before anything is updated (modeling_bert.py:183-186).  The device-side
+                    # check of this step ran at the head of its forward; poll its flag (host-mapped, no synchronisation) before the
+                    # weights move, or wait for it when the model runs in strict mode
+                    if getattr(model, "strict_ids", False):
+                        model.check_ids()
+                    elif hasattr(model, "_raise_on_bad_ids"):
+                        model._raise_on_bad_ids()
+                    opt.step()                 # clip_grad_norm_(max_grad_norm) + AdamW in the same sweep (run.py:207-209)
+                    sched.step()
+                    model.zero_grad()
+                    global_step += 1
+                    if rank == 0 and logging_steps > 0 and global_step % logging_steps == 0:
+                        now = tr_loss.item()
+                        log_fn("Step: {}, LR: {}, Loss: {}".format(global_step, sched.get_last_lr()[0], (now - logging_loss) / logging_steps))
+                        logging_loss = now
+                    if rank == 0 and save_steps > 0 and global_step % save_steps == 0:
+                        if output_dir is None:
+                            raise ValueError("save_steps needs output_dir")
+                        ckpt = os.path.join(output_dir, "saved_ckpt-{}".format(global_step))
+                        os.makedirs(ckpt, exist_ok=True)
+                        model.save_pretrained(ckpt)
+                        torch.save(training_args, os.path.join(ckpt, "training_args.bin"))
+                if max_steps > 0 and global_step > max_steps:
+                    stop = True
+                    break
+            if stop:
+                break
+    finally:
+        model.trust_fused_optimizer = trusted_before
+        model.mark_parameters_updated(frozen=False)       # whatever runs next re-derives every operand copy
     if hasattr(model, "check_ids"):
         model.check_ids()                  # a bad id in the last batches must not go unreported
-    return tr_loss.item() / max(1, step)
+    mean = tr_loss.item() / max(1, global_step)
+    return (global_step, mean) if return_global_step else mean
 
 
 @torch.no_grad()
