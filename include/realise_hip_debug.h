@@ -37,7 +37,9 @@ void realise_set_nt_variant(int v);
  * K-tiles to share out (qkv, FFN-up / -down and their data gradients) on the stream-K 256 x 192 kernel (1) or on the 128 x 192 two-per-CU
  * kernels (0, default: measured faster on every layer shape, and their live-row results are bit-identical to the dense step's - a tile that
  * stream-K cuts sums its K range in two or three chains); key 12 = the least K-tiles per workgroup of a launch that select the stream-K
- * kernel under key 11 (default 10; 0: every shape it supports) */
+ * kernel under key 11 (default 10; 0: every shape it supports; keys 11 / 12 act in the probe build only - round 6); key 13 = K7, the
+ * glyph lookup fused into the loaders of block 1's forward convolutions (1, default: no gathered image batch in the forward; a
+ * training step gathers it at the head of the backward for the two weight-gradient reductions) or gather_images + dense loaders (0) */
 void realise_set_engine(int key, int value);
 /* realise_gemm_tn_grouped over a list of live reduction blocks, as the engine's backward calls it: live[k] (device, ascending) = index
  * of the k-th block of `list_rows` rows that holds anything but exact zeros in the A operands, *n_live (device) = how many; the other
@@ -54,6 +56,11 @@ int realise_gemm_nt_rows(void* stream, int dtype, const void* A, int64_t lda, co
  * are neither read nor written. */
 int realise_gemm_nt_live(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
                          const realise_epilogue* ep, const int* live_list, const int* live_count);
+/* Round 6: the same over a device-side list of ROWS (row-granular packing, what a training step launches by default): row_list[k] =
+ * index of the k-th listed row (ascending), *row_count = how many; tile t of the 128 x 192 kernel works on rows row_list[128 t ..
+ * 128 t + 127], so no tile row is spent on rows that merely complete a 16-row block.  Listed rows: bit-identical to the dense launch. */
+int realise_gemm_nt_live_rows(void* stream, const void* A, int64_t lda, const void* B, int64_t ldb, int M, int N, int K,
+                              const realise_epilogue* ep, const int* row_list, const int* row_count);
 /* The stream-K form of the layer GEMMs (bf16, K % 128 == 0; gemm_nt8s.hip): ONE round of 256 workgroups over 256 x 192 tiles, the
  * (tile, K-tile) space cut into 256 equal ranges, tiles that a cut splits folded in-kernel in workgroup order.  live_list / live_count
  * as realise_gemm_nt_live, or both NULL (all rows).  part: exchange buffer of 256 * 24 * 512 * 16 bytes; flags: 256 x 64 ints (a flag every 256 bytes), zero before the

@@ -78,6 +78,7 @@ SYMBOLS = {
     "realise_gemm_tn_grouped": (_I, [_P, _I, _I, C.POINTER(TnProblem), _I]),
     "realise_gemm_nt_rows": (_I, [_P, _I, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue), _P]),
     "realise_gemm_nt_live": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue), _P, _P]),
+    "realise_gemm_nt_live_rows": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue), _P, _P]),
     "realise_gemm_nt_streamk": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, C.POINTER(Epilogue), _P, _P, _P, _P, _I, _P]),
     "realise_gemm_nt_splitk": (_I, [_P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _P]),
     "realise_gemm_tn_grouped_live": (_I, [_P, _I, _I, C.POINTER(TnProblem), _I, _P, _P, _I, _I]),

@@ -79,7 +79,13 @@ void set_cls_splitk(int n) { g_cls_splitk = n < 0 ? 0 : (n > 4 ? 4 : n); }
 // installed), the returned training logits of such rows are computed from those stale states and mean nothing, as the reference's
 // mean nothing.  The loss, every live row's activations and every gradient are bit-identical to the dense pass (same kernels, same
 // accumulation order per row; tests/test_round4_gpu.py).  Evaluation / inference forwards are always dense.
-static int g_live_rows = 1;
+// Round 6, value 2 (DEFAULT): the list the layer GEMMs walk holds the live ROWS, not 16-row blocks (gemm_nt8_live, EpiParams::live_unit
+// = 1): a GEMM tile is any 128 live rows.  The blocks that complete a sentence's last 16 rows cost 0.709 - 0.648 = 6 % of the batch's
+// rows, and 42 instead of 46 tile rows put the 2304-wide qkv launch into ONE round of the 512 two-per-CU slots.  Every other consumer
+// (LayerNorm, attention, the weight-gradient reductions) keeps the 16-row block tables: rows 16-row blocks hold beyond the live
+// length are simply not produced by the GEMMs any more, and they are rows every consumer already treats as padding (row_live == 0).
+// 1 = the round-4 / 5 form (16-row blocks), 0 = dense.
+static int g_live_rows = 2;
 void set_live_rows(int on) { g_live_rows = on; }
 // realise_set_engine(11, v): 1 = the layer GEMMs of the transformer stacks on the stream-K 256 x 192 kernel (gemm_nt8s.hip) where its
 // one-round launch has at least g_streamk_min (realise_set_engine(12, n), default 10) K-tiles per workgroup to share out; 0 (default): the
@@ -91,6 +97,14 @@ static int g_streamk = 0;
 static int g_streamk_min = 10;
 void set_streamk(int v) { g_streamk = (RL_PROBES && v > 0) ? 1 : 0; }
 void set_streamk_min(int n) { g_streamk_min = n > 0 ? n : 0; }
+// K7 (realise_set_engine key 13, default 1; models.py:831-834): the glyph lookup `char_images_multifonts.index_select(0, ids)` is fused
+// into the loaders of block 1's two forward convolutions - they gather the 3x3 / 1x1 taps straight from the NHWC glyph table through
+// the list of distinct ids (ConvLoader::img_index: one index load per 8-row piece in the tile prologue, nothing in the K loop) - so
+// the forward materialises no [U, 32, 32, 8] image batch.  A TRAINING step still needs the gathered images as the B operand of block
+// 1's two weight-gradient reductions (an index load inside that kernel's K loop costs a full drain per fetch): they are
+// gathered at the head of the backward, off the forward's path.  0 = gather_images in the forward, dense loaders (round 2-5 form).
+static int g_glyph_fuse = 1;
+void set_glyph_fuse(int on) { g_glyph_fuse = on; }
 static int g_stream_pri[3] = {0, 0, 0};
 void set_stream_priority(int which, int pri) { if (which >= 0 && which < 3) g_stream_pri[which] = pri < 0 ? -1 : (pri > 0 ? 1 : 0); }
 static hipError_t create_stream(hipStream_t* s, int which) {
@@ -158,6 +172,7 @@ template <typename T> struct Engine : EngineBase {
     int64_t cls_act, cls_inv, cls_nact, cls_xc, cls_gc, cls_slab;
     int64_t sk_part[3] = {0, 0, 0}, sk_flag[3] = {0, 0, 0};       // stream-K GEMMs: exchange buffer + workgroup flags, one set per stack (= stream)
     int64_t ln_part[3] = {0, 0, 0}, ln_flag[3] = {0, 0, 0};       // fused GEMM + LayerNorm: per-row tile partials + arrival counters, one set per stack (= stream)
+    int64_t live_rows = 0;                // ascending list of the live rows (row-granular layer GEMMs)
     int64_t row_live, live_t64, live_t32, live_t16, live_n, live_rlen;          // padding rows: exact-zero gradient rows the backward skips (row_liveness)     // classifier backward over the rows that enter the loss only (stage_head)
     int64_t ids_clean = 0, pho_clean = 0;                 // range-checked copies of src_idx / pho_idx (sanitize_ids)
     int64_t gru_table, gru_hs, gru_rzn, gru_gh, gru_out;
@@ -246,10 +261,14 @@ template <typename T> struct Engine : EngineBase {
   // a layer GEMM over the token rows: the live blocks of a live-row step (no dense fall-back: the dead rows of its operands are stale)
   int nt_sid = -1;                         // stack whose layers are being enqueued (stack_forward / layers_backward): selects the stream-K buffers
   unsigned sk_epoch[3] = {0, 0, 0};
-  int nt_rows(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep) {
+  // whole_blocks: the output is the dY operand of a weight-gradient reduction, which walks whole live 16-row BLOCKS - its rows behind a
+  // sentence's last live row inside such a block must be (re)computed (exact zeros: their dY inputs are LayerNorm-backward zeros), not
+  // left stale, so that launch keeps the block list (the GELU' data gradient of BertOutput, one of a layer's eight GEMMs).
+  int nt_rows(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep, bool whole_blocks = false) {
     if constexpr (sizeof(T) == 2) {
       EpiParams<T> e2 = ep;
-      if (rows_live) { e2.live_list = wp<int>(pl.live_t16); e2.live_count = wp<int>(pl.live_n) + 2; }
+      if (rows_live && g_live_rows == 2 && !whole_blocks) { e2.live_list = wp<int>(pl.live_rows); e2.live_count = wp<int>(pl.live_n) + 3; e2.live_unit = 1; }
+      else if (rows_live) { e2.live_list = wp<int>(pl.live_t16); e2.live_count = wp<int>(pl.live_n) + 2; }
       // one round of 256 workgroups over 256 x 192 tiles (stream-K) where there is enough to share out; a stack's launches are
       // serialised by its stream, so one exchange buffer per stack does
 #if RL_PROBES
@@ -507,7 +526,7 @@ template <typename T> struct Engine : EngineBase {
     p.count = b.take(256);
     p.loss_internal = b.take(Tk * 4 + 256);       // per-row loss terms (ordered fold: reproducible loss)
     p.cls_act = b.take(Tk * 4); p.cls_inv = b.take(Tk * 4); p.cls_nact = b.take(256);
-    p.row_live = b.take(Tk + 64); p.live_t64 = b.take((Tk / 32 + 2) * 4); p.live_t32 = b.take((Tk / 32 + 2) * 4); p.live_t16 = b.take((Tk / 16 + 4) * 4); p.live_n = b.take(256); p.live_rlen = b.take(B * 4 + 64);
+    p.row_live = b.take(Tk + 64); p.live_t64 = b.take((Tk / 32 + 2) * 4); p.live_t32 = b.take((Tk / 32 + 2) * 4); p.live_t16 = b.take((Tk / 16 + 4) * 4); p.live_n = b.take(256); p.live_rlen = b.take(B * 4 + 64); p.live_rows = b.take((Tk + 128) * 4);
     p.cls_xc = b.take(Tk * H * e); p.cls_gc = b.take(Tk * H * e);
     p.zero_once.push_back({p.cls_xc, Tk * H * e}); p.zero_once.push_back({p.cls_gc, Tk * H * e});
     p.cls_slab = (!glyph_only && sizeof(T) == 2) ? b.take(4 * Tk * H * 4) : 0;      // fp32 planes of the split-K classifier data gradient
@@ -811,7 +830,7 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(wgrad(0, dso, H, wp<T>(t.post), I, H, I, gp(o.out_b), gp(o.out_w)));
       {  // d pre = (d s2' . W_out) * gelu'(pre)
         EpiParams<T> ep; ep.mode = EPI_GELU_BWD; ep.out = gD; ep.ldo = I; ep.aux = wp<T>(t.pre); ep.ldaux = I;
-        RL_TRY(nt_rows(st, dso, H, sp<T>(w.out_wT), H, Tk, I, H, ep));
+        RL_TRY(nt_rows(st, dso, H, sp<T>(w.out_wT), H, Tk, I, H, ep, true));      // gD feeds wgrad(1): whole live blocks
       }
       RL_TRY(wgrad(1, gD, I, wp<T>(t.y1), H, I, H, gp(o.in_b), gp(o.in_w)));
       {  // d y1 = d s2 + d pre . W_in
@@ -875,6 +894,7 @@ template <typename T> struct Engine : EngineBase {
     ConvLoader<T> g;
     g.src = src; g.img_index = index; g.rows = rows; g.rows_dev = rows_dev; g.Hr = Hr; g.Wr = Hr; g.Hs = Hs; g.Ws = Hs; g.C = C;
     g.KH = ksz; g.KW = ksz; g.stride = stride; g.pad = pad; g.mode = mode; g.K = ksz * ksz * C;
+    if (index != nullptr) g.index_rows = V;          // (gathers from the whole glyph table: the 32-bit offset span check uses the table size)
     return g;
   }
   // glyph dedup bookkeeping of block k's output map: device row bound, multiplicities, pixels per image
@@ -905,6 +925,11 @@ template <typename T> struct Engine : EngineBase {
     }
     return RL_OK;
   }
+  bool glyph_gathered = false;             // gu_dense holds the distinct glyph images of the last resnet_forward
+  int gather_glyphs(hipStream_t st) {
+    return gather_images<T>(st, sp<T>(sh_glyph), wp<int64_t>(pl.gu_ids), wp<int>(pl.gu_bounds), pl.B * pl.S,
+                            (int64_t)cfg.glyph_size * cfg.glyph_size * 8, wp<T>(pl.gu_dense));
+  }
   int resnet_forward(hipStream_t st, const int64_t* ids, const T** out) {
     // The glyph stack of a token depends only on its id, so the ResNet runs once per DISTINCT id of the batch
     // (order of first occurrence) and BatchNorm weights each glyph by its multiplicity: identical statistics
@@ -915,10 +940,11 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(glyph_unique(st, ids, pl.B * pl.S, V, wp<int>(pl.gu_first), wp<int>(pl.gu_flag), wp<int64_t>(pl.gu_ids),
                           wp<float>(pl.gu_counts), wp<int>(pl.gu_inv), wp<int>(pl.gu_bounds), hw));
     }
-    RL_TRY(gather_images<T>(st, sp<T>(sh_glyph), wp<int64_t>(pl.gu_ids), wp<int>(pl.gu_bounds), pl.B * pl.S,
-                            (int64_t)cfg.glyph_size * cfg.glyph_size * 8, wp<T>(pl.gu_dense)));
-    const T* x = wp<T>(pl.gu_dense);
-    const int64_t* index = nullptr;
+    const bool fuse7 = g_glyph_fuse != 0 && (int64_t)V * cfg.glyph_size * cfg.glyph_size * 8 * (int64_t)sizeof(T) < 0xFFFFFE00ll;
+    glyph_gathered = !fuse7;
+    if (!fuse7) RL_TRY(gather_glyphs(st));
+    const T* x = fuse7 ? sp<T>(sh_glyph) : wp<T>(pl.gu_dense);
+    const int64_t* index = fuse7 ? wp<int64_t>(pl.gu_ids) : nullptr;
     for (int k = 0; k < 5; ++k) {
       const BlockOff& o = L.blocks[k];
       const BlockSh& s = sh_blk[k];
@@ -957,6 +983,7 @@ template <typename T> struct Engine : EngineBase {
   int resnet_backward(hipStream_t st, const T* d_top) {
     float* sums = wp<float>(pl.bn_sums);
     const T* d_out = d_top;
+    if (!glyph_gathered) { RL_TRY(gather_glyphs(st)); glyph_gathered = true; }      // K7: block 1's weight gradients read the gathered images
     for (int k = 4; k >= 0; --k) {
       const BlockOff& o = L.blocks[k];
       const BlockSh& s = sh_blk[k];
@@ -1194,7 +1221,7 @@ template <typename T> struct Engine : EngineBase {
     // their forward activations in the transformer stacks either.
     dead_ok = b.tgt_idx != nullptr && b.loss_masks != nullptr && g_skip_dead && b.want_dlogits && b.masks != nullptr && (Tk % 64) == 0 &&
               Tk / live_list_rows() <= TN_LIST_MAX_ENTRIES;      // (the weight-gradient kernels keep the block list in LDS: beyond 65536 bf16 token rows the step is dense)
-    if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_t16), wp<int>(pl.live_n), wp<int>(pl.live_rlen)));
+    if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_t16), wp<int>(pl.live_n), wp<int>(pl.live_rlen), wp<int>(pl.live_rows)));
     // (the weight gradients of a live-row step must walk the same block list - only the grouped launch takes one: ADVICE round 4)
     rows_live = dead_ok && b.training && g_live_rows && g_wgrad_group && live16() && (H % 64) == 0 && (I % 64) == 0 && (int64_t)Tk * I * 2 < 0xFFFFFF00ll;
     const T* bert_h = nullptr;

@@ -238,7 +238,10 @@ __device__ __forceinline__ void nt8_gru_epilogue(char* smem, const EpiParams<bf1
 
 // XEPI: 0 = the standard epilogues (EpiParams::mode), 1 = K4 (+ LayerNorm across the row band's tiles), 2 = K6 (GRU gate math on
 // gate-interleaved B rows), 3 = the standard epilogues over a LIST of live 16-row blocks (EpiParams::live_list) - separate
-// instantiations, so that the special forms' registers are not the layer GEMMs' problem
+// instantiations, so that the special forms' registers are not the layer GEMMs' problem; 4 = the same over a LIST of live ROWS
+// (round 6, EpiParams::live_unit == 1: row-granular packing - a tile is ANY 128 listed rows, so no tile row is spent on the padding
+// rows that complete a sentence's last 16-row block; the per-lane fetch offset of a piece and the output row of an epilogue item
+// come from the list, nothing changes in the main loop)
 template <typename C, int PROBE, bool KTAIL = false, int XEPI = 0>
 __global__ void __launch_bounds__(512, 2 * C::WGS)
 gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __restrict__ B_, int64_t ldb, int M, int N, int K, int tiles_n,
@@ -262,18 +265,20 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
     const int per = (((K + 63) >> 6) + ep.ksplit - 1) / ep.ksplit;
     const int k0 = split * per * 64;
     A += k0; B += k0; K = min(K - k0, per * 64);
-  } else if constexpr (XEPI == 3) {
+  } else if constexpr (XEPI == 3 || XEPI == 4) {
     tile = 0;
   } else {
     tile = xcd_remap(blockIdx.x, ntiles);
   }
   int tm, tn;
   int nlive = 0;                                            // XEPI 3: live 16-row blocks; tile row tm owns list entries tm * BM / 16 ..
-  if constexpr (XEPI == 3) {
+  constexpr bool LIVE = XEPI == 3 || XEPI == 4;
+  constexpr int LUNIT = XEPI == 4 ? 1 : 16;                 // rows per list entry
+  if constexpr (LIVE) {
     // the launch is sized for every block being live; the XCD split is made over the tiles that exist (made over the nominal count,
     // the surplus tiles - the tail of the logical order - would all sit on the last XCDs and leave them idle)
     nlive = *ep.live_count;
-    const int tml = (nlive + C::BM / 16 - 1) / (C::BM / 16);      // live tile rows
+    const int tml = (nlive + C::BM / LUNIT - 1) / (C::BM / LUNIT);      // live tile rows
     const int ntl = tml * tiles_n;
     if (ep.xcd_gc > 1) {
       // 2-D XCD split (EpiParams::xcd_gc): XCD x = blockIdx % 8 (as dispatched today; another placement changes speed only) works on row
@@ -295,7 +300,7 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   }
   const int m0 = tm * C::BM, n0 = tn * C::BN;
   const int mlive = ep.m_dev != nullptr ? *ep.m_dev : M;
-  if (XEPI != 3 && m0 >= mlive) return;                     // device-side live-row count: the whole workgroup leaves before any barrier
+  if (!LIVE && m0 >= mlive) return;                         // device-side live-row count: the whole workgroup leaves before any barrier
   const int mzero = ep.m_exact ? mlive : M;                 // A rows at or beyond it read as zeros
   GruRows gru_rows;
   if constexpr (XEPI == 2) nt8_gru_prefetch<C>(ep, gru_rows, mlive, N / 3, m0, tn, wave / C::WN, wave % C::WN, lane);
@@ -325,7 +330,15 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
         grow = gate * (N / 3) + tn * 64 + half * 32 + (cc & 31);
       }
     }
-    bool park = XEPI != 3 && !is_b && m0 + row + lrow >= mzero;
+    bool park = !LIVE && !is_b && m0 + row + lrow >= mzero;
+    if constexpr (XEPI == 4) {
+      if (!is_b) {                                  // the lane's row of the piece is the list's entry (tile row tm owns entries tm * BM ..)
+        const int j = tm * C::BM + row + lrow;
+        const int r = j < nlive ? ep.live_list[j] : -1;
+        grow = r < 0 ? 0 : r;
+        park = r < 0;                               // list exhausted inside the last tile: zeros
+      }
+    }
     if constexpr (XEPI == 3) {
       if (!is_b) {                                  // a piece is 8 rows of ONE 16-row block (row % 8 == 0): wave-uniform list entry
         const int j = tm * (C::BM / 16) + (row >> 4);
@@ -473,6 +486,20 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   // the stores before it; the bias-only epilogues - qkv, FFN-up - now run their items without a single wait).  Same (acc * alpha) +
   // bias per element as epilogue8: same bits.
   EpiParams<bf16_t> epx = ep;
+  // row-granular list: the output row of every item this lane will store (NCH chunks x NIT items), requested here - before the first
+  // store, so that no tracked load meets a pending store later -; -1 beyond the list
+  constexpr int NCH_ = C::RM / ER;
+  int rid[XEPI == 4 ? NCH_ : 1][XEPI == 4 ? NIT : 1];
+  if constexpr (XEPI == 4) {
+#pragma unroll
+    for (int c = 0; c < NCH_; ++c)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int e = lane + 64 * it, r = e / ITEMS;
+        const int jr = tm * C::BM + wm * C::RM + c * ER + r;
+        rid[c][it] = jr < nlive ? ep.live_list[jr] : -1;
+      }
+  }
   if constexpr (!KTAIL) {
     if (ep.bias_first && ep.slab == nullptr) {
       if (ep.alpha != 1.0f) {
@@ -496,7 +523,7 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   // Round 5 (same knob): the residual / pre-activation / accumulated-output octets of ALL of the wave's items are requested here, before
   // the first store, from addresses clamped into the matrix (unconditional loads: nothing between them for the compiler to wait on);
   // epilogue8_pre then runs item by item on registers.  Two-per-CU shape only (RM / ER chunks x NIT items = 6 octets = 24 registers).
-  if constexpr (!KTAIL && (XEPI == 0 || XEPI == 3) && C::WGS == 2) {
+  if constexpr (!KTAIL && (XEPI == 0 || LIVE) && C::WGS == 2) {
     const bool use_aux = ep.mode == EPI_DROP_RESID || ep.mode == EPI_GELU_BWD;
     const bool use_old = ep.mode == EPI_STORE && ep.accumulate != 0;
     if (ep.bias_first && ep.slab == nullptr && ep.rm_hw_shift < 0 && (use_aux || use_old) && !(ep.mode == EPI_GELU_BWD && ep.accumulate) &&
@@ -524,7 +551,9 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
           const int e = lane + 64 * it, r = e / ITEMS, c8 = e - r * ITEMS;
-          pre[c][it] = *(const u32x4_t*)(src + (int64_t)min(rcs[c] + r, M - 1) * ld + min(col_w + c8 * 8, N - 8));
+          int prow = rcs[c] + r;
+          if constexpr (XEPI == 4) prow = max(rid[c][it], 0);
+          pre[c][it] = *(const u32x4_t*)(src + (int64_t)min(prow, M - 1) * ld + min(col_w + c8 * 8, N - 8));
         }
       // first transpose under the loads' latency, then ONE unconditional wait for all six octets: left to their first uses - inside the
       // items' bounds-check branches - the compiler could not prove them landed on every path and re-waited, with stores pending, by vmcnt(0)
@@ -550,7 +579,11 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
         for (int it = 0; it < NIT; ++it) {
           const int e = lane + 64 * it, r = e / ITEMS, c8 = e - r * ITEMS;
           const floatx4 v0 = *(const floatx4*)(et + r * RS + c8 * 8), v1 = *(const floatx4*)(et + r * RS + c8 * 8 + 4);
-          if (cok[c]) epilogue8_pre(e3, M, N, rcs[c] + r, col_w + c8 * 8, v0, v1, __builtin_bit_cast(uint4, pre[c][it]));
+          if constexpr (XEPI == 4) {
+            if (rid[c][it] >= 0) epilogue8_pre(e3, M, N, rid[c][it], col_w + c8 * 8, v0, v1, __builtin_bit_cast(uint4, pre[c][it]));
+          } else {
+            if (cok[c]) epilogue8_pre(e3, M, N, rcs[c] + r, col_w + c8 * 8, v0, v1, __builtin_bit_cast(uint4, pre[c][it]));
+          }
         }
       }
       return;
@@ -560,7 +593,7 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   for (int c = 0; c < C::RM / ER; ++c) {
     int row_c = row_w + c * ER;
     if constexpr (XEPI == 3) {                      // the chunk's 16 rows are one listed block (or lie beyond the list: nothing to store)
-      static_assert(XEPI != 3 || ER == 16, "live-row form: one 16-row block per epilogue chunk");
+      static_assert(!LIVE || ER == 16, "live-row form: one 16-row block per epilogue chunk");
       const int j = tm * (C::BM / 16) + ((wm * C::RM + c * ER) >> 4);
       if (j >= nlive) continue;
       row_c = ep.live_list[j] * 16;
@@ -573,7 +606,9 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
     for (int it = 0; it < NIT; ++it) {
       const int e = lane + 64 * it, r = e / ITEMS, c8 = e - r * ITEMS;
       const floatx4 v0 = *(const floatx4*)(et + r * RS + c8 * 8), v1 = *(const floatx4*)(et + r * RS + c8 * 8 + 4);
-      if (!KTAIL && ep.slab != nullptr) {
+      if constexpr (XEPI == 4) {
+        if (rid[c][it] >= 0) epilogue8<T>(epx, M, N, rid[c][it], col_w + c8 * 8, v0, v1);
+      } else if (!KTAIL && ep.slab != nullptr) {
         const int row = row_c + r, col = col_w + c8 * 8;
         if (row < M && col < N) {
           float* o = ep.slab + (int64_t)split * ep.slab_stride + (int64_t)row * N + col;
@@ -605,6 +640,7 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
   ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
   if (ep.m_dev != nullptr) prof_set_exec(ep.m_dev, 2.0 * N * K, C::BM, M);      // tiles that start at or beyond the count leave at once
   if constexpr (XEPI == 3) prof_set_exec(ep.live_count, 2.0 * N * K * 16.0, C::BM / 16, M / 16);      // (counted in 16-row blocks)
+  if constexpr (XEPI == 4) prof_set_exec(ep.live_count, 2.0 * N * K, C::BM, M);                       // (counted in rows, whole tiles)
 #if RL_PROBES
   if constexpr (!KTAIL) {
     if (g_nt8_probe == 2) { RL_LAUNCH((gemm_nt8_kernel<C, 2>), dim3(ntiles), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, ep); return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH; }
@@ -614,7 +650,7 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
   EpiParams<bf16_t> epk = ep;
   epk.bias_first = nt8_bias_first_on() && (N % 4) == 0 && N >= 4;
   int grid = ntiles * (KTAIL || ep.ksplit < 1 ? 1 : ep.ksplit);
-  if constexpr (XEPI == 3) { if (ep.xcd_gc > 1) grid = (tiles_m + 8 / ep.xcd_gc) * tiles_n; }      // every row group rounded up to whole tile rows
+  if constexpr (XEPI == 3 || XEPI == 4) { if (ep.xcd_gc > 1) grid = (tiles_m + 8 / ep.xcd_gc) * tiles_n; }      // every row group rounded up to whole tile rows
   RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL, XEPI>), dim3(grid), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, epk);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
@@ -920,6 +956,8 @@ int gemm_nt8_live(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B,
   if (g_nt8_live_gc) gc = g_nt8_live_gc;
   while (gc > 1 && (tiles_n % gc) != 0) gc >>= 1;
   e2.xcd_gc = gc;
+  if (ep.live_unit == 1) return launch_nt8_cfg<Cfg128x192q, false, 4>(st, A, lda, B, ldb, M, N, K, e2);      // list of rows
+  if (ep.live_unit != 16) return RL_ERR_ARG;
   return launch_nt8_cfg<Cfg128x192q, false, 3>(st, A, lda, B, ldb, M, N, K, e2);
 }
 

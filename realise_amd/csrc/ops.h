@@ -79,9 +79,10 @@ template <typename T> struct LnBwdArgs {
 // masks == 1 or loss_masks == 1 (everything after it is padding that no query attends to and no loss term reads: every backward
 // activation row there is an exact zero).  row_live[B * S] bytes; tiles64 / tiles32 / tiles16 (nullable): ascending indices of the
 // 64- / 32- / 16-row blocks of the token rows that hold a live row, n_tiles[0..2] their counts (the live-block lists of the
-// weight-gradient reductions).
+// weight-gradient reductions).  rows (nullable): the live rows themselves, ascending, n_tiles[3] of them (round 6: the row-granular
+// list of the layer GEMMs).
 int row_liveness(hipStream_t st, const int64_t* masks, const int64_t* loss_masks, int B, int S, uint8_t* row_live, int* tiles64, int* tiles32,
-                 int* tiles16, int* n_tiles, int* rlen);       // rlen[b] = live rows of sentence b (the attention backward's bound)
+                 int* tiles16, int* n_tiles, int* rlen, int* rows = nullptr);       // rlen[b] = live rows of sentence b (the attention backward's bound)
 template <typename T> int ln_bwd(hipStream_t st, const LnBwdArgs<T>& a);
 // dgamma / dbeta += fixed-order sum of the per-workgroup records of up to LN_FOLD_MAX LayerNorm sites, one launch
 constexpr int LN_FOLD_MAX = 8;

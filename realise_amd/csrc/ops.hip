@@ -1235,7 +1235,7 @@ __device__ __forceinline__ float block_reduce(float v, float* sm, bool is_max) {
 // 32- and 16-row block lists by ballot + prefix scan (ascending, deterministic).
 __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __restrict__ masks, const int64_t* __restrict__ loss_masks, int B, int S,
                                                              uint8_t* __restrict__ row_live, int* __restrict__ tiles64, int* __restrict__ tiles32,
-                                                             int* __restrict__ tiles16, int* __restrict__ n_tiles, int* __restrict__ rlen) {
+                                                             int* __restrict__ tiles16, int* __restrict__ n_tiles, int* __restrict__ rlen, int* __restrict__ rows) {
   __shared__ int wsum[16];
   __shared__ int base_s;
   const int T = B * S, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1253,9 +1253,9 @@ __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __res
   }
   __syncthreads();
   // phase 3: block lists
-  for (int pass = 0; pass < 3; ++pass) {
-    const int bp = 64 >> pass;
-    int* out = pass == 0 ? tiles64 : (pass == 1 ? tiles32 : tiles16);
+  for (int pass = 0; pass < 4; ++pass) {          // (pass 3: the live ROWS themselves, n_tiles[3] of them - the row-granular GEMM list)
+    const int bp = pass == 3 ? 1 : 64 >> pass;
+    int* out = pass == 0 ? tiles64 : (pass == 1 ? tiles32 : (pass == 2 ? tiles16 : rows));
     if (out == nullptr) continue;
     if (threadIdx.x == 0) base_s = 0;
     __syncthreads();
@@ -1263,7 +1263,8 @@ __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __res
     for (int k0 = 0; k0 < nblk; k0 += 1024) {
       const int k = k0 + threadIdx.x;
       bool live = false;
-      if (k < nblk)
+      if (k < nblk && bp == 1) live = row_live[k] != 0;
+      else if (k < nblk)
         for (int r = 0; r < bp; r += 16) {                       // 16 row bytes at a time
           const uint4 v = *(const uint4*)(row_live + (int64_t)k * bp + r);
           live = live || (v.x | v.y | v.z | v.w) != 0u;
@@ -1284,9 +1285,9 @@ __global__ void __launch_bounds__(1024) row_liveness_kernel(const int64_t* __res
   }
 }
 int row_liveness(hipStream_t st, const int64_t* masks, const int64_t* loss_masks, int B, int S, uint8_t* row_live, int* tiles64, int* tiles32,
-                 int* tiles16, int* n_tiles, int* rlen) {
+                 int* tiles16, int* n_tiles, int* rlen, int* rows) {
   if (B < 1 || S < 1 || ((int64_t)B * S) % 64 != 0 || masks == nullptr) return RL_ERR_ARG;
-  hipLaunchKernelGGL(row_liveness_kernel, dim3(1), dim3(1024), 0, st, masks, loss_masks, B, S, row_live, tiles64, tiles32, tiles16, n_tiles, rlen);
+  hipLaunchKernelGGL(row_liveness_kernel, dim3(1), dim3(1024), 0, st, masks, loss_masks, B, S, row_live, tiles64, tiles32, tiles16, n_tiles, rlen, rows);
   return RL_LAUNCH_CHECK();
 }
 

@@ -194,7 +194,7 @@ def test_fused_dense_residual_layernorm_matches_the_two_launch_form(drop):
             return float(loss.item()), logits.float().clone(), taps, grads
         finally:
             lib.realise_set_engine(8, 0)
-            lib.realise_set_engine(10, 1)
+            lib.realise_set_engine(10, 2)
 
     lf, logf, tf, gf = run(1)
     lu, logu, tu, gu = run(0)
@@ -368,7 +368,7 @@ def test_live_row_training_step_equals_the_dense_step(B, S, layers):
                             {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
             return out
         finally:
-            lib.realise_set_engine(10, 1)
+            lib.realise_set_engine(10, 2)
 
     dense, lived = step(0), step(1)
     for (l0, z0, g0), (l1, z1, g1) in zip(dense, lived):
@@ -418,7 +418,7 @@ def test_live_row_training_trajectory_follows_the_dense_one():
             torch.cuda.synchronize()
             return losses, float(el.item()), elog.float().clone()
         finally:
-            lib.realise_set_engine(10, 1)
+            lib.realise_set_engine(10, 2)
 
     ll, el, zl = run(1)
     ld, ed, zd = run(0)

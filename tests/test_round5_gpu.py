@@ -472,9 +472,9 @@ def test_long_sequence_bf16_step_and_live_rows(golden_dir):
             torch.cuda.synchronize()
             return m, float(loss.item()), grads_of(m)
         finally:
-            lib.realise_set_engine(10, 1)
+            lib.realise_set_engine(10, 2)
 
-    m1, l1, g1 = step(1)
+    m1, l1, g1 = step(2)
     m0, l0, g0 = step(0)
     assert abs(l1 - float(g["loss"])) < 5e-2
     rows = [r for r in r3.grad_report(m1, g) if r[4] > 1e-9 and int(g["grad/" + r[0] + "/n"]) >= 64 and not r3.is_softmax_shift(r[0]) and not r3.is_resnet_conv_path(r[0])]
