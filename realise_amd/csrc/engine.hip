@@ -1255,6 +1255,27 @@ template <typename T> struct Engine : EngineBase {
     const DropParams dfin = site(5000, cfg.hidden_dropout);
     const T* cls_in = top;
     if (dfin.thresh) { RL_TRY(dropout_apply<T>(st, top, wp<T>(pl.out_d), Tk, H, dfin)); cls_in = wp<T>(pl.out_d); }
+    if (b.logits_out == nullptr) {
+      // K13 (round 6; models.py:859-869 as the training loop consumes it, run.py:191 takes the loss alone): no [B*S, V] logits.  The
+      // classifier runs over the rows that enter the loss only - listed first, the classifier input gathered to match - and writes
+      // their logits rows, compacted and at the gradient's row pitch, INTO the gradient buffer; the cross-entropy kernel reads each
+      // row once into registers and stores the row's gradient over it.  Same fp32 accumulators, same bf16 rounding, same row kernel
+      // as the two-buffer form: loss and every gradient bit-identical (tests/test_round6_gpu.py).
+      if (sizeof(T) != 2 || !b.tgt_idx || !b.loss_masks || !b.loss_out || !b.want_dlogits || !g_cls_compact || Tk > 65536) return RL_ERR_ARG;
+      cls_compact = true;
+      CeCompact cc; cc.act_idx = wp<int>(pl.cls_act); cc.inv = wp<int>(pl.cls_inv); cc.n_act = wp<int>(pl.cls_nact);
+      cc.phase = 1;
+      RL_TRY(ce_loss<T>(st, nullptr, Vp, b.tgt_idx, b.loss_masks, Tk, V, b.loss_out, wp<float>(pl.count), wp<T>(pl.dlogits),
+                        wp<float>(pl.loss_internal), Vp, cc));
+      RL_TRY(gather_rows<T>(st, cls_in, wp<int>(pl.cls_act), wp<int>(pl.cls_nact), Tk, H, wp<T>(pl.cls_xc)));
+      EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = wp<T>(pl.dlogits); ep.ldo = Vp; ep.bias = pp(L.cls_b);
+      RL_TRY(gemm_nt<T>(st, wp<T>(pl.cls_xc), H, sp<T>(sh_cls_w), H, Tk, V, H, ep, wp<int>(pl.cls_nact)));
+      cc.phase = 2; cc.logits_compact = 1;
+      RL_TRY(ce_loss<T>(st, wp<T>(pl.dlogits), Vp, b.tgt_idx, b.loss_masks, Tk, V, b.loss_out, wp<float>(pl.count), wp<T>(pl.dlogits),
+                        wp<float>(pl.loss_internal), Vp, cc));
+      have_fwd = b.training != 0;
+      return RL_OK;
+    }
     {  // tied vocabulary classifier (models.py:859)
       EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = (T*)b.logits_out; ep.ldo = V; ep.bias = pp(L.cls_b);
       RL_TRY(gemm_nt<T>(st, cls_in, H, sp<T>(sh_cls_w), H, Tk, V, H, ep));

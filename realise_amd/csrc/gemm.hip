@@ -439,6 +439,14 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
     if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 44) || g_nt_variant >= 50)) {
       if (nt8_supported(M, N, K, ep, la.ld, ldb)) return gemm_nt8(st, la.base, la.ld, B, ldb, M, N, K, ep, (g_nt_variant >= 10 && g_nt_variant < 50) ? g_nt_variant - 10 : 0);
     }
+    // a device-side row bound on a wide output (round 6: the training classifier over the loss rows): the persistent kernel, which
+    // shrinks its tile walk to the live tile rows on the device
+    if (la.rows_dev != nullptr && ep.m_dev == nullptr && g_nt_probe == 0 && g_nt_variant == 0 && M >= 1024 &&
+        (long)((M + 255) / 256) * ((N + 191) / 192) >= 384 && nt8p_supported(M, N, K, ep, la.ld, ldb)) {
+      EpiParams<T> e2 = ep;
+      e2.m_dev = la.rows_dev;
+      return gemm_nt8p(st, la.base, la.ld, B, ldb, M, N, K, e2);
+    }
     // a device-side row bound (the GRU steps of a device-built batch: nominal M = B*S, the alive count lives on the device): the
     // 8-wave kernel with exact row masking - tiles beyond the count leave at once, rows beyond it inside the last live tile read zeros
     if (la.rows_dev != nullptr && ep.m_dev == nullptr && g_nt_probe == 0 && g_nt_variant == 0 && M >= 1024 && N >= 256 && (K % 64) == 0 &&

@@ -43,8 +43,23 @@ __device__ __forceinline__ void asm_after_wait(u32x4& v) {      // pins the uses
 // The body lives in a __device__ function: the host pass of hipcc 7.2 parses __global__ bodies and silently drops the stub of a
 // kernel template whose body it cannot digest (device-only builtins inside lambdas); a __device__ function is never looked into.
 template <typename C, int EPI>
-__device__ __forceinline__ void nt8p_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int M, int N,
-                                          int K, int tiles_n, int ntiles, const EpiParams<bf16_t>& ep, int rows_per_xcd) {
+__device__ __forceinline__ void nt8p_body(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int M_, int N,
+                                          int K, int tiles_n, int ntiles_, const EpiParams<bf16_t>& ep, int rows_per_xcd_) {
+  // Round 6: an optional device-side row count (EpiParams::m_dev; the training classifier over the rows that enter the loss - their
+  // number lives on the device).  The launch is sized for the nominal M; every workgroup shrinks the problem to the live tile rows
+  // before it derives its tile walk: rows at or beyond the count are neither read (they lie outside the A descriptor: zeros) nor
+  // stored (outside the output descriptor: dropped), tiles beyond it do not exist.
+  int M = M_, ntiles = ntiles_, rows_per_xcd = rows_per_xcd_;
+  if (ep.m_dev != nullptr) {
+    const int md = *ep.m_dev;
+    if (md <= 0) return;
+    if (md < M) {
+      M = md;
+      const int tml = (M + C::BM - 1) / C::BM;
+      ntiles = tml * tiles_n;
+      rows_per_xcd = (rows_per_xcd_ > 0 && (tml % 8) == 0) ? tml / 8 : 0;
+    }
+  }
   typedef MmaBF16 Mma;
   constexpr int NPW = C::NPW, NPH = C::NPH, NS = C::NS, LEAD = C::LEAD, SQ = C::SQ, HT = C::HT, MT = C::MT, NT = C::NT;
   static_assert(!C::HOLD_B && C::ISSUE_AT == 0 && C::FW == 8 && (NT % 2) == 0, "persistent kernel: hold-A schedule, fetches at the end of the memory segment");
@@ -348,6 +363,7 @@ static int launch_nt8p(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_
   const int grid = ntiles < max_wg ? ntiles : max_wg;
   const int rows_per_xcd = (g_nt8p_order == 1 && (tiles_m % 8) == 0 && (grid % 8) == 0 && grid >= 8) ? tiles_m / 8 : 0;
   ProfScope ps(st, PK_GEMM_NT, 2.0 * M * N * K);
+  if (ep.m_dev != nullptr) prof_set_exec(ep.m_dev, 2.0 * N * K, C::BM, M);
   RL_LAUNCH((gemm_nt8p_kernel<C, EPI>), dim3(grid), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, ep, rows_per_xcd);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }

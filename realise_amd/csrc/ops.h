@@ -109,7 +109,7 @@ template <typename T> int dropout_apply(hipStream_t st, const T* x, T* y, int ro
 // cc.act_idx != nullptr (needs row_loss): COMPACTED gradient rows - dlogits row j belongs to the j-th row that enters the loss
 // (cc.act_idx[j] = its token row, cc.inv[row] = j or -1, *cc.n_act = how many; all written here); rows outside the loss are neither
 // visited nor written.  The classifier's data / weight gradients then run over *n_act rows instead of all of them.
-struct CeCompact { int* act_idx = nullptr; int* inv = nullptr; int* n_act = nullptr; };
+struct CeCompact { int* act_idx = nullptr; int* inv = nullptr; int* n_act = nullptr; int phase = 0; int logits_compact = 0; };      // (phase / logits_compact: ce_loss)
 template <typename T>
 int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask, int rows, int V,
             float* loss_out, float* count_buf, T* dlogits, float* row_loss = nullptr, int64_t ld_dl = 0, const CeCompact& cc = CeCompact());

@@ -1325,13 +1325,13 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels, const int64_t* __restrict__ loss_mask,
           int V, float* loss_out, const float* __restrict__ count, T* __restrict__ dlogits, float* __restrict__ row_loss, int64_t ld_dl,
-          const int* __restrict__ act_idx, const int* __restrict__ n_act) {
+          const int* __restrict__ act_idx, const int* __restrict__ n_act, int logits_compact) {
   __shared__ float sm[4];
   // compacted form (act_idx != nullptr): workgroup j works on the j-th ACTIVE row and writes gradient row j; the rows outside the loss
   // are not visited at all (their loss terms were zeroed by active_rows_kernel, their gradient rows do not exist)
   if (act_idx != nullptr && (int)blockIdx.x >= *n_act) return;
   const int row = act_idx != nullptr ? act_idx[blockIdx.x] : (int)blockIdx.x;
-  const T* x = logits + (int64_t)row * ld;
+  const T* x = logits + (int64_t)(logits_compact ? (int)blockIdx.x : row) * ld;
   T* dx = dlogits ? dlogits + (int64_t)(act_idx != nullptr ? (int)blockIdx.x : row) * ld_dl : nullptr;
   // a padded gradient row (ld_dl > V: 128-byte aligned rows for the GEMMs that consume it) keeps exact zeros in its tail
   if (dx != nullptr)
@@ -1383,13 +1383,15 @@ ce_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ 
 // rows in flight, every walk comes from HBM (PMC round 3: 659 MB read per launch for 207 MB of active rows).
 template <int NCH>
 __global__ void __launch_bounds__(256)
-ce_row16_kernel(const bf16_t* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels, const int64_t* __restrict__ loss_mask,
-                int V, float* loss_out, const float* __restrict__ count, bf16_t* __restrict__ dlogits, float* __restrict__ row_loss, int64_t ld_dl,
-                const int* __restrict__ act_idx, const int* __restrict__ n_act) {
+ce_row16_kernel(const bf16_t* logits, int64_t ld, const int64_t* __restrict__ labels, const int64_t* __restrict__ loss_mask,
+                int V, float* loss_out, const float* __restrict__ count, bf16_t* dlogits, float* __restrict__ row_loss, int64_t ld_dl,
+                const int* __restrict__ act_idx, const int* __restrict__ n_act, int logits_compact) {
   __shared__ float sm[4];
   if (act_idx != nullptr && (int)blockIdx.x >= *n_act) return;
   const int row = act_idx != nullptr ? act_idx[blockIdx.x] : (int)blockIdx.x;
-  const bf16_t* x = logits + (int64_t)row * ld;
+  // logits_compact (round 6, K13): the logits exist for the loss rows only, row j of `logits` = the j-th active row - possibly the SAME
+  // buffer as dlogits: the row is read whole into registers before its gradient row is stored over it
+  const bf16_t* x = logits + (int64_t)(logits_compact ? (int)blockIdx.x : row) * ld;
   bf16_t* dx = dlogits ? dlogits + (int64_t)(act_idx != nullptr ? (int)blockIdx.x : row) * ld_dl : nullptr;
   if (dx != nullptr)
     for (int c = V + threadIdx.x * 4; c < ld_dl; c += 1024) store4<bf16_t>(dx + c, floatx4{0.f, 0.f, 0.f, 0.f});
@@ -1408,6 +1410,13 @@ ce_row16_kernel(const bf16_t* __restrict__ logits, int64_t ld, const int64_t* __
     const int k = threadIdx.x + 256 * i;
     r[i] = k < nch ? *(const uint4*)(x + 8 * k) : uint4{0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u};      // -inf pairs: exp() = 0
   }
+  // the label's logit is read here, with the row, and pinned behind its wait: in the in-place form (logits == dlogits) other waves
+  // store gradient chunks over the row as soon as they are past the two reductions below
+  const bool lab_ok0 = lab64 >= 0 && lab64 < V;
+  float x_lab = to_f<bf16_t>(x[lab_ok0 ? (int)lab64 : 0]);
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x_lab));
+#endif
   float mx = -3.0e38f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -1431,7 +1440,7 @@ ce_row16_kernel(const bf16_t* __restrict__ logits, int64_t ld, const int64_t* __
   const int lab = lab_ok ? (int)lab64 : 0;
   const float lse = mx + logf(s);
   if (threadIdx.x == 0) {
-    const float l = lab_ok ? (lse - to_f<bf16_t>(x[lab])) * inv_n : __builtin_nanf("");
+    const float l = lab_ok ? (lse - x_lab) * inv_n : __builtin_nanf("");
     if (row_loss != nullptr) row_loss[row] = l;
     else atomicAdd(loss_out, l);
   }
@@ -1451,14 +1460,14 @@ ce_row16_kernel(const bf16_t* __restrict__ logits, int64_t ld, const int64_t* __
   }
 }
 template <typename T>
-static bool ce_row16_launch(hipStream_t, const T*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, T*, float*, int64_t, const int*, const int*) { return false; }
+static bool ce_row16_launch(hipStream_t, const T*, int64_t, const int64_t*, const int64_t*, int, int, float*, float*, T*, float*, int64_t, const int*, const int*, int) { return false; }
 template <>
 bool ce_row16_launch<bf16_t>(hipStream_t st, const bf16_t* logits, int64_t ld, const int64_t* labels, const int64_t* loss_mask, int rows, int V,
-                             float* loss_out, float* count_buf, bf16_t* dlogits, float* row_loss, int64_t ld_dl, const int* act_idx, const int* n_act) {
+                             float* loss_out, float* count_buf, bf16_t* dlogits, float* row_loss, int64_t ld_dl, const int* act_idx, const int* n_act, int compact) {
   constexpr int NCH = 11;          // 256 threads x 11 chunks x 8 = 22528 >= 21128
   if (!g_ce_fast || (V & 7) || (ld & 7) || (ld_dl & 7) || V > 256 * 8 * NCH || ((uintptr_t)logits & 15) || ((uintptr_t)dlogits & 15)) return false;
   hipLaunchKernelGGL((ce_row16_kernel<NCH>), dim3(rows), dim3(256), 0, st, logits, ld, labels, loss_mask, V, loss_out, count_buf, dlogits, row_loss, ld_dl,
-                     act_idx, n_act);
+                     act_idx, n_act, compact);
   return true;
 }
 
@@ -1482,19 +1491,27 @@ int ce_loss(hipStream_t st, const T* logits, int64_t ld, const int64_t* labels, 
   if ((V & 3) || (ld & 3) || (ld_dl & 3) || ld_dl < V) return RL_ERR_ARG;
   if (cc.act_idx != nullptr) {       // compacted gradient rows (needs the per-row loss terms: the ordered fold is the only sum)
     if (row_loss == nullptr || cc.inv == nullptr || cc.n_act == nullptr || rows > 65536) return RL_ERR_ARG;
-    hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(1024), 0, st, loss_mask, labels, rows, cc.act_idx, cc.inv, cc.n_act, count_buf, row_loss);
-    if (!ce_row16_launch<T>(st, logits, ld, labels, loss_mask, rows, V, loss_out, count_buf, dlogits, row_loss, ld_dl, (const int*)cc.act_idx, (const int*)cc.n_act))
+    // phases: 1 = list the active rows, 2 = loss + gradient rows, 0 = both (cc.logits_compact needs the list before the logits exist:
+    // the caller runs phase 1, the classifier over the listed rows, then phase 2)
+    if (cc.phase != 2)
+      hipLaunchKernelGGL(active_rows_kernel, dim3(1), dim3(1024), 0, st, loss_mask, labels, rows, cc.act_idx, cc.inv, cc.n_act, count_buf, row_loss);
+    if (cc.phase == 1) return RL_LAUNCH_CHECK();
+    const bool fast = ce_row16_launch<T>(st, logits, ld, labels, loss_mask, rows, V, loss_out, count_buf, dlogits, row_loss, ld_dl, (const int*)cc.act_idx,
+                                         (const int*)cc.n_act, cc.logits_compact);
+    if (!fast) {
+      if (cc.logits_compact && (const void*)logits == (const void*)dlogits) return RL_ERR_ARG;      // (the generic kernel walks a row three times: not in place)
       hipLaunchKernelGGL((ce_kernel<T>), dim3(rows), dim3(256), 0, st, logits, ld, labels, loss_mask, V, loss_out, count_buf, dlogits, row_loss, ld_dl,
-                         (const int*)cc.act_idx, (const int*)cc.n_act);
+                         (const int*)cc.act_idx, (const int*)cc.n_act, cc.logits_compact);
+    }
     hipLaunchKernelGGL(ce_fold_kernel, dim3(1), dim3(256), 0, st, row_loss, rows, loss_out);
     return RL_LAUNCH_CHECK();
   }
   (void)hipMemsetAsync(loss_out, 0, sizeof(float), st);
   (void)hipMemsetAsync(count_buf, 0, sizeof(float), st);
   hipLaunchKernelGGL(count_active_kernel, dim3(64), dim3(256), 0, st, loss_mask, labels, rows, count_buf);
-  if (!ce_row16_launch<T>(st, logits, ld, labels, loss_mask, rows, V, loss_out, count_buf, dlogits, row_loss, ld_dl, nullptr, nullptr))
+  if (!ce_row16_launch<T>(st, logits, ld, labels, loss_mask, rows, V, loss_out, count_buf, dlogits, row_loss, ld_dl, nullptr, nullptr, 0))
     hipLaunchKernelGGL((ce_kernel<T>), dim3(rows), dim3(256), 0, st, logits, ld, labels, loss_mask, V, loss_out, count_buf, dlogits, row_loss, ld_dl,
-                       (const int*)nullptr, (const int*)nullptr);
+                       (const int*)nullptr, (const int*)nullptr, 0);
   if (row_loss != nullptr) hipLaunchKernelGGL(ce_fold_kernel, dim3(1), dim3(256), 0, st, row_loss, rows, loss_out);
   return RL_LAUNCH_CHECK();
 }

@@ -72,6 +72,8 @@ class RealiseModule(nn.Module):
         # run.py:262 / test.py:140 needs it - and the compute dtype in training mode, where the trainer only reads the loss
         # (run.py:191).  "fp32" / "bf16" force one dtype in both modes.
         self.logits_dtype = logits_dtype or os.environ.get("REALISE_LOGITS_DTYPE") or "auto"
+        # False: a training forward returns (loss, None) and never writes the [B, S, V] logits (K13; forward())
+        self.train_logits = True
         if self.logits_dtype not in ("auto", "bf16", "fp32"):
             raise ValueError("logits_dtype must be 'auto', 'bf16' or 'fp32'")
         if self.compute_dtype == "fp32" and self.logits_dtype == "bf16":
@@ -518,12 +520,23 @@ class RealiseModule(nn.Module):
         self._ensure_engine(B, S, cb.Tp)
         tdt = _DTYPES[self.compute_dtype][1]
         self._fwd_gen += 1
-        logits = torch.empty((B, S, self.vocab_size), dtype=tdt, device=self.device)
+        # K13 (round 6): a training forward whose caller reads the loss alone (`model.train_logits = False`, what realise_amd.trainer
+        # sets: run.py:191 takes outputs[0]) does not produce the [B, S, V] logits at all - the classifier runs over the loss rows
+        # straight into the gradient buffer and the tuple's second entry is None.  The default keeps the reference's tuple.
+        no_logits = (need_grad and not self.train_logits and self.compute_dtype == "bf16" and self.vocab_size % 8 == 0
+                     and self.vocab_size <= 22528 and B * S <= 65536)
         loss = torch.zeros((), dtype=torch.float32, device=self.device) if tgt is not None else None
-        cb.logits_out = logits.data_ptr()
+        if no_logits:
+            logits = None
+            cb.logits_out = None
+        else:
+            logits = torch.empty((B, S, self.vocab_size), dtype=tdt, device=self.device)
+            cb.logits_out = logits.data_ptr()
         cb.loss_out = loss.data_ptr() if loss is not None else None
         _capi.check(_capi.load().realise_engine_forward(self._engine, self._stream(), C.byref(cb)), "realise_engine_forward")
         self._last = keep
+        if no_logits:
+            return (_EngineLoss.apply(self._anchor, loss, self), None)
         want = self.logits_dtype if self.logits_dtype != "auto" else ("fp32" if not training else self.compute_dtype)
         if want != self.compute_dtype:                        # reference contract: fp32 logits (models.py:859) from the bf16 engine
             wide = torch.empty((B, S, self.vocab_size), dtype=torch.float32, device=self.device)

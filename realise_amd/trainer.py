@@ -102,6 +102,9 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
     # (an exception inside the loop left the module trusting the optimizer's copies).
     trusted_before = model.trust_fused_optimizer
     model.trust_fused_optimizer = True
+    # the loop reads outputs[0] alone (run.py:191): the training forwards skip the [B, S, V] logits (modeling.py: train_logits)
+    logits_before = getattr(model, "train_logits", True)
+    model.train_logits = False
     try:
         model.zero_grad()
         stop = False
@@ -146,6 +149,7 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
                 break
     finally:
         model.trust_fused_optimizer = trusted_before
+        model.train_logits = logits_before
         model.mark_parameters_updated(frozen=False)       # whatever runs next re-derives every operand copy
     if hasattr(model, "check_ids"):
         model.check_ids()                  # a bad id in the last batches must not go unreported

@@ -433,6 +433,70 @@ def test_glyph_lookup_fused_into_block1_loaders_matches_the_gathered_form():
     for dtype in ("bf16", "fp32"):
         (l0, a0, g0, e0, z0), (l1, a1, g1, e1, z1) = run(0, dtype), run(1, dtype)
         assert l0 == l1 and e0 == e1 and torch.equal(a0, a1) and torch.equal(z0, z1)
+        # gradients: bit-identical wherever the gathered form is itself bit-stable from run to run at this size (the small-shape
+        # column reductions of the BatchNorm backward add with fp32 atomics - DESIGN 3, "reproducibility exceptions"); a tensor that
+        # moves between two runs of the SAME form is held to its L2 distance instead
+        g0b = run(0, dtype)[2]
         for n in g0:
             if n.startswith("resnet."):
-                assert torch.equal(g0[n], g1[n]), n
+                if torch.equal(g0[n], g0b[n]):
+                    assert torch.equal(g0[n], g1[n]), n
+                else:
+                    ref = (g0[n].float() - g0b[n].float()).norm().item()
+                    d = (g0[n].float() - g1[n].float()).norm().item()
+                    assert d <= 4.0 * ref + 1e-6 * g0[n].float().norm().item(), (n, d, ref)
+
+
+# ---------------------------------------------------------------------------------------------- K13: no training logits
+def test_training_forward_without_logits_matches_the_two_buffer_form():
+    """K13 (`model.train_logits = False`, what trainer.train() and bench.py set: run.py:191 reads outputs[0] alone): the classifier runs
+    over the rows that enter the loss, writes their logits rows into the gradient buffer, and the cross-entropy kernel turns every row
+    into its gradient in place.  Same accumulators, same bf16 rounding, same row kernel as the form that writes [B, S, V] logits first:
+    the loss and every gradient are bit-identical, dropout on, over three batches of different lengths; the tuple's second entry is None.
+    The persistent classifier kernel takes the device-side row count here (gemm_nt8p m_dev): a full-vocabulary head is part of it."""
+    cfg = RealiseConfig(**SMALL)
+    sd = init_state_dict_numpy(cfg, seed=41)
+    batches = [cuda_batch(16, 128, 300 + k) for k in range(3)]
+
+    def run(train_logits):
+        m = build(cfg, sd, "bf16", train=True)
+        m.train_logits = train_logits
+        out = []
+        for b in batches:
+            m.zero_grad()
+            loss, logits = m(b)
+            assert (logits is None) == (not train_logits)
+            loss.backward()
+            torch.cuda.synchronize()
+            out.append((float(loss.item()), grads_of(m)))
+        return out
+
+    a, a2, b = run(True), run(True), run(False)
+    for (la, ga), (_, ga2), (lb, gb) in zip(a, a2, b):
+        assert np.isfinite(la) and la == lb
+        assert set(ga) == set(gb)
+        for n in ga:
+            # (the tied embedding / classifier gradient takes the embedding scatter's fp32 atomics: not bit-stable between two runs of
+            # the SAME form - such a tensor is held to the distance between those two runs instead)
+            if torch.equal(ga[n], ga2[n]):
+                assert torch.equal(ga[n], gb[n]), n
+            else:
+                ref = (ga[n].float() - ga2[n].float()).norm().item()
+                d = (ga[n].float() - gb[n].float()).norm().item()
+                assert d <= 4.0 * ref + 1e-6 * ga[n].float().norm().item(), (n, d, ref)
+
+
+def test_training_forward_without_logits_keeps_the_reference_tuple_where_it_cannot_apply():
+    """fp32 parity mode and evaluation keep the reference's (loss, logits) tuple whatever `train_logits` says."""
+    cfg = RealiseConfig(**SMALL)
+    sd = init_state_dict_numpy(cfg, seed=42)
+    b = cuda_batch(4, 64, 310)
+    m = build(cfg, sd, "fp32", train=True)
+    m.train_logits = False
+    loss, logits = m(b)
+    assert logits is not None and logits.shape == (4, 64, cfg.vocab_size)
+    m2 = build(cfg, sd, "bf16", train=False)
+    m2.train_logits = False
+    with torch.no_grad():
+        loss, logits = m2(b)
+    assert logits is not None and logits.dtype == torch.float32
