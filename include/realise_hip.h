@@ -250,6 +250,9 @@ typedef struct {
                                * for bit; the logits rows behind that position are finite and meaningless (the reference never reads them:
                                * src/run.py:200, :262-270).  Engine knob 10 = 0 (the setter is declared in include/realise_hip_debug.h) computes every row. */
   const int32_t* n_alive_dev; /* DEVICE array [Tp] written by realise_build_pho (used when n_alive == NULL) */
+  float* logits_f32_out;      /* nullable: [B*S, vocab] fp32 (device) - the logits widened to fp32, the dtype the reference returns them in
+                               * (src/models.py:859); bf16 engines write them from the classifier kernel's epilogue (the same bf16-rounded
+                               * values as logits_out), no pass over logits_out.  Needs logits_out. */
 } realise_batch;
 
 /* Device-side `build_batch` (src/models.py:797-804 with the per-character Pinyin2.convert of src/utils.py:58-99 folded into

@@ -1278,7 +1278,18 @@ template <typename T> struct Engine : EngineBase {
     }
     {  // tied vocabulary classifier (models.py:859)
       EpiParams<T> ep; ep.mode = EPI_STORE; ep.out = (T*)b.logits_out; ep.ldo = V; ep.bias = pp(L.cls_b);
-      RL_TRY(gemm_nt<T>(st, cls_in, H, sp<T>(sh_cls_w), H, Tk, V, H, ep));
+      // logits_f32_out (round 6): the fp32 logits the reference returns (models.py:859) written by the classifier's own epilogue next
+      // to the compute-dtype ones the loss reads - no cast pass over [B*S, V]; a shape the persistent kernel does not take is cast here
+      int rc = RL_ERR_ARG;
+      if (b.logits_f32_out != nullptr && sizeof(T) == 2) {
+        EpiParams<T> e2 = ep; e2.out_f32 = b.logits_f32_out; e2.ldo_f32 = V;
+        rc = gemm_nt<T>(st, cls_in, H, sp<T>(sh_cls_w), H, Tk, V, H, e2);
+        if (rc != RL_OK && rc != RL_ERR_ARG) return rc;
+      }
+      if (rc != RL_OK) {
+        RL_TRY(gemm_nt<T>(st, cls_in, H, sp<T>(sh_cls_w), H, Tk, V, H, ep));
+        if (b.logits_f32_out != nullptr) RL_TRY(cast_to_f32<T>(st, (const T*)b.logits_out, b.logits_f32_out, (int64_t)Tk * V));
+      }
     }
     if (b.tgt_idx != nullptr) {
       if (!b.loss_masks || !b.loss_out) return RL_ERR_ARG;

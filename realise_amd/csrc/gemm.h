@@ -60,6 +60,11 @@ template <typename T> struct EpiParams {
   // slice (N / xcd_gc rows of B) stays in its 4 MiB L2 while the A rows stream through, read by xcd_gc XCDs instead of the whole
   // weight panel being streamed through all eight (gemm_nt8_live picks it from the shape; realise_set_nt8p(3, v) overrides)
   int xcd_gc = 1;
+  // round 6: optional SECOND output of a plain store, the same values widened to fp32 ([M][ldo_f32] floats) - the evaluation logits the
+  // reference returns in fp32 (src/models.py:859) leave the classifier kernel itself instead of a cast pass over [B*S, V] (persistent
+  // 256 x 192 kernel only: gemm_nt8p; every other launch form refuses it)
+  float* out_f32 = nullptr;
+  int64_t ldo_f32 = 0;
   int bias_first = 0;           // set by the launcher (realise_set_nt8p key 4): alpha / bias go into the accumulators before the epilogue's LDS transposes
   // K4 (BertSelfOutput / BertOutput, modeling_bert.py:273-277, 339-343): EPI_DROP_RESID followed by the LayerNorm of the row in the SAME
   // launch (8-wave 128 x 192 kernel, M % 128 == 0, N % 192 == 0, N / 192 <= 8).  A row spans N / 192 column tiles = workgroups: each
@@ -435,6 +440,7 @@ bool nt8s_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t ld
 int gemm_nt8s(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
 void set_nt8p_wgs(int n);
 void set_nt8_epi_pre(int on);      // 1 (default): alpha / bias into the accumulators before the 8-wave kernels' epilogue transposes (one bias fetch per wave, no per-item waits)
+void set_nt8_live_big(int v);     // measurement knob (realise_set_nt8p key 5): wide row-list launches on 256 x 256 one-per-CU tiles
 void set_nt8_live_gc(int gc);      // live-row GEMMs: 0 (default) column groups of the XCD split from the shape, 1 / 2 / 4 / 8 forced
 void set_nt8p_order(int o);
 void set_nt8_single_round(int on);   // outputs of at most one 128 x 192 tile per CU: 1 the three-stage one-per-CU shape, 0 (default) the two-per-CU shape

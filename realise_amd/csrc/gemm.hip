@@ -436,6 +436,7 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
     if (la.rows_dev == nullptr && g_nt_probe == 0 && (g_nt_variant == 50 || ((g_nt_variant == 0 || (g_nt_variant == 53 && ep.mode != EPI_GELU_BWD)) && M >= 1024 && (long)((M + 255) / 256) * ((N + 191) / 192) >= 384)) &&
         nt8p_supported(M, N, K, ep, la.ld, ldb))
       return gemm_nt8p(st, la.base, la.ld, B, ldb, M, N, K, ep);
+    if (ep.out_f32 != nullptr) return RL_ERR_ARG;        // (the fp32 copy exists in the persistent kernel's epilogue only: the caller casts)
     if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 44) || g_nt_variant >= 50)) {
       if (nt8_supported(M, N, K, ep, la.ld, ldb)) return gemm_nt8(st, la.base, la.ld, B, ldb, M, N, K, ep, (g_nt_variant >= 10 && g_nt_variant < 50) ? g_nt_variant - 10 : 0);
     }
@@ -484,13 +485,14 @@ template <typename T>
 int gemm_nt(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep,
             const int* rows_dev) {
   if (lda % Geo<T>::VEC) return RL_ERR_ARG;
+  if (ep.out_f32 != nullptr && sizeof(T) != 2) return RL_ERR_ARG;
   DenseLoader<T> la{A, lda, M, K};
   la.rows_dev = rows_dev;
   return launch_nt<T, DenseLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }
 template <typename T>
 int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la_, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep) {
-  if (la_.C % Geo<T>::VEC) return RL_ERR_ARG;
+  if (la_.C % Geo<T>::VEC || ep.out_f32 != nullptr) return RL_ERR_ARG;
   ConvLoader<T> la = la_;
   la.finalize();
   if (la.K != K || !la.span_ok()) return RL_ERR_ARG;

@@ -940,6 +940,8 @@ static int g_nt8_bias_first = 1;        // alpha / bias into the accumulators be
 void set_nt8_epi_pre(int on) { g_nt8_bias_first = on; }
 static int nt8_bias_first_on() { return g_nt8_bias_first; }
 static int g_nt8_live_gc = 0;
+static int g_nt8_live_big = 0;
+void set_nt8_live_big(int v) { g_nt8_live_big = v; }
 void set_nt8_live_gc(int gc) { g_nt8_live_gc = (gc == 1 || gc == 2 || gc == 4 || gc == 8) ? gc : 0; }
 int gemm_nt8_live(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep) {
   if (ep.live_list == nullptr || ep.live_count == nullptr || ep.m_dev != nullptr || ep.slab != nullptr || ep.rm_hw_shift >= 0 ||
@@ -956,6 +958,19 @@ int gemm_nt8_live(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B,
   if (g_nt8_live_gc) gc = g_nt8_live_gc;
   while (gc > 1 && (tiles_n % gc) != 0) gc >>= 1;
   e2.xcd_gc = gc;
+#if RL_PROBES
+  if (ep.live_unit == 1 && g_nt8_live_big && N >= (g_nt8_live_big == 2 ? 2304 : 3072) && (N % 256) == 0) {
+    // (round 6 measurement knob, probe build only, realise_set_nt8p(5, v): the wide outputs of a row-list launch on 256 x 256 one-per-CU
+    // tiles - at the bench's ~5.3 k live rows FFN-up is 21 x 12 = 252 tiles, ONE round of the chip, where 128 x 192 tiles make 672 =
+    // 1.3 rounds.  Measured: bit-identical, family 6.27 -> 6.70 ms/step, step 15.0 -> 15.3 ms: the one-per-CU tile exposes
+    // its prologue and epilogue and keeps the other streams' kernels off the CU)
+    int g2 = gc;
+    const int tn2 = N / 256;
+    while (g2 > 1 && (tn2 % g2) != 0) g2 >>= 1;
+    e2.xcd_gc = g2;
+    return launch_nt8_cfg<Cfg256x256, false, 4>(st, A, lda, B, ldb, M, N, K, e2);
+  }
+#endif
   if (ep.live_unit == 1) return launch_nt8_cfg<Cfg128x192q, false, 4>(st, A, lda, B, ldb, M, N, K, e2);      // list of rows
   if (ep.live_unit != 16) return RL_ERR_ARG;
   return launch_nt8_cfg<Cfg128x192q, false, 3>(st, A, lda, B, ldb, M, N, K, e2);

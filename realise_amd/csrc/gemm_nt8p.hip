@@ -22,6 +22,7 @@
 namespace rl {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+constexpr int EPI_STORE_F32X = 8;      // template value only (not an EpiMode): EPI_STORE + EpiParams::out_f32
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 // (the host pass of hipcc parses kernel bodies too and silently drops a kernel stub whose body holds AMDGPU register constraints
@@ -63,7 +64,9 @@ __device__ __forceinline__ void nt8p_body(const bf16_t* __restrict__ A, int64_t 
   typedef MmaBF16 Mma;
   constexpr int NPW = C::NPW, NPH = C::NPH, NS = C::NS, LEAD = C::LEAD, SQ = C::SQ, HT = C::HT, MT = C::MT, NT = C::NT;
   static_assert(!C::HOLD_B && C::ISSUE_AT == 0 && C::FW == 8 && (NT % 2) == 0, "persistent kernel: hold-A schedule, fetches at the end of the memory segment");
-  constexpr int NSTORE = MT * (NT / 2) * (EPI == EPI_GELU ? 2 : 1);      // 16-byte store instructions of one tile's epilogue, per wave
+  // EPI_STORE_F32X (this file only): EPI_STORE + the fp32 copy of every stored value (EpiParams::out_f32), one 16-byte store per
+  // accumulator tile in the accumulator layout (a lane: 4 consecutive columns of one row)
+  constexpr int NSTORE = MT * (NT / 2) * (EPI == EPI_GELU ? 2 : 1) + (EPI == EPI_STORE_F32X ? MT * NT : 0);      // 16-byte store instructions of one tile's epilogue, per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,6 +128,8 @@ __device__ __forceinline__ void nt8p_body(const bf16_t* __restrict__ A, int64_t 
     i32x4 r = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
     return r;
   };
+  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == EPI_STORE_F32X ? (void*)ep.out_f32 : (void*)ep.out), 0,
+                                                                       EPI == EPI_STORE_F32X ? (int)(uint32_t)(((int64_t)(M - 1) * ep.ldo_f32 + N) * 4) : 0, 0x00020000);
   const bool has_bias = EPI != EPI_GELU_BWD && ep.bias != nullptr;
   const i32x4 wBias = rsrc_words(has_bias ? (const void*)ep.bias : (const void*)A, has_bias ? (uint32_t)N * 4u : 0u);
   const i32x4 wX = rsrc_words(EPI == EPI_GELU_BWD ? (const void*)ep.aux : (const void*)A,
@@ -324,6 +329,17 @@ __device__ __forceinline__ void nt8p_body(const bf16_t* __restrict__ A, int64_t 
           }
         }
         emit(rsO, v0, v1);
+        if constexpr (EPI == EPI_STORE_F32X) {
+          // the fp32 copy carries the bf16-ROUNDED values (what a cast of the bf16 logits would hold): the two outputs agree bit for bit
+          const int rf = row_w + 16 * i, cf = col_f + 32 * jp;
+          auto rnd = [](floatx4 a) { floatx4 o; const uint32_t p0 = pack2bf(a[0], a[1]), p1 = pack2bf(a[2], a[3]);
+                                     o[0] = __uint_as_float(p0 << 16); o[1] = __uint_as_float(p0 & 0xffff0000u);
+                                     o[2] = __uint_as_float(p1 << 16); o[3] = __uint_as_float(p1 & 0xffff0000u); return o; };
+          const uint32_t of0 = (rf < M && cf < N) ? (uint32_t)(((int64_t)rf * ep.ldo_f32 + cf) * 4) : 0xFFFFFF00u;
+          const uint32_t of1 = (rf < M && cf + 16 < N) ? (uint32_t)(((int64_t)rf * ep.ldo_f32 + cf + 16) * 4) : 0xFFFFFF00u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rnd(v0)), rsF, of0, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rnd(v1)), rsF, of1, 0, 0);
+        }
       }
     }
     if (!more) break;
@@ -343,6 +359,8 @@ gemm_nt8p_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 typedef Nt8Cfg<256, 192, 4, 2, false, 2, 2, 4> PCfg256x192;
 
 bool nt8p_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb) {
+  if (ep.out_f32 != nullptr && (ep.mode != EPI_STORE || ep.accumulate || (N % 4) != 0 || (ep.ldo_f32 % 4) != 0 || ep.ldo_f32 < N ||
+                                (int64_t)M * ep.ldo_f32 * 4 >= 0xFFFFFF00ll)) return false;
   const bool mode_ok = (ep.mode == EPI_STORE && !ep.accumulate) || (ep.mode == EPI_GELU && ep.out2 != nullptr) ||
                        (ep.mode == EPI_GELU_BWD && !ep.accumulate && ep.aux != nullptr);
   return mode_ok && ep.alpha == 1.0f && ep.rm_hw_shift < 0 && (K % 64) == 0 && K >= 128 && (N % 8) == 0 && (ep.ldo % 8) == 0 &&
@@ -374,7 +392,9 @@ void set_nt8p_wgs(int n) { g_nt8p_wgs = n > 0 ? n : 256; }
 int gemm_nt8p(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep) {
   if (!nt8p_supported(M, N, K, ep, lda, ldb)) return RL_ERR_ARG;
   switch (ep.mode) {
-    case EPI_STORE: return launch_nt8p<PCfg256x192, EPI_STORE>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
+    case EPI_STORE:
+      if (ep.out_f32 != nullptr) return launch_nt8p<PCfg256x192, EPI_STORE_F32X>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
+      return launch_nt8p<PCfg256x192, EPI_STORE>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
     case EPI_GELU: return launch_nt8p<PCfg256x192, EPI_GELU>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
     case EPI_GELU_BWD: return launch_nt8p<PCfg256x192, EPI_GELU_BWD>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
     default: return RL_ERR_ARG;

@@ -533,15 +533,18 @@ class RealiseModule(nn.Module):
             logits = torch.empty((B, S, self.vocab_size), dtype=tdt, device=self.device)
             cb.logits_out = logits.data_ptr()
         cb.loss_out = loss.data_ptr() if loss is not None else None
+        # reference contract: fp32 logits (models.py:859) from the bf16 engine - written by the classifier kernel's own epilogue next to
+        # the bf16 ones the loss reads (realise_batch.logits_f32_out, round 6: no cast pass over [B, S, V])
+        want = self.logits_dtype if self.logits_dtype != "auto" else ("fp32" if not training else self.compute_dtype)
+        wide = None
+        if not no_logits and want != self.compute_dtype:
+            wide = torch.empty((B, S, self.vocab_size), dtype=torch.float32, device=self.device)
+            cb.logits_f32_out = wide.data_ptr()
         _capi.check(_capi.load().realise_engine_forward(self._engine, self._stream(), C.byref(cb)), "realise_engine_forward")
         self._last = keep
         if no_logits:
             return (_EngineLoss.apply(self._anchor, loss, self), None)
-        want = self.logits_dtype if self.logits_dtype != "auto" else ("fp32" if not training else self.compute_dtype)
-        if want != self.compute_dtype:                        # reference contract: fp32 logits (models.py:859) from the bf16 engine
-            wide = torch.empty((B, S, self.vocab_size), dtype=torch.float32, device=self.device)
-            _capi.check(_capi.load().realise_cast_to_f32(self._stream(), _DTYPES[self.compute_dtype][0], logits.data_ptr(),
-                                                          wide.data_ptr(), logits.numel()), "realise_cast_to_f32")
+        if wide is not None:
             logits = wide
         if tgt is None:
             return (logits,)

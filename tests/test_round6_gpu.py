@@ -478,12 +478,13 @@ def test_training_forward_without_logits_matches_the_two_buffer_form():
         for n in ga:
             # (the tied embedding / classifier gradient takes the embedding scatter's fp32 atomics: not bit-stable between two runs of
             # the SAME form - such a tensor is held to the distance between those two runs instead)
-            if torch.equal(ga[n], ga2[n]):
+            atomics = "embeddings" in n or n == "classifier.weight"      # (embed_bwd adds with fp32 atomics: equal only by chance)
+            if not atomics and torch.equal(ga[n], ga2[n]):
                 assert torch.equal(ga[n], gb[n]), n
             else:
                 ref = (ga[n].float() - ga2[n].float()).norm().item()
                 d = (ga[n].float() - gb[n].float()).norm().item()
-                assert d <= 4.0 * ref + 1e-6 * ga[n].float().norm().item(), (n, d, ref)
+                assert d <= 4.0 * ref + 1e-5 * ga[n].float().norm().item(), (n, d, ref)
 
 
 def test_training_forward_without_logits_keeps_the_reference_tuple_where_it_cannot_apply():
@@ -500,3 +501,24 @@ def test_training_forward_without_logits_keeps_the_reference_tuple_where_it_cann
     with torch.no_grad():
         loss, logits = m2(b)
     assert logits is not None and logits.dtype == torch.float32
+
+
+# ---------------------------------------------------------------------------------------------- fp32 logits from the classifier's epilogue
+@pytest.mark.parametrize("B,S", [(16, 128), (4, 64)])
+def test_eval_fp32_logits_come_from_the_classifier_epilogue_bit_for_bit(B, S):
+    """The reference returns fp32 logits (src/models.py:859).  A bf16 engine used to cast its bf16 logits in a pass of its own; now the
+    persistent classifier kernel stores the fp32 copy itself (realise_batch.logits_f32_out; B*S = 2048 rows takes that kernel, 256 rows the
+    cast fallback inside the engine).  Either way the fp32 tensor holds exactly the bf16 logits widened, and the loss is the same."""
+    cfg = RealiseConfig(**SMALL)
+    sd = init_state_dict_numpy(cfg, seed=51)
+    b = cuda_batch(B, S, 400 + B)
+    m = build(cfg, sd, "bf16", train=False)
+    with torch.no_grad():
+        loss_w, wide = m(b)
+    m16 = build(cfg, sd, "bf16", train=False, logits_dtype="bf16")
+    with torch.no_grad():
+        loss_n, narrow = m16(b)
+    torch.cuda.synchronize()
+    assert wide.dtype == torch.float32 and narrow.dtype == torch.bfloat16
+    assert float(loss_w.item()) == float(loss_n.item())
+    assert torch.equal(wide, narrow.float())
