@@ -39,7 +39,10 @@ void realise_set_nt_variant(int v);
  * stream-K cuts sums its K range in two or three chains); key 12 = the least K-tiles per workgroup of a launch that select the stream-K
  * kernel under key 11 (default 10; 0: every shape it supports; keys 11 / 12 act in the probe build only - round 6); key 13 = K7, the
  * glyph lookup fused into the loaders of block 1's forward convolutions (1, default: no gathered image batch in the forward; a
- * training step gathers it at the head of the backward for the two weight-gradient reductions) or gather_images + dense loaders (0) */
+ * training step gathers it at the head of the backward for the two weight-gradient reductions) or gather_images + dense loaders (0);
+ * key 14 = K9 in evaluation mode: BatchNorm on its running statistics applied in the glyph convolutions' epilogues (1, default: per
+ * block three launches, shortcut first, its normalised output added in the second convolution's epilogue) or as separate scale / shift
+ * and apply kernels over the raw convolution outputs (0, the round-5 form) */
 void realise_set_engine(int key, int value);
 /* realise_gemm_tn_grouped over a list of live reduction blocks, as the engine's backward calls it: live[k] (device, ascending) = index
  * of the k-th block of `list_rows` rows that holds anything but exact zeros in the A operands, *n_live (device) = how many; the other

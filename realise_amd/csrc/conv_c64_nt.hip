@@ -27,7 +27,8 @@ constexpr uint32_t CN_RECORDS = 0xFFFFFE00u;
 template <int FLIP>
 __global__ void __launch_bounds__(512, 1)
 conv_c64_nt_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt, bf16_t* __restrict__ out, int rows_max,
-                   const int* __restrict__ rows_dev) {
+                   const int* __restrict__ rows_dev, const float* __restrict__ col_scale, const float* __restrict__ col_shift,
+                   const bf16_t* __restrict__ aux, int relu) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Wl = smem;
   char* img0 = smem + CN_W_BYTES;
@@ -65,6 +66,15 @@ conv_c64_nt_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt, 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(base + (wave * 4 + j) * 1024), 16, ib + foff[j], 0, 0, 0);
   };
 
+  // EPI_AFFINE (round 6: evaluation-mode BatchNorm folded into the convolution): out = [relu](acc * scale[c] + shift[c] (+ aux)); a
+  // lane owns channels j * 16 + 4 g .. + 3 of its pixels for the whole walk
+  floatx4 sc4[4], sh4[4];
+  const bool affine = col_scale != nullptr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc4[j] = affine ? *(const floatx4*)(col_scale + j * 16 + 4 * g) : floatx4{1.f, 1.f, 1.f, 1.f};
+    sh4[j] = affine ? *(const floatx4*)(col_shift + j * 16 + 4 * g) : floatx4{0.f, 0.f, 0.f, 0.f};
+  }
   int img = blockIdx.x, stage = 0;
   if (img < nimg) issue(img, 0);
   for (; img < nimg; img += gridDim.x, stage ^= 1) {
@@ -102,6 +112,22 @@ conv_c64_nt_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt, 
       }
     }
     bf16_t* o = out + ((int64_t)img * 256 + wave * 32) * 64;
+    if (affine) {
+      const bf16_t* ax = aux != nullptr ? aux + ((int64_t)img * 256 + wave * 32) * 64 : nullptr;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          floatx4 v = acc[i][j] * sc4[j] + sh4[j];
+          if (ax != nullptr) v += load4<bf16_t>(ax + (i * 16 + l15) * 64 + j * 16 + 4 * g);
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          store4<bf16_t>(o + (i * 16 + l15) * 64 + j * 16 + 4 * g, v);
+        }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -110,7 +136,8 @@ conv_c64_nt_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt, 
 }
 
 // out [rows][64] = conv (flip 0, Wt = [co][tap][ci]) or its input gradient (flip 1, Wt = [ci][tap][co]) over [rows][64] NHWC 16x16 maps
-int conv_c64_nt(hipStream_t st, const bf16_t* X, const bf16_t* Wt, bf16_t* out, int rows, const int* rows_dev, int flip) {
+int conv_c64_nt(hipStream_t st, const bf16_t* X, const bf16_t* Wt, bf16_t* out, int rows, const int* rows_dev, int flip,
+                const float* col_scale, const float* col_shift, const bf16_t* aux, int relu) {
   if (rows <= 0) return RL_OK;
   if ((rows % 256) || (int64_t)rows * 128 >= (int64_t)CN_RECORDS) return RL_ERR_ARG;
   int grid = rows / 256;
@@ -122,8 +149,9 @@ int conv_c64_nt(hipStream_t st, const bf16_t* X, const bf16_t* Wt, bf16_t* out, 
     attr = true;
   }
   ProfScope ps(st, PK_CONV_NT, 2.0 * rows * 64 * 576);
-  if (flip) RL_LAUNCH(conv_c64_nt_kernel<1>, dim3(grid), dim3(512), CN_LDS, st, X, Wt, out, rows, rows_dev);
-  else RL_LAUNCH(conv_c64_nt_kernel<0>, dim3(grid), dim3(512), CN_LDS, st, X, Wt, out, rows, rows_dev);
+  if (col_scale != nullptr && col_shift == nullptr) return RL_ERR_ARG;
+  if (flip) RL_LAUNCH(conv_c64_nt_kernel<1>, dim3(grid), dim3(512), CN_LDS, st, X, Wt, out, rows, rows_dev, col_scale, col_shift, aux, relu);
+  else RL_LAUNCH(conv_c64_nt_kernel<0>, dim3(grid), dim3(512), CN_LDS, st, X, Wt, out, rows, rows_dev, col_scale, col_shift, aux, relu);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
 

@@ -15,6 +15,7 @@ void set_cls_compact(int on);      // classifier backward over the loss rows onl
 void set_ln_fuse(int on);          // dense + dropout + residual + LayerNorm as one launch (default 0: see engine.hip)
 void set_gru_fuse(int on);         // GRU time step as one launch: recurrent GEMM + gate math (default 1)
 void set_glyph_fuse(int on);       // K7: glyph lookup fused into block 1's forward conv loaders (default 1)
+void set_bn_fold(int on);          // K9 (evaluation): BatchNorm on running statistics applied in the convolutions' epilogues (default 1)
 void set_streamk(int v);           // 1: layer GEMMs on the stream-K 256 x 192 kernel (gemm_nt8s.hip; measured slower: default 0)
 void set_streamk_min(int n);       // the least K-tiles per workgroup of a launch that select it (default 10)
 void set_live_rows(int on);        // bf16 training steps: layer GEMMs / attention forward over the live 16-row blocks only (default 1)

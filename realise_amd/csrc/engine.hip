@@ -105,6 +105,9 @@ void set_streamk_min(int n) { g_streamk_min = n > 0 ? n : 0; }
 // gathered at the head of the backward, off the forward's path.  0 = gather_images in the forward, dense loaders (round 2-5 form).
 static int g_glyph_fuse = 1;
 void set_glyph_fuse(int on) { g_glyph_fuse = on; }
+// K9, evaluation mode (realise_set_engine key 14): BatchNorm on running statistics applied in the convolutions' epilogues (resnet_forward)
+static int g_bn_fold = 1;
+void set_bn_fold(int on) { g_bn_fold = on; }
 static int g_stream_pri[3] = {0, 0, 0};
 void set_stream_priority(int which, int pri) { if (which >= 0 && which < 3) g_stream_pri[which] = pri < 0 ? -1 : (pri > 0 ? 1 : 0); }
 static hipError_t create_stream(hipStream_t* s, int which) {
@@ -951,6 +954,27 @@ template <typename T> struct Engine : EngineBase {
       BlockAct& a = pl.blk[k];
       const int Co = o.cout, Cin = s.cin_pad, Pn = a.Pout;
       const RowBound rb = rbound(k);
+      if (!last.training && g_bn_fold) {
+        // K9, evaluation (round 6; char_cnn.py:15-32 with BatchNorm2d on its running statistics = a per-channel affine map): the three
+        // convolutions apply their BatchNorm in the epilogue - shortcut first (its normalised output is the second convolution's `aux`),
+        // ReLU where the reference has one.  Three launches + three 1-workgroup scale / shift kernels per block, no pass over a raw
+        // convolution output (was: 3 convolutions + 3 finalize + 2 apply launches, 5 extra passes over [Pn, Co]).
+        RL_TRY(bn_finalize_eval(st, Co, pp(o.bns.g), pp(o.bns.b), 1e-5f, BF + o.bns.rmean, BF + o.bns.rvar, wp<float>(a.bns.scale), wp<float>(a.bns.shift)));
+        RL_TRY(bn_finalize_eval(st, Co, pp(o.bn1.g), pp(o.bn1.b), 1e-5f, BF + o.bn1.rmean, BF + o.bn1.rvar, wp<float>(a.bn1.scale), wp<float>(a.bn1.shift)));
+        RL_TRY(bn_finalize_eval(st, Co, pp(o.bn2.g), pp(o.bn2.b), 1e-5f, BF + o.bn2.rmean, BF + o.bn2.rvar, wp<float>(a.bn2.scale), wp<float>(a.bn2.shift)));
+        EpiParams<T> ea; ea.mode = EPI_AFFINE; ea.ldo = Co;
+        ea.out = wp<T>(a.cs); ea.col_scale = wp<float>(a.bns.scale); ea.bias = wp<float>(a.bns.shift); ea.relu = 0;
+        RL_TRY(gemm_nt_conv<T>(st, geom(x, index, Pn, a.Hout, a.Hin, Cin, 1, 2, 0, 0, rb.rows_dev), sp<T>(s.wsf), Cin, Pn, Co, Cin, ea));
+        ea.out = wp<T>(a.h1); ea.col_scale = wp<float>(a.bn1.scale); ea.bias = wp<float>(a.bn1.shift); ea.relu = 1;
+        RL_TRY(gemm_nt_conv<T>(st, geom(x, index, Pn, a.Hout, a.Hin, Cin, 3, 2, 1, 0, rb.rows_dev), sp<T>(s.w1f), 9 * Cin, Pn, Co, 9 * Cin, ea));
+        ea.out = wp<T>(a.out); ea.col_scale = wp<float>(a.bn2.scale); ea.bias = wp<float>(a.bn2.shift); ea.relu = 1;
+        ea.aux = wp<T>(a.cs); ea.ldaux = Co;
+        if (a.Hout == 1) RL_TRY(gemm_nt<T>(st, wp<T>(a.h1), Co, sp<T>(s.w2f) + 4 * Co, 9 * Co, Pn, Co, Co, ea, rb.rows_dev));
+        else RL_TRY(gemm_nt_conv<T>(st, geom(wp<T>(a.h1), nullptr, Pn, a.Hout, a.Hout, Co, 3, 1, 1, 0, rb.rows_dev), sp<T>(s.w2f), 9 * Co, Pn, Co, 9 * Co, ea));
+        x = wp<T>(a.out);
+        index = nullptr;
+        continue;
+      }
       EpiParams<T> ep; ep.mode = EPI_STORE; ep.ldo = Co;
       // residual_function.0: 3x3 stride 2 pad 1 (char_cnn.py:16)
       ep.out = wp<T>(a.c1);

@@ -10,6 +10,7 @@ enum EpiMode {
   EPI_GELU = 1,        // out2 = pre = acc+bias ; out = gelu(pre)                (K5)
   EPI_DROP_RESID = 2,  // out = dropout(acc+bias) + aux                            (K4 minus LN)
   EPI_GELU_BWD = 4,    // out = acc * gelu'(aux)                                   (K14)
+  EPI_AFFINE = 8,      // out = [relu](acc * col_scale[col] + bias[col] (+ aux))  (K9, evaluation: BatchNorm folded into the convolution)
 };
 
 template <typename T> struct EpiParams {
@@ -60,6 +61,12 @@ template <typename T> struct EpiParams {
   // slice (N / xcd_gc rows of B) stays in its 4 MiB L2 while the A rows stream through, read by xcd_gc XCDs instead of the whole
   // weight panel being streamed through all eight (gemm_nt8_live picks it from the shape; realise_set_nt8p(3, v) overrides)
   int xcd_gc = 1;
+  // EPI_AFFINE (round 6; src/char_cnn.py:15-32 in evaluation mode, where BatchNorm2d is the per-channel affine map scale = gamma /
+  // sqrt(running_var + eps), shift = beta - running_mean * scale): the convolution's epilogue applies it to the fp32 accumulators,
+  // adds the (already normalised) shortcut `aux` when given and clamps at zero when `relu` - no BatchNorm launch, no pass over the raw
+  // convolution output.  col_scale is valid with EPI_AFFINE only; `bias` is the shift.  4-wave kernels and conv_c64_nt.
+  const float* col_scale = nullptr;
+  int relu = 0;
   // round 6: optional SECOND output of a plain store, the same values widened to fp32 ([M][ldo_f32] floats) - the evaluation logits the
   // reference returns in fp32 (src/models.py:859) leave the classifier kernel itself instead of a cast pass over [B*S, V] (persistent
   // 256 x 192 kernel only: gemm_nt8p; every other launch form refuses it)
@@ -459,7 +466,8 @@ int gemm_tn8(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int6
 void tn_fold_launch(hipStream_t st, const TnEpi& ep, int nsplit, int I, int J);     // out += alpha * sum of the split slabs, fixed order
 void set_tn_variant(int v);
 void set_conv_c64(int on);          // 1 (default): 64-channel 3x3 s1 conv forward / dgrad / wgrad on 16x16 maps via the LDS-resident kernels
-int conv_c64_nt(hipStream_t st, const bf16_t* X, const bf16_t* Wt, bf16_t* out, int rows, const int* rows_dev, int flip);         // conv_c64_nt.hip
+int conv_c64_nt(hipStream_t st, const bf16_t* X, const bf16_t* Wt, bf16_t* out, int rows, const int* rows_dev, int flip,
+                const float* col_scale = nullptr, const float* col_shift = nullptr, const bf16_t* aux = nullptr, int relu = 0);         // conv_c64_nt.hip
 int conv_wgrad_c64(hipStream_t st, const bf16_t* dY, const bf16_t* X, int rows, const int* rows_dev, const TnEpi& te);   // conv_wgrad_c64.hip
 void set_tn_group_ring(int on);     // grouped TN: 0 two full stages (default), 1 four stages of half-height K-tiles (measured 11 % slower)               // 0 production, 9 force the 4-wave TN kernel
 

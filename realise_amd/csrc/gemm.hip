@@ -486,13 +486,14 @@ int gemm_nt(hipStream_t st, const T* A, int64_t lda, const T* B, int64_t ldb, in
             const int* rows_dev) {
   if (lda % Geo<T>::VEC) return RL_ERR_ARG;
   if (ep.out_f32 != nullptr && sizeof(T) != 2) return RL_ERR_ARG;
+  if (ep.col_scale != nullptr && ep.mode != EPI_AFFINE) return RL_ERR_ARG;
   DenseLoader<T> la{A, lda, M, K};
   la.rows_dev = rows_dev;
   return launch_nt<T, DenseLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }
 template <typename T>
 int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la_, const T* B, int64_t ldb, int M, int N, int K, const EpiParams<T>& ep) {
-  if (la_.C % Geo<T>::VEC || ep.out_f32 != nullptr) return RL_ERR_ARG;
+  if (la_.C % Geo<T>::VEC || ep.out_f32 != nullptr || (ep.col_scale != nullptr && ep.mode != EPI_AFFINE)) return RL_ERR_ARG;
   ConvLoader<T> la = la_;
   la.finalize();
   if (la.K != K || !la.span_ok()) return RL_ERR_ARG;
@@ -501,9 +502,12 @@ int gemm_nt_conv(hipStream_t st, const ConvLoader<T>& la_, const T* B, int64_t l
     // 64 -> 64 channels, 3x3 / stride 1 / pad 1 on 16x16 maps (glyph ResNet block 1), plain store: the LDS-resident image + weights kernel
     if (g_conv_c64 && g_nt_probe == 0 && la.par < 0 && la.C == 64 && la.KH == 3 && la.KW == 3 && la.stride == 1 && la.pad == 1 && la.mode <= 1 &&
         la.Hr == 16 && la.Wr == 16 && la.Hs == 16 && la.Ws == 16 && la.img_index == nullptr && N == 64 && K == 576 && ldb == 576 &&
-        M == la.rows && (M % 256) == 0 && (int64_t)M * 128 < 0xFFFFFE00ll && ep.mode == EPI_STORE && ep.accumulate == 0 && ep.bias == nullptr &&
-        ep.out2 == nullptr && ep.alpha == 1.0f && ep.ldo == 64 && ep.rm_hw_shift < 0)
-      return conv_c64_nt(st, la.src, B, ep.out, M, la.rows_dev, la.mode);
+        M == la.rows && (M % 256) == 0 && (int64_t)M * 128 < 0xFFFFFE00ll && ep.out2 == nullptr && ep.alpha == 1.0f && ep.ldo == 64 && ep.rm_hw_shift < 0) {
+      if (ep.mode == EPI_STORE && ep.accumulate == 0 && ep.bias == nullptr && ep.col_scale == nullptr)
+        return conv_c64_nt(st, la.src, B, ep.out, M, la.rows_dev, la.mode);
+      if (ep.mode == EPI_AFFINE && ep.col_scale != nullptr && ep.bias != nullptr && (ep.aux == nullptr || ep.ldaux == 64))
+        return conv_c64_nt(st, la.src, B, ep.out, M, la.rows_dev, la.mode, ep.col_scale, ep.bias, ep.aux, ep.relu);
+    }
   }
   return launch_nt<T, ConvLoader<T>>(st, la, B, ldb, M, N, K, ep);
 }

@@ -30,12 +30,21 @@ __device__ __forceinline__ void epilogue4(const EpiParams<T>& ep, int M, int N, 
   if (row >= M || col >= N) return;
   row = epi_row<T>(ep, row);
   if (ep.alpha != 1.0f) v *= ep.alpha;
+  if (ep.col_scale != nullptr) v *= *(const floatx4*)(ep.col_scale + col);
   if (ep.bias != nullptr) v += *(const floatx4*)(ep.bias + col);
   switch (ep.mode) {
     case EPI_STORE: {
       T* o = ep.out + (int64_t)row * ep.ldo + col;
       if (ep.accumulate) v += load4<T>(o);
       store4<T>(o, v);
+    } break;
+    case EPI_AFFINE: {
+      if (ep.aux != nullptr) v += load4<T>(ep.aux + (int64_t)row * ep.ldaux + col);
+      if (ep.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      store4<T>(ep.out + (int64_t)row * ep.ldo + col, v);
     } break;
     case EPI_GELU: {
       if (ep.out2 != nullptr) store4<T>(ep.out2 + (int64_t)row * ep.ldo + col, v);
@@ -72,11 +81,20 @@ __device__ __forceinline__ void epilogue8(const EpiParams<T>& ep, int M, int N, 
   if (row >= M || col >= N) return;
   row = epi_row<T>(ep, row);
   if (ep.alpha != 1.0f) { a *= ep.alpha; b *= ep.alpha; }
+  if (ep.col_scale != nullptr) { a *= *(const floatx4*)(ep.col_scale + col); b *= *(const floatx4*)(ep.col_scale + col + 4); }
   if (ep.bias != nullptr) { a += *(const floatx4*)(ep.bias + col); b += *(const floatx4*)(ep.bias + col + 4); }
   T* o = ep.out + (int64_t)row * ep.ldo + col;
   switch (ep.mode) {
     case EPI_STORE: {
       if (ep.accumulate) { floatx4 pa, pb; load8<T>(o, pa, pb); a += pa; b += pb; }
+      store8<T>(o, a, b);
+    } break;
+    case EPI_AFFINE: {
+      if (ep.aux != nullptr) { floatx4 ra, rb; load8<T>(ep.aux + (int64_t)row * ep.ldaux + col, ra, rb); a += ra; b += rb; }
+      if (ep.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = fmaxf(a[j], 0.f); b[j] = fmaxf(b[j], 0.f); }
+      }
       store8<T>(o, a, b);
     } break;
     case EPI_GELU: {

@@ -906,6 +906,7 @@ typedef Nt8Cfg<256, 128, 4, 2, true, 2, 3, 4, 0, 4> Cfg256x128w;
 typedef Nt8Cfg<128, 192, 2, 4, true, 2, 3, 4, 0, 4> Cfg128x192w;
 
 bool nt8_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb) {
+  if (ep.mode == EPI_AFFINE || ep.col_scale != nullptr) return false;      // (the 4-wave kernels' epilogues carry it)
   return (K % 8) == 0 && K >= 64 && (N % 8) == 0 && (ep.ldo % 8) == 0 && (ep.aux == nullptr || (ep.ldaux % 8) == 0) &&
          (lda % 8) == 0 && (ldb % 8) == 0 && M >= 1 && N >= 8 &&
          (int64_t)M * lda * 2 < 0xFFFFFF00ll && (int64_t)N * ldb * 2 < 0xFFFFFF00ll;

@@ -359,6 +359,7 @@ gemm_nt8p_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __rest
 typedef Nt8Cfg<256, 192, 4, 2, false, 2, 2, 4> PCfg256x192;
 
 bool nt8p_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t lda, int64_t ldb) {
+  if (ep.col_scale != nullptr) return false;
   if (ep.out_f32 != nullptr && (ep.mode != EPI_STORE || ep.accumulate || (N % 4) != 0 || (ep.ldo_f32 % 4) != 0 || ep.ldo_f32 < N ||
                                 (int64_t)M * ep.ldo_f32 * 4 >= 0xFFFFFF00ll)) return false;
   const bool mode_ok = (ep.mode == EPI_STORE && !ep.accumulate) || (ep.mode == EPI_GELU && ep.out2 != nullptr) ||

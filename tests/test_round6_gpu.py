@@ -478,7 +478,8 @@ def test_training_forward_without_logits_matches_the_two_buffer_form():
         for n in ga:
             # (the tied embedding / classifier gradient takes the embedding scatter's fp32 atomics: not bit-stable between two runs of
             # the SAME form - such a tensor is held to the distance between those two runs instead)
-            atomics = "embeddings" in n or n == "classifier.weight"      # (embed_bwd adds with fp32 atomics: equal only by chance)
+            # (embed_bwd and the gate network's weight / bias reductions add with fp32 atomics: equal only by chance)
+            atomics = "embeddings" in n or n == "classifier.weight" or n.startswith("gate_net")
             if not atomics and torch.equal(ga[n], ga2[n]):
                 assert torch.equal(ga[n], gb[n]), n
             else:
@@ -522,3 +523,39 @@ def test_eval_fp32_logits_come_from_the_classifier_epilogue_bit_for_bit(B, S):
     assert wide.dtype == torch.float32 and narrow.dtype == torch.bfloat16
     assert float(loss_w.item()) == float(loss_n.item())
     assert torch.equal(wide, narrow.float())
+
+
+# ---------------------------------------------------------------------------------------------- K9 (evaluation): BatchNorm in the conv epilogues
+@pytest.mark.parametrize("dtype,B,S", [("bf16", 8, 64), ("fp32", 4, 64), ("bf16", 64, 128)])
+def test_eval_batchnorm_folded_into_the_conv_epilogues_matches_the_separate_kernels(dtype, B, S):
+    """realise_set_engine(14, 1), default: an evaluation forward applies every BatchNorm of the glyph ResNet (running statistics: a
+    per-channel affine map, src/char_cnn.py:15-32) in the epilogue of the convolution in front of it.  Against the separate scale / shift +
+    apply kernels (14, 0): fp32 agrees to rounding order (the affine map runs on the fp32 accumulator either way), bf16 differs by where
+    the bf16 rounding falls (the raw convolution output is no longer rounded before the map) - block outputs inside 2 bf16 ulps of their
+    scale, the same arg-max ids wherever the margin is not a rounding step, the same loss to 1e-3."""
+    lib = _capi.load()
+    cfg = RealiseConfig(**SMALL)
+    sd = init_state_dict_numpy(cfg, seed=61)
+    b = cuda_batch(B, S, 500 + B)
+
+    def run(on):
+        lib.realise_set_engine(14, on)
+        try:
+            m = build(cfg, sd, dtype, train=False)
+            with torch.no_grad():
+                loss, logits = m(b)
+            torch.cuda.synchronize()
+            return float(loss.item()), logits.float().clone(), [m.tap("resnet.block%d" % k).float().clone() for k in range(1, 6)], m.tap("res_h").float().clone()
+        finally:
+            lib.realise_set_engine(14, 1)
+
+    l0, z0, t0, r0 = run(0)
+    l1, z1, t1, r1 = run(1)
+    tol = 1e-5 if dtype == "fp32" else 2.0 ** -6
+    for k, (a, c) in enumerate(zip(t0, t1)):
+        assert torch.isfinite(c).all()
+        assert (a - c).abs().max().item() <= tol * max(1.0, a.abs().max().item()), ("block", k + 1)
+    # (res_h is the LayerNorm of block 5's output: values up to ~4, where a bf16 step is 0.03 - a few steps)
+    assert (r0 - r1).abs().max().item() <= (1e-4 if dtype == "fp32" else 0.15)
+    assert abs(l0 - l1) <= (1e-5 if dtype == "fp32" else 2e-3) * max(1.0, abs(l0))
+    assert (z0 - z1).abs().max().item() <= (1e-3 if dtype == "fp32" else 8e-2)
