@@ -103,11 +103,15 @@ def test_fused_optimizer_default_sees_a_raw_parameter_write():
 
     seen_default, stale_trusted, seen_marked = run(False, False), run(True, False), run(True, True)
     # (the arena-level AdamW of the untrusted run and the engine sweep of the trusted one round a step differently in the last bits)
+    # the two 'seen' runs differ by isolated single bf16 steps of a logit (2^-7 relative: 0.0625 at |logit| >= 8), the run that missed the
+    # write differs everywhere: the maximum is held to two such steps, the comparison is made on the mean
     seen = (seen_default - seen_marked).abs().max().item()
     missed = (seen_default - stale_trusted).abs().max().item()
-    print("zeroed FFN weight: default vs marked %.3e, default vs trusted-unmarked %.3e" % (seen, missed))
-    assert seen <= 2e-2
-    assert missed > 20 * max(seen, 1e-3), "the trusted run was expected to miss the raw write (that is what the flag trades)"
+    seen_mean = (seen_default - seen_marked).abs().mean().item()
+    missed_mean = (seen_default - stale_trusted).abs().mean().item()
+    print("zeroed FFN weight: default vs marked %.3e (mean %.3e), default vs trusted-unmarked %.3e (mean %.3e)" % (seen, seen_mean, missed, missed_mean))
+    assert seen <= max(2e-2, 2.0 ** -6 * seen_default.abs().max().item())
+    assert missed_mean > 20 * max(seen_mean, 1e-4), "the trusted run was expected to miss the raw write (that is what the flag trades)"
 
 
 @pytest.mark.parametrize("knob", ["wgrad_group", "tn_group_ring"])
