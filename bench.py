@@ -444,6 +444,9 @@ def main():
     opt = FusedAdamW(model, groups, lr=5e-5, eps=1e-8, max_grad_norm=1.0)         # train.sh / run.py:333-339
     opt.fused_operand_copies = bool(py_knobs.get("fused", 1))
     model.trust_fused_optimizer = True                      # this loop makes no parameter write besides opt.step() (trainer.train() does the same)
+    # (--knob opt:pipeline=1: the optimizer sweep pipelined under the next forward, realise_engine_adamw_pipelined - measured 0.03-0.2 ms
+    # SLOWER per step: its LDS-using tiles cannot share a CU with two 80 KB GEMM workgroups, so the sweep only runs in their gaps; off)
+    model.pipeline_optimizer = bool(py_knobs.get("pipeline", 0))
     model.train_logits = bool(py_knobs.get("train_logits", 0))   # the loop reads outputs[0] alone (run.py:191): K13, no [B, S, V] logits in training
     sched = get_linear_schedule_with_warmup(opt, 10000, 1000000)
 

@@ -308,6 +308,21 @@ int realise_adamw_grouped(void* stream, float* p, const float* g, float* m, floa
  * realise_engine_refresh_shadows_ex(e, stream, 1) instead of the full refresh. */
 int realise_engine_adamw(realise_engine* e, void* stream, float* m, float* v, const uint8_t* group_of_block64,
                          const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm);
+/* realise_engine_adamw, PIPELINED across the step boundary (round 6; run.py:207-211 followed by the next iteration's run.py:191).  The
+ * sweep streams 32 bytes per parameter and nothing overlaps it while it sits between the backward and the next forward on `stream`.
+ * This form orders the engine's side stream behind `stream` (gradients and grad_norm_sq are final there) and runs the sweep on it in the
+ * order the next forward consumes the parameters, an event behind every piece: [everything outside the Linear weights, the tied
+ * word table / classifier, BERT layers 0-1] [layers 2-3] [pinyin + output stacks, GRU] [the remaining BERT layers two by two].
+ * realise_engine_forward and realise_engine_refresh_shadows_ex make their streams wait for a piece right in front of its first reader
+ * and for all of it before they return, so the caller's stream is held for the first piece only (~0.3 of the ~1.1 ms at the full model
+ * size).  Same kernels and per-element arithmetic as realise_engine_adamw: the same bits.  CONTRACT: between this call and the next
+ * realise_engine_forward / realise_engine_refresh_shadows_ex(e, s, 0) / realise_engine_sync_optimizer nothing else may read or write
+ * the parameter, gradient or moment arenas on any stream.  realise_set_engine(15, 0) turns it into realise_engine_adamw. */
+int realise_engine_adamw_pipelined(realise_engine* e, void* stream, float* m, float* v, const uint8_t* group_of_block64,
+                                   const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm);
+/* order `stream` behind every piece of a pending pipelined sweep (no-op without one): before a checkpoint, a state_dict, any access to
+ * the arenas from outside the engine */
+int realise_engine_sync_optimizer(realise_engine* e, void* stream);
 int realise_fill_f32(void* stream, float* p, float value, int64_t n);
 /* widen a compute-dtype tensor to fp32 (the reference returns fp32 logits, src/models.py:859); 16-byte aligned pointers */
 int realise_cast_to_f32(void* stream, int dtype, const void* src, float* dst, int64_t n);

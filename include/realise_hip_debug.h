@@ -42,7 +42,8 @@ void realise_set_nt_variant(int v);
  * training step gathers it at the head of the backward for the two weight-gradient reductions) or gather_images + dense loaders (0);
  * key 14 = K9 in evaluation mode: BatchNorm on its running statistics applied in the glyph convolutions' epilogues (1, default: per
  * block three launches, shortcut first, its normalised output added in the second convolution's epilogue) or as separate scale / shift
- * and apply kernels over the raw convolution outputs (0, the round-5 form) */
+ * and apply kernels over the raw convolution outputs (0, the round-5 form); key 15 = realise_engine_adamw_pipelined runs pipelined (1,
+ * default) or as the plain sweep on the caller's stream (0) */
 void realise_set_engine(int key, int value);
 /* realise_gemm_tn_grouped over a list of live reduction blocks, as the engine's backward calls it: live[k] (device, ascending) = index
  * of the k-th block of `list_rows` rows that holds anything but exact zeros in the A operands, *n_live (device) = how many; the other

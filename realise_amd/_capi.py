@@ -143,6 +143,8 @@ SYMBOLS = {
     "realise_engine_refresh_shadows": (_I, [_P, _P]),
     "realise_engine_refresh_shadows_ex": (_I, [_P, _P, _I]),
     "realise_engine_adamw": (_I, [_P, _P, _P, _P, _P, C.POINTER(AdamwGroup), _I, _L, _P, _F]),
+    "realise_engine_adamw_pipelined": (_I, [_P, _P, _P, _P, _P, C.POINTER(AdamwGroup), _I, _L, _P, _F]),
+    "realise_engine_sync_optimizer": (_I, [_P, _P]),
     "realise_engine_invalidate_frozen": (None, [_P]),
     "realise_engine_set_id_flag": (None, [_P, _P]),
     "realise_engine_set_grads_fresh": (None, [_P, _I]),

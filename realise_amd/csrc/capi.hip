@@ -177,9 +177,9 @@ void realise_set_nt_probe(int mode) { set_nt_probe(mode); }
 void realise_set_nt_variant(int v) { set_nt_variant(v); }
 void realise_set_nt_group_m(int g) { set_nt8_group_m(g); }
 void realise_set_ln(int key, int value) {
-  if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); else if (key == 2) set_bn_fast(value); else if (key == 3) set_bn_chunks(value); else if (key == 4) set_ce_fast(value); else if (key == 5) set_ln_v2(value);
+  if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); else if (key == 2) set_bn_fast(value); else if (key == 3) set_bn_chunks(value); else if (key == 4) set_ce_fast(value); else if (key == 5) set_ln_v2(value); else if (key == 6) set_adamw_reg(value);
 }
-void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); else if (key >= 1 && key <= 3) set_stream_priority(key - 1, value); else if (key == 4) set_cls_compact(value); else if (key == 5) set_skip_dead(value); else if (key == 6) set_cls_splitk(value); else if (key == 7) set_tn_group8(value); else if (key == 8) set_ln_fuse(value); else if (key == 9) set_gru_fuse(value); else if (key == 10) set_live_rows(value); else if (key == 11) set_streamk(value); else if (key == 12) set_streamk_min(value); else if (key == 13) set_glyph_fuse(value); else if (key == 14) set_bn_fold(value); }
+void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); else if (key >= 1 && key <= 3) set_stream_priority(key - 1, value); else if (key == 4) set_cls_compact(value); else if (key == 5) set_skip_dead(value); else if (key == 6) set_cls_splitk(value); else if (key == 7) set_tn_group8(value); else if (key == 8) set_ln_fuse(value); else if (key == 9) set_gru_fuse(value); else if (key == 10) set_live_rows(value); else if (key == 11) set_streamk(value); else if (key == 12) set_streamk_min(value); else if (key == 13) set_glyph_fuse(value); else if (key == 14) set_bn_fold(value); else if (key == 15) set_opt_pipe(value); }
 void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); else if (key == 2) set_nt8_single_round(value); else if (key == 3) set_nt8_live_gc(value); else if (key == 4) set_nt8_epi_pre(value); else if (key == 5) set_nt8_live_big(value); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }
@@ -534,8 +534,15 @@ int realise_engine_adamw(realise_engine* e, void* stream, float* m, float* v, co
                          const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm) {
   AdamwGroups gs;
   if (!e || !make_adamw_groups(groups, n_groups, step, gs)) return RL_ERR_ARG;
-  return e->impl->adamw_step((hipStream_t)stream, m, v, group_of_block64, gs, grad_norm_sq, max_grad_norm);
+  return e->impl->adamw_step((hipStream_t)stream, m, v, group_of_block64, gs, grad_norm_sq, max_grad_norm, 0);
 }
+int realise_engine_adamw_pipelined(realise_engine* e, void* stream, float* m, float* v, const uint8_t* group_of_block64,
+                                   const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm) {
+  AdamwGroups gs;
+  if (!e || !make_adamw_groups(groups, n_groups, step, gs)) return RL_ERR_ARG;
+  return e->impl->adamw_step((hipStream_t)stream, m, v, group_of_block64, gs, grad_norm_sq, max_grad_norm, 1);
+}
+int realise_engine_sync_optimizer(realise_engine* e, void* stream) { return e ? e->impl->sync_optimizer((hipStream_t)stream) : RL_ERR_ARG; }
 int realise_profile_enable(int max_launches) { return prof_enable(max_launches); }
 void realise_profile_pause(int paused) { prof_pause(paused); }
 void realise_profile_mode(int attached) { prof_set_mode(attached); }

@@ -15,6 +15,7 @@ void set_cls_compact(int on);      // classifier backward over the loss rows onl
 void set_ln_fuse(int on);          // dense + dropout + residual + LayerNorm as one launch (default 0: see engine.hip)
 void set_gru_fuse(int on);         // GRU time step as one launch: recurrent GEMM + gate math (default 1)
 void set_glyph_fuse(int on);       // K7: glyph lookup fused into block 1's forward conv loaders (default 1)
+void set_opt_pipe(int on);         // realise_engine_adamw_pipelined as such (1, default) or as the plain sweep on the caller's stream (0)
 void set_bn_fold(int on);          // K9 (evaluation): BatchNorm on running statistics applied in the convolutions' epilogues (default 1)
 void set_streamk(int v);           // 1: layer GEMMs on the stream-K 256 x 192 kernel (gemm_nt8s.hip; measured slower: default 0)
 void set_streamk_min(int n);       // the least K-tiles per workgroup of a launch that select it (default 10)
@@ -33,7 +34,8 @@ struct EngineBase {
   virtual int refresh_shadows(hipStream_t st) = 0;
   virtual int refresh_shadows_ex(hipStream_t st, int skip_linear) = 0;
   virtual int adamw_step(hipStream_t st, float* m, float* v, const uint8_t* group_of_block, const struct AdamwGroups& gs, const float* norm_sq,
-                         float max_norm) = 0;
+                         float max_norm, int pipelined) = 0;
+  virtual int sync_optimizer(hipStream_t st) = 0;
   virtual void invalidate_frozen() = 0;
   virtual void set_id_flag(int* flag) = 0;
   virtual void set_grads_fresh(int fresh) = 0;

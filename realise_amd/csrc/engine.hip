@@ -108,6 +108,10 @@ void set_glyph_fuse(int on) { g_glyph_fuse = on; }
 // K9, evaluation mode (realise_set_engine key 14): BatchNorm on running statistics applied in the convolutions' epilogues (resnet_forward)
 static int g_bn_fold = 1;
 void set_bn_fold(int on) { g_bn_fold = on; }
+// realise_engine_adamw_pipelined runs as such (1, default; 2 / 3: diagnostics - every reader waits for the whole sweep / the sliced
+// launches on the caller's stream) or as the plain sweep on the caller's stream (0): realise_set_engine key 15
+static int g_opt_pipe = 1;
+void set_opt_pipe(int on) { g_opt_pipe = on; }
 static int g_stream_pri[3] = {0, 0, 0};
 void set_stream_priority(int which, int pri) { if (which >= 0 && which < 3) g_stream_pri[which] = pri < 0 ? -1 : (pri > 0 ? 1 : 0); }
 static hipError_t create_stream(hipStream_t* s, int which) {
@@ -228,6 +232,8 @@ template <typename T> struct Engine : EngineBase {
       (void)hipStreamDestroy(side);
     }
     for (hipEvent_t e : ev_sig) if (e != nullptr) (void)hipEventDestroy(e);
+    if (ev_grads != nullptr) (void)hipEventDestroy(ev_grads);
+    for (int k = 0; k < OPT_EV_MAX; ++k) if (ev_opt[k] != nullptr) (void)hipEventDestroy(ev_opt[k]);
     for (int k = 0; k < 2; ++k) if (ev_shadow[k] != nullptr) (void)hipEventDestroy(ev_shadow[k]);
   }
   // branch overlap: two engine-owned streams next to the caller's, fork / join events
@@ -392,6 +398,9 @@ template <typename T> struct Engine : EngineBase {
   int refresh_shadows_ex(hipStream_t st, int skip_linear) override {
     if (!sh) return RL_ERR_ARG;
     RL_TRY(ensure_descs(st));
+    // a pipelined optimizer sweep (adamw_step): the convolution weights this call reads are in its first piece; a full refresh reads everything
+    RL_TRY(wait_opt(st, skip_linear ? 0 : -1));
+    if (!skip_linear) opt_pending = false;
     // Three independent pieces on three streams (when the branch streams exist): the bert stack's copies on the caller's stream -
     // the forward that follows needs nothing else for its first 12 layers -, classifier + pinyin / output stacks + GRU on the pinyin
     // stream, the conv-weight launch (+ the glyph table when it changed) on the glyph stream, where the glyph branch of the
@@ -441,8 +450,41 @@ template <typename T> struct Engine : EngineBase {
   // FusedAdamW's step as the engine runs it: the Linear weights (90 % of the parameters) in the tiles of the operand-copy kernel,
   // which stores the new fp32 value AND its compute-dtype W / W^T copies in the same pass; everything else by the flat grouped
   // kernel, told by a byte per 64 parameters what the tiled launches own.  The next forward then calls refresh_shadows_ex(st, 1).
+  // ---- pipelined form (round 6, realise_engine_adamw_pipelined).  The sweep is 1.1 ms of pure HBM streaming (32 B per parameter) that
+  // nothing could overlap while it sat between the backward and the next forward on the caller's stream.  Here it runs on the
+  // engine's side stream in the order the next forward consumes the parameters - everything outside the Linear weights (biases,
+  // LayerNorm, embeddings, convolution weights), the tied word table / classifier, BERT layers 0-1 | layers 2-3 | pinyin stack +
+  // output stack + GRU | the remaining BERT layers two by two - with an event behind every piece, and the forward (and
+  // refresh_shadows_ex) waits for a piece right in front of its first reader: the caller's stream is held for ~0.3 ms instead of the
+  // whole sweep, the rest streams under the first layers of the forward.  Same kernels, same arithmetic per element: same bits.
+  // Contract: between this call and the next forward / realise_engine_sync_optimizer nothing else may touch parameters, gradients or
+  // moments (the module opts in per loop: pipeline_optimizer).
+  static constexpr int OPT_EV_MAX = 16;
+  hipEvent_t ev_opt[OPT_EV_MAX] = {}; hipEvent_t ev_grads = nullptr;
+  int opt_groups = 0;                      // bert layer groups of the pending sweep: events 0 .. opt_groups - 1, event opt_groups = the other stacks
+  bool opt_pending = false;
+  bool opt_events_ok() {
+    if (ev_grads != nullptr) return true;
+    if (hipEventCreateWithFlags(&ev_grads, hipEventDisableTiming) != hipSuccess) { ev_grads = nullptr; return false; }
+    for (int k = 0; k < OPT_EV_MAX; ++k)
+      if (hipEventCreateWithFlags(&ev_opt[k], hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+  }
+  // order stream s behind piece k of the pending sweep (k < 0: behind all of it)
+  int wait_opt(hipStream_t s, int k) {
+    if (!opt_pending) return RL_OK;
+    if (g_opt_pipe >= 2) k = -1;             // (diagnostics: every reader waits for the whole sweep)
+    const int lo = k < 0 ? 0 : std::min(k, opt_groups), hi = k < 0 ? opt_groups : lo;
+    for (int i = lo; i <= hi; ++i) if (hipStreamWaitEvent(s, ev_opt[i], 0) != hipSuccess) return RL_ERR_LAUNCH;
+    return RL_OK;
+  }
+  int sync_optimizer(hipStream_t st) override {
+    RL_TRY(wait_opt(st, -1));
+    opt_pending = false;
+    return RL_OK;
+  }
   int adamw_step(hipStream_t st, float* m, float* v, const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq,
-                 float max_norm) override {
+                 float max_norm, int pipelined) override {
     if (!sh || !m || !v || !group_of_block) return RL_ERR_ARG;
     RL_TRY(ensure_descs(st));
     const int64_t n = L.arena_elems[AR_TRAIN];
@@ -470,6 +512,43 @@ template <typename T> struct Engine : EngineBase {
     }
     RL_TRY(wait_shadows(st));           // (the previous refresh may still be writing the copies on the branch streams)
     const CastDesc* dd = (const CastDesc*)(sh + sh_descs);
+    RL_TRY(sync_optimizer(st));         // (a pipelined sweep nobody waited for: two steps without a forward in between)
+    const int Lb = (int)sh_bert.size();
+    if (pipelined && g_opt_pipe && side_ok() && opt_events_ok() && (Lb + 1) / 2 + 1 <= OPT_EV_MAX && n_descs_a == 4 * Lb) {
+      RL_TRY(join_side(st));
+      hipStream_t side = g_opt_pipe == 3 ? st : this->side;      // (diagnostics, 3: the sliced launches on the caller's stream)
+      if (hipEventRecord(ev_grads, st) != hipSuccess || hipStreamWaitEvent(side, ev_grads, 0) != hipSuccess) return RL_ERR_LAUNCH;
+      auto tile_begin = [&](int i, bool group_b) -> int {      // descriptor i of group A (0 .. n_descs_a) / B (0 .. n_descs - n_descs_a); the end = the group's tile count
+        if (!group_b) return i < n_descs_a ? desc_host[i].tile_begin : desc_tiles_a;
+        return n_descs_a + i < n_descs ? desc_host[n_descs_a + i].tile_begin : desc_tiles;
+      };
+      auto bert_layers = [&](int l0, int l1) -> int {          // the Linear weights of BERT layers [l0, l1)
+        const int a = 4 * l0, b = 4 * std::min(l1, Lb);
+        if (b <= a) return RL_OK;
+        return adamw_cast_multi<T>(side, dd + a, b - a, tile_begin(b, false) - tile_begin(a, false), P, G, m, v, group_of_block, gs, norm_sq, max_norm, tile_begin(a, false));
+      };
+      const int nb = n_descs - n_descs_a;                      // group B: [0] = tied word table / classifier, then pinyin / output stacks, GRU
+      opt_groups = (Lb + 1) / 2;
+      RL_TRY(adamw_chunks(side, P, G, m, v, (const FillChunk*)(sh + sh_skip), n_achunks, group_of_block, gs, norm_sq, max_norm));
+      RL_TRY(adamw_cast_multi<T>(side, dd + n_descs_a, 1, tile_begin(1, true), P, G, m, v, group_of_block, gs, norm_sq, max_norm, 0));
+      RL_TRY(bert_layers(0, 2));
+      if (hipEventRecord(ev_opt[0], side) != hipSuccess) return RL_ERR_LAUNCH;
+      for (int g = 1; g < opt_groups; ++g) {
+        RL_TRY(bert_layers(2 * g, 2 * g + 2));
+        if (hipEventRecord(ev_opt[g], side) != hipSuccess) return RL_ERR_LAUNCH;
+        if (g == 1 && nb > 1) {
+          RL_TRY(adamw_cast_multi<T>(side, dd + n_descs_a + 1, nb - 1, desc_tiles - tile_begin(1, true), P, G, m, v, group_of_block, gs, norm_sq, max_norm, tile_begin(1, true)));
+          if (hipEventRecord(ev_opt[opt_groups], side) != hipSuccess) return RL_ERR_LAUNCH;
+        }
+      }
+      if (opt_groups < 2 || nb <= 1) {                          // (a one- or two-layer stack, or no other stacks: the last event still has to exist)
+        if (opt_groups < 2 && nb > 1)
+          RL_TRY(adamw_cast_multi<T>(side, dd + n_descs_a + 1, nb - 1, desc_tiles - tile_begin(1, true), P, G, m, v, group_of_block, gs, norm_sq, max_norm, tile_begin(1, true)));
+        if (hipEventRecord(ev_opt[opt_groups], side) != hipSuccess) return RL_ERR_LAUNCH;
+      }
+      opt_pending = true;
+      return RL_OK;
+    }
     RL_TRY(adamw_cast_multi<T>(st, dd, n_descs_a, desc_tiles_a, P, G, m, v, group_of_block, gs, norm_sq, max_norm));
     RL_TRY(adamw_cast_multi<T>(st, dd + n_descs_a, n_descs - n_descs_a, desc_tiles, P, G, m, v, group_of_block, gs, norm_sq, max_norm));
     return adamw_chunks(st, P, G, m, v, (const FillChunk*)(sh + sh_skip), n_achunks, group_of_block, gs, norm_sq, max_norm);
@@ -722,6 +801,8 @@ template <typename T> struct Engine : EngineBase {
     }
     const T* x = wp<T>(a.emb_y);
     for (size_t l = 0; l < a.layers.size(); ++l) {
+      // a pipelined optimizer sweep (adamw_step) steps the BERT layers two by two: wait in front of a pair's first reader
+      if (sid == 0 && l >= 2 && (l % 2) == 0) RL_TRY(wait_opt(st, (int)l / 2));
       const LayerOff& o = so.layers[l];
       const LayerSh& w = shs[l];
       LayerAct& t = a.layers[l];
@@ -1221,6 +1302,7 @@ template <typename T> struct Engine : EngineBase {
     }
     last = b;
     last.Tp = Tp;
+    RL_TRY(wait_opt(st, 0));           // a pipelined optimizer sweep: its first piece holds everything the first kernels read
     have_glyph_fwd = false;            // the activations a glyph_backward would read are about to be overwritten
     dead_ok = false; rows_live = false; cls_compact = false;
     last_alive.assign(Tp, 0);
@@ -1260,6 +1342,7 @@ template <typename T> struct Engine : EngineBase {
     if (!(ovl && g_fwd_order == 1)) RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, last.src_idx, nullptr, 0, &bert_h));
     const T* top = bert_h;
     if (cfg.model_type == 1) {
+      RL_TRY(wait_opt(s_pho, opt_groups));                          // (pipelined sweep: pinyin / output stacks and the GRU are one piece)
       RL_TRY(gru_forward(s_pho));
       const T* pho_h = nullptr;
       RL_TRY(stack_forward(s_pho, 1, L.pho, sh_pho, pl.pho, nullptr, wp<T>(pl.gru_out), 0, &pho_h));
@@ -1273,9 +1356,11 @@ template <typename T> struct Engine : EngineBase {
       }
       if (ovl && g_fwd_order == 1) { RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, last.src_idx, nullptr, 0, &bert_h)); top = bert_h; }
       if (ovl) RL_TRY(join(st));
+      RL_TRY(sync_optimizer(st));                                   // every piece of a pipelined sweep is now in front of this stream
       RL_TRY(gate_fwd<T>(st, gate_args()));
       RL_TRY(stack_forward(st, 2, L.outb, sh_out, pl.outb, nullptr, wp<T>(pl.fused), 1, &top));
     }
+    RL_TRY(sync_optimizer(st));
     const DropParams dfin = site(5000, cfg.hidden_dropout);
     const T* cls_in = top;
     if (dfin.thresh) { RL_TRY(dropout_apply<T>(st, top, wp<T>(pl.out_d), Tk, H, dfin)); cls_in = wp<T>(pl.out_d); }
@@ -1338,6 +1423,7 @@ template <typename T> struct Engine : EngineBase {
   bool have_glyph_fwd = false;
   int glyph_forward(hipStream_t st, const int64_t* ids, int B, int S, int training, void* res_out) override {
     if (!sh || !ws || cfg.model_type != 1 || !ids || !res_out || B < 1 || S < 1) return RL_ERR_ARG;
+    RL_TRY(sync_optimizer(st));
     if (pl.B != B || pl.S != S || pl.Tp != -1) {
       RL_TRY(install_plan(st, make_plan(B, S, -1)));
     }
@@ -1356,6 +1442,7 @@ template <typename T> struct Engine : EngineBase {
   // accumulates the gradients of the 15 conv / BatchNorm parameter tensors for d_res [B*S, 768] (per token)
   int glyph_backward(hipStream_t st, const void* d_res) override {
     if (!have_glyph_fwd || !d_res) { fprintf(stderr, "[realise_hip] glyph_backward without a training glyph_forward\n"); return RL_ERR_ARG; }
+    RL_TRY(sync_optimizer(st));
     RL_TRY(begin_gradient_pass(st, true));
     const int Tk = pl.B * pl.S;
     RL_TRY(segment_sum<T>(st, (const T*)d_res, wp<int>(pl.gu_inv), Tk, H, wp<float>(pl.seg_acc), wp<T>(pl.r_dout), wp<int>(pl.gu_bounds)));

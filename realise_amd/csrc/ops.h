@@ -185,6 +185,7 @@ int gru_table_bwd(hipStream_t st, const float* dtable, int ld_dtable, const floa
 // a BasicBlock's bn2 + shortcut BN (shared dy and ReLU mask read once).  *2 functions return RL_ERR_ARG when the fast path does not apply.
 void set_bn_fast(int on);
 void set_bn_chunks(int n);
+void set_adamw_reg(int on);         // realise_set_ln key 6: AdamW + operand-copy tiles with the in-register transpose (1) or through LDS (0, default)
 void set_ce_fast(int on);           // bf16 masked cross-entropy with the logits row held in registers (default 1)
 int bn_fast();
 // one-pass training statistics of a bf16 [P, C] map + everything bn_finalize_train does (2 launches instead of 5, x read once);
@@ -273,7 +274,7 @@ int adamw_grouped(hipStream_t st, float* p, const float* g, float* m, float* v, 
 // copies from the updated values, one pass; P0 / G0 / M0 / V0 = bases of the parameter / gradient / moment arenas
 template <typename T>
 int adamw_cast_multi(hipStream_t st, const CastDesc* descs, int n, int total_tiles, float* P0, const float* G0, float* M0, float* V0,
-                     const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq, float max_norm);
+                     const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq, float max_norm, int tile_base = 0);
 int clip_scale(hipStream_t st, float* g, int64_t n, const float* norm_sq, float max_norm);
 int fill_f32(hipStream_t st, float* p, float v, int64_t n);
 struct FillChunk { int64_t off; int32_t len, pad; };     // off: 4-element aligned

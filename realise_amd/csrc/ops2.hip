@@ -934,15 +934,18 @@ template <typename T>
 __global__ void __launch_bounds__(256) adamw_cast_multi_kernel(const CastDesc* __restrict__ descs, int n, float* __restrict__ P0,
                                                                const float* __restrict__ G0, float* __restrict__ M0, float* __restrict__ V0,
                                                                const uint8_t* __restrict__ group_of_block, AdamwGroups gs,
-                                                               const float* __restrict__ norm_sq, float max_norm) {
+                                                               const float* __restrict__ norm_sq, float max_norm, int tile_base) {
   __shared__ float tile[64][65];
-  int lo = 0, hi = n - 1;                               // last descriptor with tile_begin <= blockIdx.x
+  // tile_base (round 6): the launch covers a SLICE of a descriptor group - descs points at the slice's first descriptor, whose
+  // tile_begin (counted from the group's first) is tile_base
+  const int bid = (int)blockIdx.x + tile_base;
+  int lo = 0, hi = n - 1;                               // last descriptor with tile_begin <= bid
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (descs[mid].tile_begin <= bid) lo = mid; else hi = mid - 1;
   }
   const CastDesc d = descs[lo];
-  const int t = blockIdx.x - d.tile_begin;
+  const int t = bid - d.tile_begin;
   const int r0 = (t / d.tiles_c) * 64, c0 = (t % d.tiles_c) * 64;
   const int q = threadIdx.x & 15, y = threadIdx.x >> 4;     // 16 quads x 16 rows per pass
   T* dst = (T*)d.dst;
@@ -997,16 +1000,92 @@ __global__ void __launch_bounds__(256) adamw_cast_multi_kernel(const CastDesc* _
     }
   }
 }
+// The same tile without LDS (round 6): a thread owns a 4 x 4 block - rows r0 + 4 y .. + 3, columns c0 + 4 q .. + 3 - so the transposed
+// copy is an in-register transpose (four 8-byte stores of four consecutive W^T columns each), all sixteen 16-byte loads of the thread
+// are in flight together, there is no barrier, and - the reason it was written - a workgroup that needs no LDS can share a CU with the
+// two 80 KB GEMM workgroups of a running forward (the pipelined sweep, engine.hip adamw_step).  Same arithmetic per element: same bits.
+template <typename T>
+__global__ void __launch_bounds__(256) adamw_cast_multi_reg_kernel(const CastDesc* __restrict__ descs, int n, float* __restrict__ P0,
+                                                                   const float* __restrict__ G0, float* __restrict__ M0, float* __restrict__ V0,
+                                                                   const uint8_t* __restrict__ group_of_block, AdamwGroups gs,
+                                                                   const float* __restrict__ norm_sq, float max_norm, int tile_base) {
+  const int bid = (int)blockIdx.x + tile_base;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_begin <= bid) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = descs[lo];
+  const int t = bid - d.tile_begin;
+  const int r0 = (t / d.tiles_c) * 64, c0 = (t % d.tiles_c) * 64;
+  const int q = threadIdx.x & 15, y = threadIdx.x >> 4;
+  T* dst = (T*)d.dst;
+  T* dstT = (T*)d.dstT;
+  const int64_t base = d.src - P0;
+  float clip = 1.0f;
+  if (norm_sq != nullptr) {
+    const float c = max_norm / (sqrtf(norm_sq[0]) + 1e-6f);
+    clip = c < 1.0f ? c : 1.0f;
+  }
+  const int c = c0 + 4 * q, rb = r0 + 4 * y;
+  if (c >= d.C || rb >= d.R) return;
+  floatx4 pv[4], gv[4], mv[4], vv[4];
+  int gid[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = rb + k;
+    pv[k] = floatx4{0.f, 0.f, 0.f, 0.f}; gid[k] = 255;
+    if (r < d.R) {
+      const int64_t e = base + (int64_t)r * d.C + c;
+      pv[k] = *(const floatx4*)(P0 + e);
+      gid[k] = group_of_block[e >> 6];
+      if (gid[k] < gs.n) { gv[k] = *(const floatx4*)(G0 + e); mv[k] = *(const floatx4*)(M0 + e); vv[k] = *(const floatx4*)(V0 + e); }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = rb + k;
+    if (r >= d.R) continue;
+    const int64_t e = base + (int64_t)r * d.C + c;
+    if (gid[k] < gs.n) {
+      const AdamwGroup h = gs.g[gid[k]];
+      const floatx4 g4 = gv[k] * clip;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        mv[k][j] = mv[k][j] * h.beta1 + (1.0f - h.beta1) * g4[j];
+        vv[k][j] = vv[k][j] * h.beta2 + (1.0f - h.beta2) * g4[j] * g4[j];
+        float pi = pv[k][j] - h.step_size * (mv[k][j] / (sqrtf(vv[k][j]) + h.eps));
+        if (h.weight_decay > 0.f) pi -= h.lr * h.weight_decay * pi;
+        pv[k][j] = pi;
+      }
+      *(floatx4*)(M0 + e) = mv[k]; *(floatx4*)(V0 + e) = vv[k]; *(floatx4*)(P0 + e) = pv[k];
+    }
+    if (dst != nullptr) store4<T>(dst + (int64_t)r * d.C + c, pv[k]);
+  }
+  if (dstT == nullptr) return;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const floatx4 v = floatx4{pv[0][j], pv[1][j], pv[2][j], pv[3][j]};
+    if (rb + 3 < d.R && (d.ldT & 3) == 0) store4<T>(dstT + (int64_t)(c + j) * d.ldT + rb, v);
+    else for (int k = 0; k < 4 && rb + k < d.R; ++k) dstT[(int64_t)(c + j) * d.ldT + rb + k] = from_f<T>(v[k]);
+  }
+}
+// realise_set_ln key 6: 1 = the register-transpose tile above, 0 (default) = the LDS tile (round 4).  Measured level (14.67 against 14.61-
+// 14.83 ms/step, three pairs), and the pipelined sweep on it is level with the plain sweep too: what overlaps competes for HBM.
+static int g_adamw_reg = 0;
+void set_adamw_reg(int on) { g_adamw_reg = on; }
+
 template <typename T>
 int adamw_cast_multi(hipStream_t st, const CastDesc* descs, int n, int total_tiles, float* P0, const float* G0, float* M0, float* V0,
-                     const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq, float max_norm) {
+                     const uint8_t* group_of_block, const AdamwGroups& gs, const float* norm_sq, float max_norm, int tile_base) {
   if (n <= 0 || total_tiles <= 0) return RL_OK;
   if (gs.n < 1 || gs.n > ADAMW_MAX_GROUPS || group_of_block == nullptr) return RL_ERR_ARG;
-  hipLaunchKernelGGL((adamw_cast_multi_kernel<T>), dim3(total_tiles), dim3(256), 0, st, descs, n, P0, G0, M0, V0, group_of_block, gs, norm_sq, max_norm);
+  if (g_adamw_reg) hipLaunchKernelGGL((adamw_cast_multi_reg_kernel<T>), dim3(total_tiles), dim3(256), 0, st, descs, n, P0, G0, M0, V0, group_of_block, gs, norm_sq, max_norm, tile_base);
+  else hipLaunchKernelGGL((adamw_cast_multi_kernel<T>), dim3(total_tiles), dim3(256), 0, st, descs, n, P0, G0, M0, V0, group_of_block, gs, norm_sq, max_norm, tile_base);
   return RL_LAUNCH_CHECK();
 }
-template int adamw_cast_multi<bf16_t>(hipStream_t, const CastDesc*, int, int, float*, const float*, float*, float*, const uint8_t*, const AdamwGroups&, const float*, float);
-template int adamw_cast_multi<float>(hipStream_t, const CastDesc*, int, int, float*, const float*, float*, float*, const uint8_t*, const AdamwGroups&, const float*, float);
+template int adamw_cast_multi<bf16_t>(hipStream_t, const CastDesc*, int, int, float*, const float*, float*, float*, const uint8_t*, const AdamwGroups&, const float*, float, int);
+template int adamw_cast_multi<float>(hipStream_t, const CastDesc*, int, int, float*, const float*, float*, float*, const uint8_t*, const AdamwGroups&, const float*, float, int);
 
 // g *= min(1, max_norm / (sqrt(*norm_sq) + 1e-6)) - the in-place half of clip_grad_norm_ (run.py:207) for callers that step with a
 // stock optimizer (FusedAdamW applies the coefficient inside its own sweep instead)

@@ -208,6 +208,7 @@ class RealiseModule(nn.Module):
             raise RuntimeError("constructed with tie=False; build the module with tie=True to share the weight")
 
     def load_state_dict(self, state_dict, strict=True):
+        self.sync_optimizer()
         sd = dict(state_dict)
         if self._tie and "classifier.weight" in sd and "bert.embeddings.word_embeddings.weight" in sd:
             del sd["classifier.weight"]        # the reference re-points it at the embedding after loading (run.py:431)
@@ -313,6 +314,7 @@ class RealiseModule(nn.Module):
             for p in self._grad_params():
                 p.grad = None
             return
+        self.sync_optimizer()                # (a pipelined optimizer sweep may still be reading the gradients)
         self._grads.zero_()
         self._zero_pending = False
         if set_to_none:
@@ -433,6 +435,23 @@ class RealiseModule(nn.Module):
     # write): the forward after a FusedAdamW step trusts the copies that step wrote and re-derives the conv-weight copies only.
     trust_fused_optimizer = False
     _linear_copies_current = False
+    # True (needs trust_fused_optimizer; nobody sets it by default): FusedAdamW's engine sweep runs PIPELINED across the step boundary - on
+    # the engine's side stream, in the order the next forward consumes the parameters, that forward waiting piece by piece
+    # (realise_engine_adamw_pipelined).  Built for the 1.1 ms the sweep holds the caller's stream at the full model size; MEASURED 0.03-0.2
+    # ms/step slower than the plain sweep (the sweep's tiles use LDS and cannot share a CU with two 80 KB GEMM workgroups -
+    # it runs in their gaps, and what overlaps competes for the same memory system), so it stays opt-in.  Until the next forward
+    # nothing but the engine may then touch parameters, gradients or optimizer moments; state_dict() / save_pretrained() /
+    # load_state_dict() / zero_grad(set_to_none=False) / sync_optimizer() order the caller's stream behind the sweep first.
+    pipeline_optimizer = False
+
+    def sync_optimizer(self):
+        """order the current stream behind a pending pipelined optimizer sweep (no-op without one)"""
+        if getattr(self, "_engine", None) is not None and self._grads.is_cuda:
+            _capi.check(_capi.load().realise_engine_sync_optimizer(self._engine, self._stream()), "realise_engine_sync_optimizer")
+
+    def state_dict(self, *args, **kwargs):
+        self.sync_optimizer()
+        return super().state_dict(*args, **kwargs)
 
     def mark_parameters_updated(self, frozen=True, linear_copies_current=False):
         """call after mutating parameters through a path torch's version counter cannot see: raw pointers, or ``p.data.copy_()``

@@ -91,8 +91,10 @@ class FusedAdamW(torch.optim.Optimizer):
             groups = (_capi.AdamwGroup * len(self.param_groups))()
             for k, g in enumerate(self.param_groups):
                 groups[k] = _capi.AdamwGroup(g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], 1 if g["correct_bias"] else 0)
-            _capi.check(lib.realise_engine_adamw(mod._engine, st, self._m.data_ptr(), self._v.data_ptr(), self._group_map(flat_p).data_ptr(), groups,
-                                                 len(self.param_groups), self._step, norm_ptr, max_norm), "realise_engine_adamw")
+            # (pipeline_optimizer: the same sweep on the engine's side stream, the next forward waiting for it piece by piece)
+            sweep = lib.realise_engine_adamw_pipelined if getattr(mod, "pipeline_optimizer", False) else lib.realise_engine_adamw
+            _capi.check(sweep(mod._engine, st, self._m.data_ptr(), self._v.data_ptr(), self._group_map(flat_p).data_ptr(), groups,
+                              len(self.param_groups), self._step, norm_ptr, max_norm), "realise_engine_adamw")
             mod.mark_parameters_updated(frozen=False, linear_copies_current=True)
             return
         if uniform and covered == wanted:
@@ -119,6 +121,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         """torch's param_groups plus the flat first / second moments and the step count (they live outside ``self.state``)"""
+        self.module.sync_optimizer()
         sd = super().state_dict()
         sd["realise_flat"] = {"m": self._m.detach().clone(), "v": self._v.detach().clone(), "step": int(self._step)}
         return sd
@@ -126,6 +129,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         sd = dict(state_dict)
         flat = sd.pop("realise_flat", None)
+        self.module.sync_optimizer()
         super().load_state_dict(sd)
         if flat is not None:
             if flat["m"].numel() != self._m.numel():

@@ -105,6 +105,9 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
     # the loop reads outputs[0] alone (run.py:191): the training forwards skip the [B, S, V] logits (modeling.py: train_logits)
     logits_before = getattr(model, "train_logits", True)
     model.train_logits = False
+    # (modeling.py: pipeline_optimizer stays as the caller set it - the pipelined optimizer sweep measured slower than the plain one;
+    # whatever it is, the sweep is joined before this function returns)
+    pipe_before = getattr(model, "pipeline_optimizer", False)
     try:
         model.zero_grad()
         stop = False
@@ -150,6 +153,9 @@ def train(model, items, *, batch_size=64, max_seq_length=128, epochs=1, lr=5e-5,
     finally:
         model.trust_fused_optimizer = trusted_before
         model.train_logits = logits_before
+        model.pipeline_optimizer = pipe_before
+        if hasattr(model, "sync_optimizer"):
+            model.sync_optimizer()
         model.mark_parameters_updated(frozen=False)       # whatever runs next re-derives every operand copy
     if hasattr(model, "check_ids"):
         model.check_ids()                  # a bad id in the last batches must not go unreported
