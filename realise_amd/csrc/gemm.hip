@@ -396,7 +396,9 @@ static int launch_nt_tile(hipStream_t st, const ALoader& la, const DenseLoader<T
   const int tiles_m = (M + BM_ - 1) / BM_, tiles_n = (N + BN_ - 1) / BN_;
   const int ntiles = tiles_m * tiles_n;
   const size_t ring = NSTAGE * (size_t)(BM_ + BN_) * 128, etile = (size_t)WM * WN * 64 * (16 * NF + 4) * 4;
-  const size_t lds = ring > etile ? ring : etile;        // the epilogue re-uses the ring as per-wave transpose tiles
+  // (NF = 6, round 6 probe: 128 x 192 on FOUR waves of 64 x 96 - the ring alone, 80 KB, so that two workgroups share a CU as the 8-wave
+  // 128 x 192 kernel's do; its epilogue then stores straight from the accumulator layout)
+  const size_t lds = (NF == 6 || ring > etile) ? ring : etile;        // the epilogue re-uses the ring as per-wave transpose tiles
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -407,7 +409,7 @@ static int launch_nt_tile(hipStream_t st, const ALoader& la, const DenseLoader<T
     if (la.rows_dev != nullptr) prof_set_exec(la.rows_dev, 2.0 * N * K, BM_, M);   // device-side row bound: surplus tiles exit at once
   EpiParams<T> epp = ep;
   epp.probe = g_nt_probe;
-  epp.wide = g_nt_wide && (N % 8 == 0) && (ep.ldo % 8 == 0) && (ep.aux == nullptr || ep.ldaux % 8 == 0);
+  epp.wide = NF != 6 && g_nt_wide && (N % 8 == 0) && (ep.ldo % 8 == 0) && (ep.aux == nullptr || ep.ldaux % 8 == 0);
   RL_LAUNCH((gemm_nt_kernel<T, ALoader, WM, WN, NSTAGE, NF, SPREAD>), dim3(ntiles), dim3(64 * WM * WN), lds, st, la, lb, M, N, K, tiles_n, ntiles, epp);
   return hipGetLastError() == hipSuccess ? RL_OK : RL_ERR_LAUNCH;
 }
@@ -437,7 +439,7 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
         nt8p_supported(M, N, K, ep, la.ld, ldb))
       return gemm_nt8p(st, la.base, la.ld, B, ldb, M, N, K, ep);
     if (ep.out_f32 != nullptr) return RL_ERR_ARG;        // (the fp32 copy exists in the persistent kernel's epilogue only: the caller casts)
-    if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 44) || g_nt_variant >= 50)) {
+    if (la.rows_dev == nullptr && g_nt_probe != 1 && ((g_nt_variant == 0 && M >= 1024 && N >= 256) || (g_nt_variant >= 10 && g_nt_variant <= 44) || (g_nt_variant >= 50 && g_nt_variant < 60))) {
       if (nt8_supported(M, N, K, ep, la.ld, ldb)) return gemm_nt8(st, la.base, la.ld, B, ldb, M, N, K, ep, (g_nt_variant >= 10 && g_nt_variant < 50) ? g_nt_variant - 10 : 0);
     }
     // a device-side row bound on a wide output (round 6: the training classifier over the loss rows): the persistent kernel, which
@@ -466,6 +468,10 @@ static int launch_nt(hipStream_t st, const ALoader& la, const T* B, int64_t ldb,
               return launch_nt_tile<T, ALoader, 2, 2, 2, 4, true>(st, la, lb, M, N, K, ep);   // production tiles, spread fetch issue
       case 6: return launch_nt_tile<T, ALoader, 4, 2, 3, 4, true>(st, la, lb, M, N, K, ep);     // 256 x 128, 3 stages, spread
       case 7: return launch_nt_tile<T, ALoader, 2, 4, 3, 3, true>(st, la, lb, M, N, K, ep);     // 128 x 192, 3 stages, spread
+      // round 6: 128 x 192 on four waves of 64 x 96, two workgroups per CU - 37 % fewer fragment bytes read
+      // from LDS per K-tile than the 8-wave 128 x 192 kernel (80 against 128 KB); 60 = fetches behind the barrier, 61 = spread
+      case 60: return launch_nt_tile<T, ALoader, 2, 2, 2, 6>(st, la, lb, M, N, K, ep);
+      case 61: return launch_nt_tile<T, ALoader, 2, 2, 2, 6, true>(st, la, lb, M, N, K, ep);
       case 8: if ((K % 64) == 0 && la.rows_dev == nullptr) return launch_nt_pp(st, la, lb, M, N, K, ep);     // phase-shifted 256 x 128
               break;
       default: break;

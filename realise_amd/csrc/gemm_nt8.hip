@@ -687,12 +687,6 @@ __device__ __forceinline__ void nt8ws_loader(char* smem, const bf16_t* __restric
     }
     lo[s] = (is_b ? C::A_BYTES : 0) + row * 128;
     int grow = is_b ? min(n0 + row + lrow, N - 1) : min(m0 + row + lrow, M - 1);
-    if constexpr (XEPI == 2) {
-      if (is_b) {                                 // gate-interleaved column tile: [r | z | n] x 32 units for each of the two wave columns
-        const int c = row + lrow, half = c / 96, cc = c - half * 96, gate = cc >> 5;
-        grow = gate * (N / 3) + tn * 64 + half * 32 + (cc & 31);
-      }
-    }
     go[s] = (uint32_t)((int64_t)grow * (is_b ? ldb : lda) * 2 + kchunk_b);
   }
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(((int64_t)(M - 1) * lda + K) * 2), 0x00020000);
