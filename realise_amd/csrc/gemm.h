@@ -397,6 +397,7 @@ template <typename T> struct TnGroupProblem {
   float* out = nullptr; int64_t ldo = 0;        // fp32 [I, ldo], accumulated; ldo % 4 == 0
   float* colsum = nullptr;                      // nullable: += column sums of A (bias gradient)
   int tiles_j = 0, ntiles = 0, tile_begin = 0;  // filled by gemm_tn_group
+  int jmajor = 0;                               // filled by gemm_tn_group: tiles walked j-panel by j-panel (the B operand is the larger one)
 };
 template <typename T> struct TnGroup {
   TnGroupProblem<T> p[TN_GROUP_MAX];
@@ -447,6 +448,7 @@ bool nt8s_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t ld
 int gemm_nt8s(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
 void set_nt8p_wgs(int n);
 void set_nt8_epi_pre(int on);      // 1 (default): alpha / bias into the accumulators before the 8-wave kernels' epilogue transposes (one bias fetch per wave, no per-item waits)
+void set_tn_jmajor(int on);       // realise_set_nt8p key 6: grouped weight gradients walk a problem's tiles along its LARGER operand's panels (1; default 0: measured level)
 void set_nt8_live_big(int v);     // measurement knob (realise_set_nt8p key 5): wide row-list launches on 256 x 256 one-per-CU tiles
 void set_nt8_live_gc(int gc);      // live-row GEMMs: 0 (default) column groups of the XCD split from the shape, 1 / 2 / 4 / 8 forced
 void set_nt8p_order(int o);

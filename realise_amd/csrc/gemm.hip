@@ -233,6 +233,8 @@ gemm_nt_kernel(ALoader la, DenseLoader<T> lb, int M, int N, int K, int tiles_n, 
       epilogue4<T>(ep, M, N, m0 + wm * 64 + i * 16 + l15, n0 + wn * 16 * NF + j * 16 + 4 * g, acc[i][j]);
 }
 
+static int g_tn_jmajor = 0;      // (measured: family 2.585 against 2.545 ms/step i-major, three pairs - fewer HBM bytes, not faster: off)
+void set_tn_jmajor(int on) { g_tn_jmajor = on; }
 static int g_nt_n96 = 1;             // allow 128x96 tiles (tuning / A-B knob)
 void set_nt_allow_n96(int on) { g_nt_n96 = on; }
 static int g_nt_probe = 0, g_nt_wide = 1, g_nt_variant = 0;
@@ -570,7 +572,7 @@ template <typename T, int NB> struct ConvTaps<ConvLoaderDirect<T>, NB> : ConvTap
 // tiles in the same 64 KB: three tiles in flight per workgroup instead of one).
 template <typename T, typename BLoader, bool TR, int WI, int WJ, int NST = 2, int BPD = 1>
 __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t lda, BLoader lb, int P, int I, int J, int tiles_j, int ntiles,
-                                             int nsplit, int pchunk, int how, TnEpi ep, int logical) {
+                                             int nsplit, int pchunk, int how, TnEpi ep, int logical, int jmajor = 0) {
   typedef typename MmaOf<T>::type Mma;
   typedef TnGeo<T> G;
   constexpr int BP = G::BP / BPD, KST = G::KSTEPS / BPD;
@@ -583,7 +585,12 @@ __device__ __forceinline__ void tn_tile_body(const T* __restrict__ A, int64_t ld
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave / WJ, wj = wave - wi * WJ;
   const int split = logical / ntiles, tile = logical - split * ntiles;
-  const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+  // Tile order inside a problem.  The XCD remap hands every XCD a contiguous run of tiles; i-major (default) a run shares few dY panels
+  // and streams the WHOLE B operand through its L2, j-major the other way round.  The grouped launch picks the order that streams the
+  // smaller operand whole (round 6: FFN-down's weight gradient, I = 768, J = 3072, re-read its 33 MB `post` operand on three XCDs).
+  int ti, tj;
+  if (jmajor) { const int tiles_i = ntiles / tiles_j; tj = tile / tiles_i; ti = tile - tj * tiles_i; }
+  else { ti = tile / tiles_j; tj = tile - ti * tiles_j; }
   const int i0 = ti * BI, j0 = tj * BJ;
   lb.clamp_rows();
   const int Pe = min(P, lb.rows);                      // device-side row bound (glyph dedup): re-split the live rows evenly
@@ -835,7 +842,7 @@ gemm_tn_group_kernel(TnGroup<T> grp, int P, int pchunk) {
   ep.out = pr.out; ep.ldo = pr.ldo; ep.colsum = pr.colsum; ep.alpha = grp.alpha; ep.probe = grp.probe; ep.overwrite = grp.overwrite;
   ep.tile_list = grp.tile_list; ep.n_tiles = grp.n_tiles; ep.list_rows = grp.list_rows;
   tn_tile_body<T, DenseLoader<T>, TR, 2, 2, NST, BPD>(pr.A, pr.lda, lb, P, pr.I, pr.J, pr.tiles_j, pr.ntiles, 1, pchunk, TN_OUT_DIRECT, ep,
-                                                      logical - pr.tile_begin);
+                                                      logical - pr.tile_begin, pr.jmajor);
 }
 
 // out(mapped) += alpha * sum_s slab[s][i][j], in a fixed order (bitwise reproducible).
@@ -1034,6 +1041,7 @@ int gemm_tn_group(hipStream_t st, int n, const TnGroupProblem<T>* probs, int P, 
     if (pr.I <= 0 || pr.J <= 0 || (pr.lda % G::VEC) || (pr.ldb % G::VEC) || (pr.I % G::VEC) || (pr.J % G::VEC) || (pr.ldo & 3)) return RL_ERR_ARG;
     pr.tiles_j = (pr.J + 127) / 128;
     pr.ntiles = ((pr.I + 127) / 128) * pr.tiles_j;
+    pr.jmajor = (g_tn_jmajor && pr.J > pr.I) ? 1 : 0;
     pr.tile_begin = total;
     total += pr.ntiles;
     flops += 2.0 * P * pr.I * pr.J;
