@@ -262,6 +262,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return base + (bid >> 3);
 }
+// CU pairing (round 6 probe).  With two workgroups per CU the dispatcher of an idle XCD places local workgroups j and j + 32 on the same
+// CU (32 CUs, round-robin, observed); this permutation of the local index makes those two the logical neighbours 2j and 2j + 1 - two
+// column tiles of one tile row, which fetch the SAME A K-tiles at about the same time: the second fetch can hit the CU's vector L1
+// instead of occupying a miss slot.  Identity on an incomplete last block of 64.  Changes placement only, never results.
+__device__ __forceinline__ int cu_pair_local(int j, int run) {
+  const int blk = j & ~63, r = j & 63;
+  if (blk + 64 > run) return j;
+  return blk + (r < 32 ? 2 * r : 2 * (r - 32) + 1);
+}
+__device__ __forceinline__ int xcd_remap_paired(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, x = bid & 7;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + cu_pair_local(bid >> 3, x < r ? q + 1 : q);
+}
 
 }  // namespace rl
 

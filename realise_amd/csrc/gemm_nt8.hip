@@ -49,6 +49,8 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_n, int ntiles, i
 
 static int g_nt8_probe = 0;
 void set_nt8_probe(int mode) { g_nt8_probe = mode; }
+static int g_nt8_cu_pair = 0;
+void set_nt8_cu_pair(int on) { g_nt8_cu_pair = on; }
 static int nt8_bias_first_on();
 
 // ---- K4 epilogue: dropout(acc + bias) + residual, then the LayerNorm of the row, whose columns are spread over the N / BN workgroups
@@ -268,7 +270,7 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
   } else if constexpr (XEPI == 3 || XEPI == 4) {
     tile = 0;
   } else {
-    tile = xcd_remap(blockIdx.x, ntiles);
+    tile = ep.cu_pair ? xcd_remap_paired(blockIdx.x, ntiles) : xcd_remap(blockIdx.x, ntiles);
   }
   int tm, tn;
   int nlive = 0;                                            // XEPI 3: live 16-row blocks; tile row tm owns list entries tm * BM / 16 ..
@@ -283,16 +285,18 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
     if (ep.xcd_gc > 1) {
       // 2-D XCD split (EpiParams::xcd_gc): XCD x = blockIdx % 8 (as dispatched today; another placement changes speed only) works on row
       // group x / gc x column group x % gc, row-major inside it
-      const int gc = ep.xcd_gc, gr = 8 / gc, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+      const int gc = ep.xcd_gc, gr = 8 / gc, x = blockIdx.x & 7;
+      int j = blockIdx.x >> 3;
       const int rg = x / gc, cg = x - rg * gc, ncl = tiles_n / gc;
       const int r0 = (rg * tml) / gr, r1 = ((rg + 1) * tml) / gr;
       if (j >= (r1 - r0) * ncl) return;                     // (the whole workgroup leaves before any barrier)
+      if (ep.cu_pair) j = cu_pair_local(j, (r1 - r0) * ncl);
       const int lr = j / ncl;
       tm = r0 + lr; tn = cg * ncl + (j - lr * ncl);
       tile = tm * tiles_n + tn;
     } else {
       if ((int)blockIdx.x >= ntl) return;                   // (the whole workgroup leaves before any barrier)
-      tile = xcd_remap(blockIdx.x, ntl);
+      tile = ep.cu_pair ? xcd_remap_paired(blockIdx.x, ntl) : xcd_remap(blockIdx.x, ntl);
       tile_coords(tile, tiles_n, ntl, group_m, tm, tn);
     }
   } else {
@@ -363,6 +367,8 @@ gemm_nt8_kernel(const bf16_t* __restrict__ A_, int64_t lda, const bf16_t* __rest
     constexpr bool is_b = (s < C::HPW) ? C::HOLD_B : !C::HOLD_B;
     uint32_t voff = go[s];
     if constexpr (KTAIL) { if (ktail != 0 && ktile == nk - 1) voff = lane_past_k ? 0xFFFFFF00u : voff; }
+    // (round 6: the B fetches marked non-temporal - aux = 2 - so that a co-resident workgroup's A lines outlive them in the L1: the family
+    // 6.5 -> 7.2 ms/step; the weight tiles live on their L2 / L1 residency.  profiles/round6_ab.log)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(is_b ? rsB : rsA, (__attribute__((address_space(3))) void*)(smem + stage * C::STAGE + lo[s]), 16,
                                              voff, ktile * 128, 0, 0);
   };
@@ -649,6 +655,7 @@ static int launch_nt8_cfg(hipStream_t st, const bf16_t* A, int64_t lda, const bf
 #endif
   EpiParams<bf16_t> epk = ep;
   epk.bias_first = nt8_bias_first_on() && (N % 4) == 0 && N >= 4;
+  epk.cu_pair = (g_nt8_cu_pair && C::WGS == 2 && (tiles_n % 2) == 0 && ep.ksplit <= 1) ? 1 : 0;
   int grid = ntiles * (KTAIL || ep.ksplit < 1 ? 1 : ep.ksplit);
   if constexpr (XEPI == 3 || XEPI == 4) { if (ep.xcd_gc > 1) grid = (tiles_m + 8 / ep.xcd_gc) * tiles_n; }      // every row group rounded up to whole tile rows
   RL_LAUNCH((gemm_nt8_kernel<C, 0, KTAIL, XEPI>), dim3(grid), dim3(512), C::LDS, st, A, lda, B, ldb, M, N, K, tiles_n, ntiles, g_nt8_group_m, epk);

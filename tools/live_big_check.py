@@ -12,6 +12,8 @@ from realise_amd.init import init_state_dict_numpy
 from realise_amd.modeling import SpellBertPho2ResArch3
 
 lib = _capi.load()
+KEY = int(sys.argv[1]) if len(sys.argv) > 1 else 5      # realise_set_nt8p key under test (5: 256 x 256 row-list tiles, probe build; 7: CU pairing)
+VALUES = (1, 2) if KEY == 5 else (1,)
 cfg = RealiseConfig(num_hidden_layers=2, pho_layers=1, out_layers=1)
 sd = init_state_dict_numpy(cfg, seed=5)
 b = synthetic_batch(64, 128, seed=77)
@@ -19,7 +21,7 @@ b = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in b.items()}
 
 
 def run(v):
-    lib.realise_set_nt8p(5, v)
+    lib.realise_set_nt8p(KEY, v)
     m = SpellBertPho2ResArch3(cfg, compute_dtype="bf16")
     m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(x)) for k, x in sd.items()})
     m.to("cuda"); m.train()
@@ -28,12 +30,12 @@ def run(v):
     loss.backward()
     torch.cuda.synchronize()
     g = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
-    lib.realise_set_nt8p(5, 0)
+    lib.realise_set_nt8p(KEY, 0)
     return float(loss.item()), g
 
 
 l0, g0 = run(0)
-for v in (1, 2):
+for v in VALUES:
     l1, g1 = run(v)
     bad = [n for n in g0 if "encoder.layer" in n and not torch.equal(g0[n], g1[n])]
     print("knob", v, "loss", l0, l1, "layer gradient tensors that differ:", len(bad), bad[:4])
