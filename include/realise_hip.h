@@ -317,7 +317,7 @@ int realise_engine_adamw(realise_engine* e, void* stream, float* m, float* v, co
  * and for all of it before they return, so the caller's stream is held for the first piece only (~0.3 of the ~1.1 ms at the full model
  * size).  Same kernels and per-element arithmetic as realise_engine_adamw: the same bits.  CONTRACT: between this call and the next
  * realise_engine_forward / realise_engine_refresh_shadows_ex(e, s, 0) / realise_engine_sync_optimizer nothing else may read or write
- * the parameter, gradient or moment arenas on any stream.  realise_set_engine(15, 0) turns it into realise_engine_adamw. */
+ * the parameter, gradient or moment arenas on any stream.  (Engine knob 15 = 0, declared in realise_hip_debug.h, turns it into the plain sweep.) */
 int realise_engine_adamw_pipelined(realise_engine* e, void* stream, float* m, float* v, const uint8_t* group_of_block64,
                                    const realise_adamw_group* groups, int n_groups, int64_t step, const float* grad_norm_sq, float max_grad_norm);
 /* order `stream` behind every piece of a pending pipelined sweep (no-op without one): before a checkpoint, a state_dict, any access to
