@@ -546,20 +546,29 @@ def main():
         fsteps = max(5, args.steps)
         nom = fwd_flops_per_sentence(args.seq, mean_len) * B
         exe = fwd_flops_per_sentence(args.seq, mean_len, live) * B
-        for mode in ("eval", "train"):
+        exe_live = fwd_flops_per_sentence(args.seq, mean_len, live, rows_tiled if live_rows_on else 1.0) * B
+        for mode in ("eval", "train", "eval_live_rows"):
+            if mode == "eval_live_rows" and not live_rows_on:
+                continue
             model.train(mode == "train")
+            model.eval_live_rows = mode == "eval_live_rows"
             model.static_weights = True                      # weights do not change between these forwards
             with torch.no_grad():
                 for _ in range(2):
                     model(batch)
                 t = timed_loop(lambda i: model(batch), fsteps, world, dev)
             ms = 1e3 * t / fsteps
+            ex = exe_live if mode == "eval_live_rows" else exe
             fwd[mode] = {"ms": round(ms, 3), "sentences_per_s": round(B * world / (ms * 1e-3), 1),
                          "mfma_util_nominal": round(nom / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4),
-                         "mfma_util_executed": round(exe / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4)}
-        fwd["note"] = ("forward only, batch %d x seq %d per GPU, loss + logits computed; eval: BatchNorm running statistics, no dropout; "
-                       "train: batch statistics + dropout 0.1, no backward; target (BASELINE.json north_star): >= 0.40 bf16 MFMA "
-                       "utilisation" % (B, args.seq))
+                         "mfma_util_executed": round(ex / (ms * 1e-3) / (PEAK_BF16_TFLOPS * 1e12), 4)}
+        model.eval_live_rows = False
+        fwd["note"] = ("forward only, batch %d x seq %d per GPU, loss + logits computed; eval: BatchNorm running statistics, no dropout, every "
+                       "row of the padded batch (the reference's contract); train: batch statistics + dropout 0.1, no backward; "
+                       "eval_live_rows: the same evaluation forward with model.eval_live_rows = True - the transformer stacks over the rows "
+                       "up to every sentence's last attended position only (their logits and the loss bit-identical, the padding rows' "
+                       "logits unspecified: run.py:262-270 cuts predictions at `lengths`), nominal = the dense graph's FLOPs over its time; "
+                       "target (BASELINE.json north_star): >= 0.40 bf16 MFMA utilisation" % (B, args.seq))
         model.static_weights = False
         model.train()
 

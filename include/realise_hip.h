@@ -250,6 +250,10 @@ typedef struct {
                                * for bit; the logits rows behind that position are finite and meaningless (the reference never reads them:
                                * src/run.py:200, :262-270).  Engine knob 10 = 0 (the setter is declared in include/realise_hip_debug.h) computes every row. */
   const int32_t* n_alive_dev; /* DEVICE array [Tp] written by realise_build_pho (used when n_alive == NULL) */
+  int32_t eval_live_rows;     /* != 0 on an evaluation call (training == 0, bf16, B*S % 64 == 0): the transformer stacks run over the rows up to every
+                               * sentence's last position with masks == 1 (or loss_masks == 1) only, as training steps do - those rows' logits and the
+                               * loss are bit-identical to the dense forward's, the logits rows of the padding behind that position are finite and
+                               * meaningless (the reference's evaluation cuts its predictions at `lengths`: src/run.py:262-270).  Default 0: dense. */
   float* logits_f32_out;      /* nullable: [B*S, vocab] fp32 (device) - the logits widened to fp32, the dtype the reference returns them in
                                * (src/models.py:859); bf16 engines write them from the classifier kernel's epilogue (the same bf16-rounded
                                * values as logits_out), no pass over logits_out.  Needs logits_out. */

@@ -64,7 +64,7 @@ class Batch(C.Structure):
                 ("src_idx", C.c_void_p), ("masks", C.c_void_p), ("loss_masks", C.c_void_p), ("tgt_idx", C.c_void_p),
                 ("pho_idx", C.c_void_p), ("pho_perm", C.c_void_p), ("pho_lens_sorted", C.c_void_p),
                 ("n_alive", C.POINTER(C.c_int32)), ("loss_out", C.c_void_p), ("logits_out", C.c_void_p),
-                ("n_alive_dev", C.c_void_p), ("logits_f32_out", C.c_void_p)]
+                ("n_alive_dev", C.c_void_p), ("eval_live_rows", C.c_int32), ("logits_f32_out", C.c_void_p)]
 
 
 # every symbol include/realise_hip.h declares: name -> (restype, argtypes)

@@ -1330,6 +1330,15 @@ template <typename T> struct Engine : EngineBase {
     if (dead_ok) RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_t16), wp<int>(pl.live_n), wp<int>(pl.live_rlen), wp<int>(pl.live_rows)));
     // (the weight gradients of a live-row step must walk the same block list - only the grouped launch takes one: ADVICE round 4)
     rows_live = dead_ok && b.training && g_live_rows && g_wgrad_group && live16() && (H % 64) == 0 && (I % 64) == 0 && (int64_t)Tk * I * 2 < 0xFFFFFF00ll;
+    // Round 6, opt-in (realise_batch.eval_live_rows): an EVALUATION forward over the live rows as well.  The reference's evaluation reads
+    // the predictions of a sentence's real tokens only (run.py:262-270 cuts them at `lengths`; the loss counts loss_masks rows), so the
+    // transformer stacks need not compute the padding rows behind a sentence's last attended / loss position: their logits rows come
+    // out finite and meaningless, every other row and the loss bit-identical to the dense forward's (same kernels per row).
+    if (!b.training && !dead_ok && b.eval_live_rows && g_live_rows && live16() && b.masks != nullptr && (Tk % 64) == 0 && (H % 64) == 0 &&
+        (I % 64) == 0 && (int64_t)Tk * I * 2 < 0xFFFFFF00ll) {
+      RL_TRY(row_liveness(st, b.masks, b.loss_masks, pl.B, pl.S, wp<uint8_t>(pl.row_live), wp<int>(pl.live_t64), wp<int>(pl.live_t32), wp<int>(pl.live_t16), wp<int>(pl.live_n), wp<int>(pl.live_rlen), wp<int>(pl.live_rows)));
+      dead_ok = true; rows_live = true;      // (the tables exist; no backward follows an evaluation forward)
+    }
     const T* bert_h = nullptr;
     const bool ovl = cfg.model_type == 1 && g_branch_overlap && branches_ok();
     hipStream_t s_pho = ovl ? bst[0] : st, s_glyph = ovl ? bst[1] : st;

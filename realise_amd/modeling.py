@@ -443,6 +443,11 @@ class RealiseModule(nn.Module):
     # nothing but the engine may then touch parameters, gradients or optimizer moments; state_dict() / save_pretrained() /
     # load_state_dict() / zero_grad(set_to_none=False) / sync_optimizer() order the caller's stream behind the sweep first.
     pipeline_optimizer = False
+    # True: evaluation forwards compute the transformer stacks over the live rows only, as bf16 training steps do (realise_batch.
+    # eval_live_rows): the logits of a sentence's real tokens and the loss are bit-identical to the dense forward's, the logits rows of the
+    # padding behind its last attended position are finite and meaningless - what run.py:262-270 cuts off at `lengths` anyway.  Off by
+    # default (the reference returns defined values there); bench.py times both forms.
+    eval_live_rows = False
 
     def sync_optimizer(self):
         """order the current stream behind a pending pipelined optimizer sweep (no-op without one)"""
@@ -493,6 +498,7 @@ class RealiseModule(nn.Module):
         need_grad = training and tgt is not None and torch.is_grad_enabled()
         cb.training = 1 if training else 0
         cb.want_dlogits = 1 if need_grad else 0
+        cb.eval_live_rows = 1 if (not training and self.eval_live_rows) else 0
         self._step_seed += 1
         cb.seed = self._step_seed & 0xFFFFFFFFFFFFFFFF
         cb.src_idx, cb.masks = src.data_ptr(), masks.data_ptr()

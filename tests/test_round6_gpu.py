@@ -631,3 +631,38 @@ def test_pipelined_optimizer_sweep_gives_the_plain_sweeps_bits(layers, model_typ
         same(mid0[0][n], mid1[0][n], ("mid", n), 3 * 3e-4 * 1.5)
         assert (fin0[n].float() - fin1[n].float()).abs().mean().item() <= 2e-5, n
     assert o0["step"] == o1["step"]
+
+
+# ---------------------------------------------------------------------------------------------- live-row evaluation forward
+@pytest.mark.parametrize("B,S,with_labels", [(8, 64, True), (16, 128, True), (8, 64, False)])
+def test_live_row_evaluation_forward_matches_the_dense_one_on_every_real_token(B, S, with_labels):
+    """`model.eval_live_rows = True` (opt-in): an evaluation forward computes the transformer stacks over the rows up to every sentence's
+    last attended / loss position only, as bf16 training steps do.  Same kernels per row: the logits of every such row and the loss are
+    bit-identical to the dense forward's; the padding rows behind that position are finite (run.py:262-270 never reads them)."""
+    cfg = RealiseConfig(**SMALL)
+    sd = init_state_dict_numpy(cfg, seed=81)
+    b = cuda_batch(B, S, 700 + B)
+    if not with_labels:
+        b = {k: v for k, v in b.items() if k not in ("tgt_idx", "loss_masks")}
+    m = build(cfg, sd, "bf16", train=False)
+
+    def run(live):
+        m.eval_live_rows = live
+        with torch.no_grad():
+            out = m(b)
+        torch.cuda.synchronize()
+        return (float(out[0].item()) if with_labels else None), out[-1].clone()
+
+    l0, z0 = run(False)
+    l1, z1 = run(True)
+    l2, z2 = run(False)                      # (and the dense form again afterwards: stale rows in the workspace change nothing)
+    mk = b["masks"] == 1
+    if with_labels:
+        mk = mk | (b["loss_masks"] == 1)
+    pos = torch.arange(1, S + 1, device="cuda")[None, :]
+    last = (mk * pos).max(dim=1).values
+    real = (torch.arange(S, device="cuda")[None, :] < last[:, None])
+    assert real.float().mean().item() < 0.95, "the batch needs padding for this test to mean anything"
+    assert l0 == l1 == l2
+    assert torch.equal(z0[real], z1[real]) and torch.equal(z0, z2)
+    assert torch.isfinite(z1).all()
