@@ -795,7 +795,7 @@ template <typename T> struct Engine : EngineBase {
       ln.word = so.word >= 0 ? pp(so.word) : nullptr;
       ln.pos = pp(so.pos); ln.type0 = pp(so.type); ln.pos_zero = pos_zero;
       ln.gamma = pp(so.ln_g); ln.beta = pp(so.ln_b); ln.eps = cfg.ln_eps;
-      ln.y = wp<T>(a.emb_y); ln.xhat = wp<T>(a.emb_xhat); ln.rstd = wp<float>(a.emb_rstd);
+      ln.y = wp<T>(a.emb_y); ln.xhat = bwd_follows() ? wp<T>(a.emb_xhat) : nullptr; ln.rstd = wp<float>(a.emb_rstd);      // (xhat: the backward's operand)
       ln.drop = site(sid * 1000 + 900, cfg.hidden_dropout);
       RL_TRY(ln_fwd<T>(st, ln));
     }
@@ -824,7 +824,8 @@ template <typename T> struct Engine : EngineBase {
       RL_TRY(dense_resid_ln(st, sid, wp<T>(t.ctx), H, sp<T>(w.ao_w), pp(o.ao_b), x, site(sid * 1000 + (int)l * 10 + 2, cfg.hidden_dropout),
                             pp(o.ao_ln_g), pp(o.ao_ln_b), wp<T>(t.s1), wp<float>(t.rstd1), wp<T>(t.y1)));
       {  // BertIntermediate (modeling_bert.py:326-329)
-        EpiParams<T> ep; ep.mode = EPI_GELU; ep.out = wp<T>(t.post); ep.out2 = wp<T>(t.pre); ep.ldo = I; ep.bias = pp(o.in_b);
+        // (the pre-activation is what the backward's GELU' reads: a forward nothing differentiates - evaluation, no_grad - does not store it)
+        EpiParams<T> ep; ep.mode = EPI_GELU; ep.out = wp<T>(t.post); ep.out2 = bwd_follows() ? wp<T>(t.pre) : nullptr; ep.ldo = I; ep.bias = pp(o.in_b);
         RL_TRY(nt_rows(st, wp<T>(t.y1), H, sp<T>(w.in_w), H, Tk, I, H, ep));
       }
       // BertOutput (modeling_bert.py:339-343)
@@ -1256,6 +1257,8 @@ template <typename T> struct Engine : EngineBase {
   // a freshly planned workspace: the self-cleaning LayerNorm-backward accumulators start at zero
   int ln_epoch[3] = {0, 0, 0};
   // dense -> dropout -> + residual -> LayerNorm (modeling_bert.py:273-277, 339-343): one launch when the fused form applies
+  // the forward being enqueued is one a backward can follow (realise_engine_backward checks the same): it must leave what that pass reads
+  bool bwd_follows() const { return last.training && last.tgt_idx != nullptr && last.want_dlogits; }
   int dense_resid_ln(hipStream_t st, int sid, const T* a, int K, const T* w, const float* bias, const T* resid, const DropParams& drop,
                      const float* gamma, const float* beta, T* s_xhat, float* rstd, T* y) {
     const int Tk = pl.B * pl.S;
@@ -1275,7 +1278,7 @@ template <typename T> struct Engine : EngineBase {
     }
     RL_TRY(nt_rows(st, a, K, w, K, Tk, H, K, ep));
     LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = s_xhat; ln.gamma = gamma; ln.beta = beta;
-    ln.eps = cfg.ln_eps; ln.y = y; ln.xhat = s_xhat; ln.rstd = rstd;
+    ln.eps = cfg.ln_eps; ln.y = y; ln.xhat = bwd_follows() ? s_xhat : nullptr; ln.rstd = rstd;      // (a forward nothing differentiates does not store the normalised rows)
     if (rows_live && (Tk % 16) == 0) ln.row_live = live_rows();      // x holds fresh rows in the listed blocks only: the others are not worth a pass
     return ln_fwd<T>(st, ln);
   }
@@ -1360,7 +1363,7 @@ template <typename T> struct Engine : EngineBase {
       {
         LnFwdArgs<T> ln; ln.rows = Tk; ln.H = H; ln.x = res; ln.row_index = wp<int>(pl.gu_inv);      // token t reads its glyph's row
         ln.gamma = pp(L.res_ln_g); ln.beta = pp(L.res_ln_b); ln.eps = cfg.ln_eps;
-        ln.y = wp<T>(pl.res_h); ln.xhat = wp<T>(pl.res_xhat); ln.rstd = wp<float>(pl.res_rstd);
+        ln.y = wp<T>(pl.res_h); ln.xhat = bwd_follows() ? wp<T>(pl.res_xhat) : nullptr; ln.rstd = wp<float>(pl.res_rstd);
         RL_TRY(ln_fwd<T>(s_glyph, ln));
       }
       if (ovl && g_fwd_order == 1) { RL_TRY(stack_forward(st, 0, L.bert, sh_bert, pl.bert, last.src_idx, nullptr, 0, &bert_h)); top = bert_h; }

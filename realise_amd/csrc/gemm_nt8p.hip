@@ -23,6 +23,7 @@ namespace rl {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 constexpr int EPI_STORE_F32X = 8;      // template value only (not an EpiMode): EPI_STORE + EpiParams::out_f32
+constexpr int EPI_GELU_NOPRE = 9;      // template value only: EPI_GELU without the pre-activation store (out2 == nullptr: no backward follows)
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 // (the host pass of hipcc parses kernel bodies too and silently drops a kernel stub whose body holds AMDGPU register constraints
@@ -310,8 +311,8 @@ __device__ __forceinline__ void nt8p_body(const bf16_t* __restrict__ A, int64_t 
           const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
           __builtin_amdgcn_raw_buffer_store_b128(o, rs, off, 0, 0);
         };
-        if constexpr (EPI == EPI_GELU) {
-          emit(rsO2, v0, v1);                                    // pre-activation
+        if constexpr (EPI == EPI_GELU || EPI == EPI_GELU_NOPRE) {
+          if constexpr (EPI == EPI_GELU) emit(rsO2, v0, v1);     // pre-activation (what the backward's GELU' reads; not stored when no backward follows)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v0[e] = gelu_fwd<bf16_t>(v0[e]); v1[e] = gelu_fwd<bf16_t>(v1[e]); }
         }
@@ -362,7 +363,7 @@ bool nt8p_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t ld
   if (ep.col_scale != nullptr) return false;
   if (ep.out_f32 != nullptr && (ep.mode != EPI_STORE || ep.accumulate || (N % 4) != 0 || (ep.ldo_f32 % 4) != 0 || ep.ldo_f32 < N ||
                                 (int64_t)M * ep.ldo_f32 * 4 >= 0xFFFFFF00ll)) return false;
-  const bool mode_ok = (ep.mode == EPI_STORE && !ep.accumulate) || (ep.mode == EPI_GELU && ep.out2 != nullptr) ||
+  const bool mode_ok = (ep.mode == EPI_STORE && !ep.accumulate) || ep.mode == EPI_GELU ||
                        (ep.mode == EPI_GELU_BWD && !ep.accumulate && ep.aux != nullptr);
   return mode_ok && ep.alpha == 1.0f && ep.rm_hw_shift < 0 && (K % 64) == 0 && K >= 128 && (N % 8) == 0 && (ep.ldo % 8) == 0 &&
          (ep.aux == nullptr || (ep.ldaux % 8) == 0) && (lda % 8) == 0 && (ldb % 8) == 0 && M >= 1 && N >= 8 &&
@@ -396,7 +397,9 @@ int gemm_nt8p(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int
     case EPI_STORE:
       if (ep.out_f32 != nullptr) return launch_nt8p<PCfg256x192, EPI_STORE_F32X>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
       return launch_nt8p<PCfg256x192, EPI_STORE>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
-    case EPI_GELU: return launch_nt8p<PCfg256x192, EPI_GELU>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
+    case EPI_GELU:
+      if (ep.out2 == nullptr) return launch_nt8p<PCfg256x192, EPI_GELU_NOPRE>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
+      return launch_nt8p<PCfg256x192, EPI_GELU>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
     case EPI_GELU_BWD: return launch_nt8p<PCfg256x192, EPI_GELU_BWD>(st, A, lda, B, ldb, M, N, K, ep, g_nt8p_wgs);
     default: return RL_ERR_ARG;
   }
