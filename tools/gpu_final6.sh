@@ -14,7 +14,7 @@ bash tools/gpu_rocprof.sh fs --no-overlap --no-forward --no-glyph256 > /dev/null
 bash tools/gpu_rocprof.sh fo --no-forward --no-glyph256 > /dev/null 2>&1; cp gpurun_out/prof_fo/kernel_summary.md $O/kernel_stats_overlap.md
 tail -1 $O/kernel_stats_serial.md; tail -1 $O/kernel_stats_overlap.md
 rm -rf gpurun_out/prof_fs gpurun_out/prof_fo
-python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; cut -c1-300 $O/bench.json
+python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; cut -c1-300 $O/bench.json; cp $O/bench.json profiles/round6_final_bench.json
 python -c "import json;d=json.load(open('$O/bench.json'));r=d['roofline'];print('roofline', r['frac'], r['achieved'], r['traffic'], r.get('traffic_source'), r.get('rocprof'))"
 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-parity --no-dense-rows-ab --no-forward --no-glyph256 --dump-launches $O/launches.json > /dev/null 2>&1
 head -6 $O/pmc_counters.md | cut -c1-220
