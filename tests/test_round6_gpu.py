@@ -627,6 +627,8 @@ def test_pipelined_optimizer_sweep_gives_the_plain_sweeps_bits(layers, model_typ
     # whose gradient is all noise by up to lr per step in either direction - bounded drift, not bits
     assert all(abs(a - b) <= 1e-3 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
     for n in fin0:
+        if "running_" in n or "num_batches" in n:      # (BatchNorm running statistics follow the activations, not the optimizer: block 5
+            continue                                   #  averages 8 x 64 samples per channel and moves with every rounding step upstream)
         same(fin0[n], fin1[n], n, 6 * 3e-4 * 1.5)
         same(mid0[0][n], mid1[0][n], ("mid", n), 3 * 3e-4 * 1.5)
     # (no bound on the mean drift: a tensor whose true gradient is zero - the attention key bias, which softmax cancels - is moved by AdamW
