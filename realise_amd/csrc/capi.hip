@@ -180,7 +180,7 @@ void realise_set_ln(int key, int value) {
   if (key == 0) set_ln_fast(value); else if (key == 1) set_ln_bwd_blocks(value); else if (key == 2) set_bn_fast(value); else if (key == 3) set_bn_chunks(value); else if (key == 4) set_ce_fast(value); else if (key == 5) set_ln_v2(value); else if (key == 6) set_adamw_reg(value);
 }
 void realise_set_engine(int key, int value) { if (key == 0) set_fwd_order(value); else if (key >= 1 && key <= 3) set_stream_priority(key - 1, value); else if (key == 4) set_cls_compact(value); else if (key == 5) set_skip_dead(value); else if (key == 6) set_cls_splitk(value); else if (key == 7) set_tn_group8(value); else if (key == 8) set_ln_fuse(value); else if (key == 9) set_gru_fuse(value); else if (key == 10) set_live_rows(value); else if (key == 11) set_streamk(value); else if (key == 12) set_streamk_min(value); else if (key == 13) set_glyph_fuse(value); else if (key == 14) set_bn_fold(value); else if (key == 15) set_opt_pipe(value); }
-void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); else if (key == 2) set_nt8_single_round(value); else if (key == 3) set_nt8_live_gc(value); else if (key == 4) set_nt8_epi_pre(value); else if (key == 5) set_nt8_live_big(value); else if (key == 6) set_tn_jmajor(value); else if (key == 7) set_nt8_cu_pair(value); }
+void realise_set_nt8p(int key, int value) { if (key == 0) set_nt8p_order(value); else if (key == 1) set_nt8p_wgs(value); else if (key == 2) set_nt8_single_round(value); else if (key == 3) set_nt8_live_gc(value); else if (key == 4) set_nt8_epi_pre(value); else if (key == 5) set_nt8_live_big(value); else if (key == 6) set_tn_jmajor(value); else if (key == 7) set_nt8_cu_pair(value); else if (key == 8) set_nt8_l2_prefetch(value); }
 void realise_set_tn_probe(int mode) { set_tn_probe(mode); }
 void realise_set_attn_probe(int mode) { set_attn_probe(mode); }
 void realise_set_tn_split(int n) { set_tn_split(n); }

@@ -72,6 +72,7 @@ template <typename T> struct EpiParams {
   // 256 x 192 kernel only: gemm_nt8p; every other launch form refuses it)
   float* out_f32 = nullptr;
   int64_t ldo_f32 = 0;
+  int l2_prefetch = 0;          // set by the launcher (realise_set_nt8p key 8, probe): surplus workgroups of a narrow row-list launch prefetch their XCD's operand lines into the L2
   int cu_pair = 0;              // set by the launcher (realise_set_nt8p key 7): tile order that puts two column tiles of a tile row on one CU (common.h cu_pair_local)
   int bias_first = 0;           // set by the launcher (realise_set_nt8p key 4): alpha / bias go into the accumulators before the epilogue's LDS transposes
   // K4 (BertSelfOutput / BertOutput, modeling_bert.py:273-277, 339-343): EPI_DROP_RESID followed by the LayerNorm of the row in the SAME
@@ -449,6 +450,7 @@ bool nt8s_supported(int M, int N, int K, const EpiParams<bf16_t>& ep, int64_t ld
 int gemm_nt8s(hipStream_t st, const bf16_t* A, int64_t lda, const bf16_t* B, int64_t ldb, int M, int N, int K, const EpiParams<bf16_t>& ep);
 void set_nt8p_wgs(int n);
 void set_nt8_epi_pre(int on);      // 1 (default): alpha / bias into the accumulators before the 8-wave kernels' epilogue transposes (one bias fetch per wave, no per-item waits)
+void set_nt8_l2_prefetch(int v);  // realise_set_nt8p key 8 (probe): see gemm_nt8.hip nt8_l2_prefetch
 void set_nt8_cu_pair(int on);    // realise_set_nt8p key 7 (probe): two-per-CU 8-wave kernels pair the column tiles of a tile row on one CU
 void set_tn_jmajor(int on);       // realise_set_nt8p key 6: grouped weight gradients walk a problem's tiles along its LARGER operand's panels (1; default 0: measured level)
 void set_nt8_live_big(int v);     // measurement knob (realise_set_nt8p key 5): wide row-list launches on 256 x 256 one-per-CU tiles

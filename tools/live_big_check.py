@@ -13,7 +13,7 @@ from realise_amd.modeling import SpellBertPho2ResArch3
 
 lib = _capi.load()
 KEY = int(sys.argv[1]) if len(sys.argv) > 1 else 5      # realise_set_nt8p key under test (5: 256 x 256 row-list tiles, probe build; 7: CU pairing)
-VALUES = (1, 2) if KEY == 5 else (1,)
+VALUES = (1, 2) if KEY == 5 else ((10 + (4 << 4),) if KEY == 8 else (1,))
 cfg = RealiseConfig(num_hidden_layers=2, pho_layers=1, out_layers=1)
 sd = init_state_dict_numpy(cfg, seed=5)
 b = synthetic_batch(64, 128, seed=77)
